@@ -1,0 +1,72 @@
+"""ctypes binding of libal3d_hip.so (the C ABI in include/al3d.h).
+
+There is deliberately no fallback: if the shared library is missing or a symbol
+is absent the import raises, and every entry point raises ``Al3dError`` on a
+non-zero status.  Build with ``python __graft_entry__.py`` (or ``make -C csrc``).
+"""
+import ctypes
+import os
+
+# Load PyTorch's bundled HIP runtime first: libal3d_hip.so needs libamdhip64.so.7 by
+# SONAME, and one process must not end up with two HIP runtimes.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libal3d_hip.so")
+
+c_i64, c_int, c_dbl, c_flt, c_p = (ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                   ctypes.c_float, ctypes.c_void_p)
+
+
+class Al3dError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/al3d.h one for one
+SIGNATURES = {
+    "al3d_abi_version": (c_int, []),
+    "al3d_last_error": (ctypes.c_char_p, []),
+    "al3d_l1_distance_f32": (c_int, [c_p, c_i64, c_i64, c_int, c_p, c_p]),
+    "al3d_combine_maps_f64": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_int, c_dbl, c_dbl, c_dbl,
+                                      c_dbl, c_p, c_p]),
+    "al3d_euclid_map_f64": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
+    "al3d_max_finite_f64": (c_int, [c_p, c_i64, c_p, c_p]),
+    "al3d_greedy_workspace_bytes": (c_i64, [c_i64, c_int]),
+    "al3d_greedy_kcenter_f64": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_dbl, c_dbl,
+                                        c_dbl, c_int, c_p, c_i64, c_p, c_p, c_p]),
+    "al3d_greedy_kcenter_f32": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_dbl, c_dbl,
+                                        c_dbl, c_int, c_p, c_i64, c_p, c_p, c_p]),
+    "al3d_knn_2d_f64": (c_int, [c_p, c_i64, c_int, c_p, c_p, c_p]),
+    "al3d_apsp_workspace_bytes": (c_i64, [c_i64, c_int]),
+    "al3d_apsp_knn_f64": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (no compute)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Al3dError(
+            f"{LIB_PATH} not found: the HIP extension is not built. "
+            "Run `python __graft_entry__.py` (build()) first; there is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().al3d_last_error().decode("utf-8", "replace")
+        raise Al3dError(f"{what} failed with status {status}: {msg}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

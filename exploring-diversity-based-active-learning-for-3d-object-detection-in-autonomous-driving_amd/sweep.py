@@ -1,0 +1,90 @@
+"""Unlabeled-pool sweep: detector forward over every frame -> BEV embeddings.
+
+Replaces the reference's ``buffer_pred`` loops (det3d/selectors/feature_selector.py:51-85).
+New capability: under ``torch.distributed`` each rank sweeps the
+frames its sampler hands it and one RCCL all-gather restores the single-process
+``[N,512]`` tensor in dataset order on every rank.
+"""
+import torch
+
+
+def example_to_device(example, device, non_blocking=False):
+    """Host dict -> device (reference det3d/torchie/apis/train.py:84-110)."""
+    out = {}
+    for k, v in example.items():
+        if k in ("anchors", "anchors_mask", "reg_targets", "reg_weights", "labels"):
+            out[k] = [t.to(device, non_blocking=non_blocking) for t in v]
+        elif isinstance(v, torch.Tensor):
+            out[k] = v.to(device, non_blocking=non_blocking)
+        elif k == "calib":
+            out[k] = {k1: v1.to(device, non_blocking=non_blocking) for k1, v1 in v.items()}
+        else:
+            out[k] = v
+    return out
+
+
+def gap_embedding(neck_out):
+    """``x.mean(-1).mean(-1)``: mean over W then over H (A.1 quirk 11)."""
+    return neck_out.mean(dim=-1).mean(dim=-1)
+
+
+def gather_in_dataset_order(local_feats, local_index, num_frames):
+    """All-gather per-rank rows and scatter them back to dataset order.
+
+    ``local_index[r]`` is the dataset index of ``local_feats[r]``.  Ranks may hold
+    different row counts (padding rows carry index -1) and sampler wrap-around
+    duplicates are harmless: every copy of a frame holds the same embedding.
+    """
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        out = torch.empty((num_frames, local_feats.shape[1]), dtype=local_feats.dtype,
+                          device=local_feats.device)
+        out[local_index] = local_feats
+        return out
+    world = dist.get_world_size()
+    dev = local_feats.device
+    cnt = torch.tensor([local_feats.shape[0]], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    rows = int(max(int(c.item()) for c in cnts))
+    c = local_feats.shape[1]
+    pad_f = torch.zeros((rows, c), dtype=local_feats.dtype, device=dev)
+    pad_i = torch.full((rows,), -1, dtype=torch.int64, device=dev)
+    pad_f[: local_feats.shape[0]] = local_feats
+    pad_i[: local_index.shape[0]] = local_index
+    all_f = torch.empty((world * rows, c), dtype=local_feats.dtype, device=dev)
+    all_i = torch.empty((world * rows,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_f, pad_f)
+    dist.all_gather_into_tensor(all_i, pad_i)
+    keep = all_i >= 0
+    out = torch.empty((num_frames, c), dtype=local_feats.dtype, device=dev)
+    out[all_i[keep]] = all_f[keep]
+    return out
+
+
+def sweep_embeddings(detector, dataloader, device, num_frames=None):
+    """Run ``detector(example, return_loss=False, estimate=True)`` over the loader and
+    return the ``[N,512]`` embeddings in dataset order (on ``device``)."""
+    feats, index = [], []
+    seen = 0
+    sampler_idx = None
+    sampler = getattr(dataloader, "sampler", None)
+    if sampler is not None and hasattr(sampler, "__iter__") and not isinstance(
+            sampler, torch.utils.data.SequentialSampler):
+        sampler_idx = list(iter(sampler))
+    with torch.no_grad():
+        for data_batch in dataloader:
+            example = example_to_device(data_batch, device, non_blocking=False)
+            _, middle = detector(example, return_loss=False, estimate=True)
+            emb = gap_embedding(middle[-1])
+            feats.append(emb)
+            b = emb.shape[0]
+            if sampler_idx is not None:
+                index.extend(sampler_idx[seen:seen + b])
+            else:
+                index.extend(range(seen, seen + b))
+            seen += b
+    local = torch.cat(feats, dim=0)
+    idx = torch.as_tensor(index, dtype=torch.int64, device=local.device)
+    n = num_frames if num_frames is not None else int(idx.max().item()) + 1
+    return gather_in_dataset_order(local, idx, n)

@@ -1,0 +1,121 @@
+/*
+ * al3d.h -- C ABI of libal3d_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hot path of the diversity-based active-learning
+ * selector: every pointer is a DEVICE pointer unless stated otherwise, every
+ * size is explicit, outputs and workspaces are caller-allocated, `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Functions return 0 on
+ * success or a negative AL3D_E* code; al3d_last_error() returns a thread-local
+ * message.  No exceptions, no global state besides the error string, no
+ * allocation and no synchronisation inside any entry point (graph-capturable).
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the reference repository root).
+ */
+#ifndef AL3D_H_
+#define AL3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AL3D_OK 0
+#define AL3D_EINVAL (-1)   /* bad argument (shape, alignment, enum) */
+#define AL3D_ELAUNCH (-2)  /* HIP launch failure */
+#define AL3D_ENOSPC (-3)   /* caller-provided capacity too small */
+
+/* normalize / aggregate enums of al3d_combine_maps_f64 */
+#define AL3D_NORM_NONE 0
+#define AL3D_NORM_EXP 1     /* 1 - exp(-x) */
+#define AL3D_NORM_LINEAR 2  /* x / scale   */
+#define AL3D_AGG_SUM 0
+#define AL3D_AGG_MIN 1
+#define AL3D_AGG_MAX 2
+
+/* greedy status words written to out_meta[1] */
+#define AL3D_GREEDY_OK 0
+#define AL3D_GREEDY_DUPLICATE (-1) /* reference `assert selected_index not in ...` would fire */
+#define AL3D_GREEDY_FULL (-2)      /* out_idx capacity exhausted */
+
+int al3d_abi_version(void);
+const char* al3d_last_error(void);
+
+/* ---------------------------------------------------------------- selector */
+
+/* Pairwise embedding distance map, float32 [n,n] from feats [n,c].
+ * Replaces FeatureSelector.get_feature_distance_map
+ * (det3d/selectors/feature_selector.py:87-109; same body in
+ * spatial_temporal_feature_selector.py:97-111): p==1 -> sum |a-b|,
+ * p==2 -> sum sqrt((a-b)^2)  (also L1, bug-compatible).  Sum order c=0..C-1. */
+int al3d_l1_distance_f32(const float* feats, int64_t n, int64_t c, int p,
+                         float* out, void* stream);
+
+/* Normalise + aggregate the spatial (f64 [n,n] or NULL), temporal (derived on
+ * the fly from temporal_id [n] or NULL: |i-j| if ids equal else 1e6) and
+ * feature (f32 [n,n] or NULL) terms into out f64 [n,n].
+ * Replaces det3d/selectors/spatial_temporal_selector.py:109-155,
+ * spatial_temporal_feature_selector.py:187-219, spatial_feature_selector.py:188-197,
+ * temporal_selector.py:56-63. */
+int al3d_combine_maps_f64(const double* spatial, const int64_t* temporal_id, const float* feat,
+                          int64_t n, int normalize, int aggregate,
+                          double lambda_t, double lambda_f,
+                          double spatial_scale, double temporal_scale,
+                          double* out, void* stream);
+
+/* Same-location Euclidean map, f64 [n,n]: sqrt(dx^2+dy^2) if loc_id equal else 1e6.
+ * Replaces det3d/selectors/euclidean_spatial_selector.py:95-106. */
+int al3d_euclid_map_f64(const double* xy, const int64_t* loc_id, int64_t n, double* out,
+                        void* stream);
+
+/* max over finite entries of a[0..count) -> *out_dev (device f64; -inf if none).
+ * Replaces `spatial_distance_map[spatial_distance_map != np.inf].max()`
+ * (spatial_temporal_selector.py:139). */
+int al3d_max_finite_f64(const double* a, int64_t count, double* out_dev, void* stream);
+
+/* Greedy k-center (farthest-point) selection under a cost budget, one
+ * persistent workgroup.  Replaces the loop at
+ * det3d/selectors/spatial_temporal_selector.py:157-193 (float64 numpy) and
+ * det3d/selectors/feature_selector.py:142-172 (float32 torch).
+ *   D, seed_map   [n,n] row-major; seed_map initialises fps (== D except
+ *                 SpatialFeatureSelector)
+ *   seeded        [n_seeded] already-sampled ids; if n_seeded == 0, `first` is
+ *                 the initial pick (python random.choice on the host)
+ *   box_cost      [n] f64 = n_boxes[i] * cost_b
+ *   out_idx       [cap] picks in order;  out_meta[0] = count, out_meta[1] = status
+ *   workspace     >= al3d_greedy_workspace_bytes(n, elem_size) bytes */
+int64_t al3d_greedy_workspace_bytes(int64_t n, int elem_size);
+int al3d_greedy_kcenter_f64(const double* D, const double* seed_map, int64_t n,
+                            const int64_t* seeded, int64_t n_seeded, int64_t first,
+                            const double* box_cost, double cost_f, double start_cost,
+                            double budget_int, int check_seeded,
+                            int64_t* out_idx, int64_t cap, int64_t* out_meta,
+                            void* workspace, void* stream);
+int al3d_greedy_kcenter_f32(const float* D, const float* seed_map, int64_t n,
+                            const int64_t* seeded, int64_t n_seeded, int64_t first,
+                            const double* box_cost, double cost_f, double start_cost,
+                            double budget_int, int check_seeded,
+                            int64_t* out_idx, int64_t cap, int64_t* out_meta,
+                            void* workspace, void* stream);
+
+/* Exact k-nearest neighbours (self included) of 2-D points, ascending
+ * (distance, index).  Replaces scipy cKDTree(locations).query(locations, k+1)
+ * (spatial_temporal_selector.py:97-98).  xy [n,2] f64 -> knn_d [n,kq] f64,
+ * knn_i [n,kq] i64 (padded with inf / n when n < kq). kq <= 32. */
+int al3d_knn_2d_f64(const double* xy, int64_t n, int kq, double* knn_d, int64_t* knn_i,
+                    void* stream);
+
+/* All-pairs shortest paths over the symmetrised kNN graph (zero-length edges
+ * dropped), f64 [n,n], unreachable = +inf.  Bit-identical to Dijkstra's
+ * left-to-right path sums.  Replaces the dense edge-matrix build +
+ * scipy.sparse.csgraph.shortest_path(directed=False, method="D")
+ * (spatial_temporal_selector.py:95-104). */
+int64_t al3d_apsp_workspace_bytes(int64_t n, int kq);
+int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
+                      double* out, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AL3D_H_ */

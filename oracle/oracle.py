@@ -1,0 +1,173 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU oracle (libal3d_oracle.so).
+
+Imported by tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+bench.py, never by the product package.  ``build()`` compiles the plain-C
+restatement with gcc (oracle/Makefile).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libal3d_oracle.so")
+_lib = None
+
+c_i64, c_int, c_dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_double
+_P = ctypes.c_void_p
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.run(["make", "-C", HERE, "-B", "libal3d_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.al3d_oracle_exp_f64.restype = c_dbl
+        _lib.al3d_oracle_exp_f64.argtypes = [c_dbl]
+        _lib.al3d_oracle_exp_f32.restype = ctypes.c_float
+        _lib.al3d_oracle_exp_f32.argtypes = [ctypes.c_float]
+        _lib.al3d_oracle_knn_csr.restype = c_i64
+        _lib.al3d_oracle_max_temporal_distance.restype = c_i64
+        _lib.al3d_oracle_max_finite.restype = c_dbl
+        for f in ("al3d_oracle_greedy_f64", "al3d_oracle_greedy_f32"):
+            getattr(_lib, f).restype = c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def exp_f64(x):
+    x = _c(x, np.float64)
+    out = np.empty_like(x)
+    lib().al3d_oracle_exp_f64_array(_p(x), c_i64(x.size), _p(out))
+    return out
+
+
+def ego_xy(car_from_global):
+    c = _c(car_from_global, np.float64)
+    n = c.shape[0]
+    xy = np.empty((n, 2), dtype=np.float64)
+    lib().al3d_oracle_ego_xy(_p(c), c_i64(n), _p(xy))
+    return xy
+
+
+def knn(xy, kq):
+    xy = _c(xy, np.float64)
+    n = xy.shape[0]
+    d = np.empty((n, kq), dtype=np.float64)
+    i = np.empty((n, kq), dtype=np.int64)
+    lib().al3d_oracle_knn(_p(xy), c_i64(n), c_int(kq), _p(d), _p(i))
+    return d, i
+
+
+def knn_csr(knn_d, knn_i):
+    n, kq = knn_d.shape
+    indptr = np.empty(n + 1, dtype=np.int64)
+    indices = np.empty(2 * n * kq, dtype=np.int64)
+    weights = np.empty(2 * n * kq, dtype=np.float64)
+    nnz = lib().al3d_oracle_knn_csr(_p(_c(knn_d, np.float64)), _p(_c(knn_i, np.int64)),
+                                    c_i64(n), c_int(kq), _p(indptr), _p(indices), _p(weights))
+    return indptr, indices[:nnz].copy(), weights[:nnz].copy()
+
+
+def apsp(indptr, indices, weights, row0=0, row1=None):
+    n = indptr.shape[0] - 1
+    row1 = n if row1 is None else row1
+    out = np.empty((row1 - row0, n), dtype=np.float64)
+    lib().al3d_oracle_apsp(_p(_c(indptr, np.int64)), _p(_c(indices, np.int64)),
+                           _p(_c(weights, np.float64)), c_i64(n), c_i64(row0), c_i64(row1),
+                           _p(out))
+    return out
+
+
+def spatial_map(xy, k=8):
+    """kNN(k) graph geodesics, f64 [N,N] (spatial_temporal_selector.py:65-107)."""
+    d, i = knn(xy, k + 1)
+    return apsp(*knn_csr(d, i))
+
+
+def euclid_map(xy, loc_id):
+    xy = _c(xy, np.float64)
+    loc_id = _c(loc_id, np.int64)
+    n = xy.shape[0]
+    out = np.empty((n, n), dtype=np.float64)
+    lib().al3d_oracle_euclid_map(_p(xy), _p(loc_id), c_i64(n), _p(out))
+    return out
+
+
+def temporal_map(ids):
+    ids = _c(ids, np.int64)
+    n = ids.shape[0]
+    out = np.empty((n, n), dtype=np.float64)
+    lib().al3d_oracle_temporal_map(_p(ids), c_i64(n), _p(out))
+    return out
+
+
+def max_temporal_distance(run_id):
+    run_id = _c(run_id, np.int64)
+    return int(lib().al3d_oracle_max_temporal_distance(_p(run_id), c_i64(run_id.shape[0])))
+
+
+def max_finite(a):
+    a = _c(a, np.float64)
+    return float(lib().al3d_oracle_max_finite(_p(a), c_i64(a.size)))
+
+
+NORMALIZE = {None: 0, "none": 0, "exp": 1, "linear": 2}
+AGGREGATE = {"sum": 0, "min": 1, "max": 2}
+
+
+def combine(n, spatial=None, temporal_id=None, feat=None, normalize="exp", aggregate="sum",
+            lambda_t=1.0, lambda_f=1.0, spatial_scale=1.0, temporal_scale=1.0):
+    spatial = _c(spatial, np.float64)
+    temporal_id = _c(temporal_id, np.int64)
+    feat = _c(feat, np.float32)
+    out = np.empty((n, n), dtype=np.float64)
+    lib().al3d_oracle_combine(_p(spatial), _p(temporal_id), _p(feat), c_i64(n),
+                              c_int(NORMALIZE[normalize]), c_int(AGGREGATE[aggregate]),
+                              c_dbl(lambda_t), c_dbl(lambda_f), c_dbl(spatial_scale),
+                              c_dbl(temporal_scale), _p(out))
+    return out
+
+
+def l1_map_f32(feats, p=2):
+    feats = _c(feats, np.float32)
+    n, c = feats.shape
+    out = np.empty((n, n), dtype=np.float32)
+    lib().al3d_oracle_l1_map_f32(_p(feats), c_i64(n), c_i64(c), c_int(p), _p(out))
+    return out
+
+
+def greedy(D, seeded, first, box_cost, cost_f, start_cost, budget_int, seed_map=None,
+           check_seeded=False, cap=None):
+    """Returns (status, picks).  status 0 ok, -1 duplicate-pick assertion, -2 capacity."""
+    assert D.dtype in (np.float64, np.float32) and D.flags.c_contiguous
+    n = D.shape[0]
+    seed_map = D if seed_map is None else np.ascontiguousarray(seed_map, dtype=D.dtype)
+    seeded = np.ascontiguousarray(seeded, dtype=np.int64)
+    box_cost = _c(box_cost, np.float64)
+    cap = n + 1 if cap is None else cap
+    out = np.empty(cap, dtype=np.int64)
+    cnt = c_i64(0)
+    fn = lib().al3d_oracle_greedy_f64 if D.dtype == np.float64 else lib().al3d_oracle_greedy_f32
+    rc = fn(_p(D), _p(seed_map), c_i64(n), _p(seeded), c_i64(seeded.shape[0]), c_i64(first),
+            _p(box_cost), c_dbl(cost_f), c_dbl(start_cost), c_dbl(budget_int),
+            c_int(1 if check_seeded else 0), _p(out), c_i64(cap), ctypes.byref(cnt))
+    return int(rc), out[:cnt.value].copy()
