@@ -115,6 +115,29 @@ int64_t al3d_apsp_workspace_bytes(int64_t n, int kq);
 int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
                       double* out, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------- detector: dense */
+
+/* NHWC f32 convolution on the fp32 matrix cores with fused per-channel
+ * y = conv*scale[c] + shift[c] (+ReLU).  in [B,H,W,Cin]; wgt [Cout,k*k,Cin];
+ * out [B,OH,OW,ldc] written at channels [coff, coff+Cout).  Cin % 32 == 0.
+ * Replaces the Conv2d+BatchNorm2d(eval)+ReLU triples of RPN
+ * (det3d/models/necks/rpn.py:124-142) and the 1x1 task heads
+ * (det3d/models/bbox_heads/mg_head.py:215-231; scale=NULL, shift=bias, relu=0). */
+int al3d_conv2d_nhwc_f32(const float* in, const float* wgt, const float* scale, const float* shift,
+                         float* out, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                         int pad, int ldc, int coff, int relu, void* stream);
+
+/* ConvTranspose2d(kernel 2, stride 2) + scale/shift (+ReLU), NHWC f32.
+ * in [B,H,W,Cin]; wgt [Cout,4,Cin] with tap = dy*2+dx; out [B,2H,2W,ldc].
+ * Replaces RPN deblock 1 (det3d/models/necks/rpn.py:79-93). */
+int al3d_deconv2x2_nhwc_f32(const float* in, const float* wgt, const float* scale,
+                            const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                            int ldc, int coff, int relu, void* stream);
+
+/* BEV embedding: mean over W then over H of an NHWC map, [B,H,W,C] -> [B,C].
+ * Replaces `fpn_feats[-1].mean(-1).mean(-1)` (det3d/selectors/feature_selector.py:68-71). */
+int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,76 @@
+"""GPU suite: MFMA dense conv / deconv / GAP kernels against a plain PyTorch fp32 CPU
+reference of the same op (floating point => tolerance, stated per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# fp32 products, fp32 accumulation in a different order than the CPU reference:
+# |err| <= ~K * eps * sum|a*b|; K <= 2304 here.
+RTOL, ATOL = 2e-5, 2e-5
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p,relu", [
+    (1, 16, 16, 32, 128, 3, 1, 1, True),
+    (2, 24, 40, 64, 128, 3, 1, 1, True),      # ragged patches (24x40 not multiples of 8x16)
+    (1, 32, 32, 128, 256, 3, 2, 1, True),     # block1 entry: ZeroPad2d(1)+conv stride 2
+    (2, 13, 19, 32, 40, 1, 1, 0, False),      # head-style 1x1, Cout not a multiple of 128
+    (1, 128, 128, 256, 128, 3, 1, 1, True),   # block0 entry at full BEV size
+])
+def test_conv2d_matches_torch(B, H, W, Cin, Cout, k, s, p, relu):
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(H * 1000 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, stride=s, padding=p) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if relu:
+        ref = ref.relu()
+    got = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_conv_weight(w).to(DEV), scale.to(DEV), shift.to(DEV),
+                        k, s, p, relu)
+    torch.testing.assert_close(got.cpu(), _nhwc(ref), rtol=RTOL, atol=ATOL)
+
+
+def test_conv2d_identity_asymmetric():
+    """A = I check with an asymmetric B: catches transposed C/D register maps."""
+    from al3d import detector_ops as D
+    Cin = Cout = 64
+    x = torch.zeros(1, Cin, 8, 16)
+    for c in range(Cin):
+        x[0, c, c % 8, (3 * c) % 16] = 1.0 + c
+    w = torch.arange(Cout * Cin, dtype=torch.float32).view(Cout, Cin, 1, 1) / 100.0
+    ref = F.conv2d(x, w)
+    got = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_conv_weight(w).to(DEV), None, None, 1, 1, 0, False)
+    torch.testing.assert_close(got.cpu(), _nhwc(ref), rtol=1e-6, atol=1e-6)
+
+
+def test_deconv_and_concat_window():
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    w = torch.randn(64, 96, 2, 2, generator=g) / 8.0
+    scale = torch.rand(96, generator=g) + 0.5
+    shift = torch.randn(96, generator=g) * 0.1
+    ref = (F.conv_transpose2d(x, w, stride=2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).relu()
+    out = torch.full((2, 24, 40, 160), -7.0, device=DEV)
+    D.deconv2x2_nhwc(_nhwc(x).to(DEV), D.pack_deconv_weight(w).to(DEV), scale.to(DEV), shift.to(DEV),
+                     True, out=out, coff=64)
+    o = out.cpu()
+    torch.testing.assert_close(o[..., 64:], _nhwc(ref), rtol=RTOL, atol=ATOL)
+    assert torch.all(o[..., :64] == -7.0)          # channel window respected
+
+
+def test_gap_matches_two_stage_mean():
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 100, 24, 40, generator=g)     # NCHW
+    ref = x.mean(-1).mean(-1)
+    got = D.gap_nhwc(_nhwc(x).to(DEV))
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
