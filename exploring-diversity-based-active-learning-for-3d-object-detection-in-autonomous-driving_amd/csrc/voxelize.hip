@@ -1,0 +1,260 @@
+// Point-cloud voxelisation + mean VFE for a batch of frames, deterministic.
+//
+// Reference semantics (det3d/ops/point_cloud/point_cloud_ops.py:213-296 +
+// det3d/models/readers/voxel_encoder.py:206-211):
+//   c = floor((p_xyz - range_min) / voxel_size) in float32; keep 0 <= c < grid
+//   voxels are numbered in order of FIRST APPEARANCE in the point list; only the first
+//   max_voxels of them are kept; each keeps its first max_points points in input order;
+//   feature = sum(points of the voxel, slot order) / count.
+// A parallel device has no "first come": the order is rebuilt from point indices --
+//   (1) atomicMin of the point index per cell finds each cell's first point ("leader"),
+//   (2) an exclusive scan over leader flags numbers the voxels in first-appearance order,
+//   (3) points are bucketed per voxel, and one thread per voxel picks its max_points
+//       smallest point indices in ascending order.
+// Every output is therefore independent of scheduling.  Built with -ffp-contract=off:
+// the float32 subtract/divide/floor must round like numpy.
+#include "al3d_common.h"
+#include "al3d_scan.h"
+
+#define VX_EMPTY 0x7fffffff
+
+struct VoxCfg {
+    float min_x, min_y, min_z, vs_x, vs_y, vs_z;
+    int gx, gy, gz;         // grid size (x, y, z)
+    int max_points, max_voxels, nfeat;
+};
+
+__device__ __forceinline__ int64_t vox_cell(const float* __restrict__ p, const VoxCfg& c)
+{
+    const float fx = floorf((p[0] - c.min_x) / c.vs_x);
+    const float fy = floorf((p[1] - c.min_y) / c.vs_y);
+    const float fz = floorf((p[2] - c.min_z) / c.vs_z);
+    if (!(fx >= 0.f && fx < (float)c.gx && fy >= 0.f && fy < (float)c.gy && fz >= 0.f && fz < (float)c.gz))
+        return -1;
+    return ((int64_t)(int)fz * c.gy + (int)fy) * c.gx + (int)fx;
+}
+
+__device__ __forceinline__ int frame_of(const int64_t* __restrict__ off, int B, int64_t i)
+{
+    int lo = 0, hi = B;  // largest b with off[b] <= i
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// pass 1: cell id per point; first[b][cell] = min point index (frame-local)
+__global__ void vox_first_kernel(const float* __restrict__ pts, const int64_t* __restrict__ off, int B,
+                                 VoxCfg c, int64_t cells, int* __restrict__ first, int* __restrict__ pcell_hi,
+                                 int* __restrict__ pcell_lo)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= off[B]) return;
+    const int b = frame_of(off, B, i);
+    const int64_t cell = vox_cell(pts + i * c.nfeat, c);
+    // cells < 2^31 is checked on the host, so one int carries the cell id
+    pcell_lo[i] = cell < 0 ? -1 : (int)cell;
+    pcell_hi[i] = b;
+    if (cell >= 0) atomicMin(&first[(int64_t)b * cells + cell], (int)(i - off[b]));
+}
+
+// pass 2: leader flags
+__global__ void vox_flag_kernel(const int64_t* __restrict__ off, int B, int64_t cells,
+                                const int* __restrict__ first, const int* __restrict__ pframe,
+                                const int* __restrict__ pcell, int* __restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= off[B]) return;
+    const int cell = pcell[i], b = pframe[i];
+    flag[i] = (cell >= 0 && first[(int64_t)b * cells + cell] == (int)(i - off[b])) ? 1 : 0;
+}
+
+// pass 3: voxels per frame, row bases (frames are concatenated in the outputs)
+__global__ void vox_base_kernel(const int64_t* __restrict__ off, int B, const int* __restrict__ lscan,
+                                const int* __restrict__ flag, int max_voxels, int* __restrict__ num_voxels,
+                                int* __restrict__ row_base)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int base = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t s = off[b], e = off[b + 1];
+        int tot = 0;
+        if (e > s) tot = lscan[e - 1] + flag[e - 1] - lscan[s];
+        if (tot > max_voxels) tot = max_voxels;
+        num_voxels[b] = tot;
+        row_base[b] = base;
+        base += tot;
+    }
+    row_base[B] = base;
+}
+
+// pass 4: output row per point (or -1), coordinates of kept voxels, points per voxel
+__global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg c, int64_t cells,
+                                  const int* __restrict__ first, const int* __restrict__ pframe,
+                                  const int* __restrict__ pcell, const int* __restrict__ lscan,
+                                  const int* __restrict__ row_base, int* __restrict__ prow,
+                                  int* __restrict__ coords, int* __restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= off[B]) return;
+    const int cell = pcell[i], b = pframe[i];
+    int row = -1;
+    if (cell >= 0) {
+        const int lead = first[(int64_t)b * cells + cell];
+        const int vid = lscan[off[b] + lead] - lscan[off[b]];
+        if (vid < c.max_voxels) {
+            row = row_base[b] + vid;
+            atomicAdd(&cnt[row], 1);
+            if (lead == (int)(i - off[b])) {
+                const int x = cell % c.gx, y = (cell / c.gx) % c.gy, z = cell / (c.gx * c.gy);
+                coords[4 * row + 0] = b; coords[4 * row + 1] = z;
+                coords[4 * row + 2] = y; coords[4 * row + 3] = x;
+            }
+        }
+    }
+    prow[i] = row;
+}
+
+// pass 5: bucket the point indices per voxel (arrival order is irrelevant: pass 6 sorts)
+__global__ void vox_bucket_kernel(int64_t npts, const int* __restrict__ prow, const int* __restrict__ boff,
+                                  int* __restrict__ cursor, int* __restrict__ bucket)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const int row = prow[i];
+    if (row < 0) return;
+    const int pos = atomicAdd(&cursor[row], 1);
+    bucket[boff[row] + pos] = (int)i;
+}
+
+// pass 6: one thread per voxel: its max_points smallest point indices, ascending;
+// padded voxel tensor, clipped count and the mean feature.
+#define VX_MAXP 32
+__global__ void vox_gather_kernel(const float* __restrict__ pts, VoxCfg c, int rows,
+                                  const int* __restrict__ boff, const int* __restrict__ cnt,
+                                  const int* __restrict__ bucket, const int* __restrict__ row_base,
+                                  int B, float* __restrict__ voxels,
+                                  int* __restrict__ num_points, float* __restrict__ feat)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows || row >= row_base[B]) return;
+    const int n = cnt[row], o = boff[row];
+    const int keep = n < c.max_points ? n : c.max_points;
+    int sel[VX_MAXP];
+    int have = 0;
+    for (int t = 0; t < n; ++t) {           // insertion into a sorted list of <= max_points
+        const int idx = bucket[o + t];
+        if (have == c.max_points && idx > sel[have - 1]) continue;
+        int pos = have < c.max_points ? have : c.max_points - 1;
+        while (pos > 0 && sel[pos - 1] > idx) { sel[pos] = sel[pos - 1]; --pos; }
+        sel[pos] = idx;
+        if (have < c.max_points) ++have;
+    }
+    num_points[row] = keep;
+    const float denom = (float)keep;
+    for (int f = 0; f < c.nfeat; ++f) {
+        float s = 0.f;
+        for (int t = 0; t < c.max_points; ++t) {
+            const float v = t < keep ? pts[(int64_t)sel[t] * c.nfeat + f] : 0.f;
+            if (voxels) voxels[((int64_t)row * c.max_points + t) * c.nfeat + f] = v;
+            s += v;
+        }
+        feat[(int64_t)row * c.nfeat + f] = s / denom;
+    }
+}
+
+// pass 7: put the touched cells of the first-index grid back to EMPTY
+__global__ void vox_restore_kernel(int64_t npts, int64_t cells, const int* __restrict__ pframe,
+                                   const int* __restrict__ pcell, int* __restrict__ first)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const int cell = pcell[i];
+    if (cell >= 0) first[(int64_t)pframe[i] * cells + cell] = VX_EMPTY;
+}
+
+__global__ void vox_fill_i32(int* p, int64_t n, int v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+extern "C" int64_t al3d_voxelize_grid_bytes(int B, int gx, int gy, int gz)
+{
+    return (int64_t)B * gx * gy * gz * 4;
+}
+
+extern "C" int al3d_voxelize_grid_init(void* grid, int B, int gx, int gy, int gz, void* stream)
+{
+    AL3D_REQUIRE(grid, "al3d_voxelize_grid_init: null grid");
+    const int64_t n = (int64_t)B * gx * gy * gz;
+    hipLaunchKernelGGL(vox_fill_i32, dim3(2048), dim3(256), 0, (hipStream_t)stream, (int*)grid, n, VX_EMPTY);
+    AL3D_CHECK_LAUNCH("vox_fill_i32");
+    return AL3D_OK;
+}
+
+extern "C" int64_t al3d_voxelize_workspace_bytes(int64_t npts, int B, int max_voxels)
+{
+    const int64_t rows = (int64_t)B * max_voxels;
+    // pframe, pcell, flag, lscan, prow, bucket (npts each) + cnt, boff, cursor (rows+1 each)
+    // + scan scratch
+    return al3d_align(npts * 4, 256) * 6 + al3d_align((rows + 1) * 4, 256) * 3 +
+           al3d_scan_workspace_bytes(npts > rows ? npts : rows) + 1024;
+}
+
+extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_offsets, int64_t npts,
+                                      int B, int nfeat, const float* range_min, const float* voxel_size,
+                                      const int* grid_size, int max_points, int max_voxels,
+                                      void* first_grid, void* workspace, float* feat, int* coords,
+                                      int* num_points, float* voxels, int* num_voxels, int* row_base,
+                                      void* stream)
+{
+    AL3D_REQUIRE(points && point_offsets && range_min && voxel_size && grid_size && first_grid &&
+                     workspace && feat && coords && num_points && num_voxels && row_base,
+                 "al3d_voxelize_mean_f32: null pointer");
+    AL3D_REQUIRE(B >= 1 && nfeat >= 3 && npts >= 0 && npts < (1LL << 31), "al3d_voxelize_mean_f32: bad sizes");
+    AL3D_REQUIRE(max_points >= 1 && max_points <= VX_MAXP, "al3d_voxelize_mean_f32: max_points must be in [1,%d]", VX_MAXP);
+    AL3D_REQUIRE(max_voxels >= 1, "al3d_voxelize_mean_f32: max_voxels must be >= 1");
+    VoxCfg c;
+    c.min_x = range_min[0]; c.min_y = range_min[1]; c.min_z = range_min[2];
+    c.vs_x = voxel_size[0]; c.vs_y = voxel_size[1]; c.vs_z = voxel_size[2];
+    c.gx = grid_size[0]; c.gy = grid_size[1]; c.gz = grid_size[2];
+    c.max_points = max_points; c.max_voxels = max_voxels; c.nfeat = nfeat;
+    const int64_t cells = (int64_t)c.gx * c.gy * c.gz;
+    AL3D_REQUIRE(cells > 0 && cells < (1LL << 31), "al3d_voxelize_mean_f32: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = (int64_t)B * max_voxels;
+    unsigned char* w = (unsigned char*)workspace;
+    auto take = [&](int64_t bytes) { unsigned char* p = w; w += al3d_align(bytes, 256); return p; };
+    int* pframe = (int*)take(npts * 4);
+    int* pcell = (int*)take(npts * 4);
+    int* flag = (int*)take(npts * 4);
+    int* lscan = (int*)take(npts * 4);
+    int* prow = (int*)take(npts * 4);
+    int* bucket = (int*)take(npts * 4);
+    int* cnt = (int*)take((rows + 1) * 4);
+    int* boff = (int*)take((rows + 1) * 4);
+    int* cursor = (int*)take((rows + 1) * 4);
+    void* scan_ws = (void*)w;
+    int* first = (int*)first_grid;
+    const unsigned pb = (unsigned)al3d_cdiv(npts > 0 ? npts : 1, 256);
+    if (hipMemsetAsync(cnt, 0, (rows + 1) * 4, s) != hipSuccess ||
+        hipMemsetAsync(cursor, 0, (rows + 1) * 4, s) != hipSuccess)
+        return al3d_fail(AL3D_ELAUNCH, "al3d_voxelize_mean_f32: memset failed");
+    hipLaunchKernelGGL(vox_first_kernel, dim3(pb), dim3(256), 0, s, points, point_offsets, B, c, cells,
+                       first, pframe, pcell);
+    hipLaunchKernelGGL(vox_flag_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, cells, first, pframe,
+                       pcell, flag);
+    int rc = al3d_exclusive_scan_i32(flag, lscan, npts, scan_ws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vox_base_kernel, dim3(1), dim3(64), 0, s, point_offsets, B, lscan, flag, max_voxels,
+                       num_voxels, row_base);
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, c, cells, first,
+                       pframe, pcell, lscan, row_base, prow, coords, cnt);
+    rc = al3d_exclusive_scan_i32(cnt, boff, rows + 1, scan_ws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vox_bucket_kernel, dim3(pb), dim3(256), 0, s, npts, prow, boff, cursor, bucket);
+    hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s, points, c,
+                       (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);
+    hipLaunchKernelGGL(vox_restore_kernel, dim3(pb), dim3(256), 0, s, npts, cells, pframe, pcell, first);
+    AL3D_CHECK_LAUNCH("voxelize");
+    return AL3D_OK;
+}

@@ -69,3 +69,64 @@ def gap_nhwc(x):
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
     lib.call("al3d_gap_nhwc_f32", _ptr(x), B, H, W, C, _ptr(out), _stream())
     return out
+
+
+# ------------------------------------------------------------------ voxelizer
+class Voxelizer:
+    """Batched device voxelizer + mean VFE (owns the persistent first-index grid).
+
+    ``cfg`` keys follow the reference's ``voxel_generator`` dict
+    (examples/active/cbgs_spatial_temporal.py:279-284): range, voxel_size,
+    max_points_in_voxel, max_voxel_num.
+    """
+
+    def __init__(self, point_cloud_range, voxel_size, max_points_in_voxel, max_voxel_num,
+                 max_batch=8, device="cuda"):
+        import ctypes
+        import numpy as np
+        self.device = torch.device(device)
+        rng = np.asarray(point_cloud_range, dtype=np.float32)
+        vs = np.asarray(voxel_size, dtype=np.float32)
+        # grid_size = round((max - min) / voxel_size) in float32 (voxel_generator.py:11-13)
+        grid = np.round((rng[3:] - rng[:3]) / vs).astype(np.int64)
+        self.grid_size = grid                      # (x, y, z)
+        self.range_min = (ctypes.c_float * 3)(*rng[:3].tolist())
+        self.voxel_size = (ctypes.c_float * 3)(*vs.tolist())
+        self.grid_c = (ctypes.c_int * 3)(*[int(g) for g in grid])
+        self.max_points = int(max_points_in_voxel)
+        self.max_voxels = int(max_voxel_num)
+        self.max_batch = int(max_batch)
+        nbytes = lib.load().al3d_voxelize_grid_bytes(self.max_batch, *[int(g) for g in grid])
+        self.grid = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        lib.call("al3d_voxelize_grid_init", _ptr(self.grid), self.max_batch,
+                 int(grid[0]), int(grid[1]), int(grid[2]), _stream())
+
+    def __call__(self, points, point_offsets, want_voxels=False):
+        """points [P,F] f32 (frames concatenated), point_offsets [B+1] i64 (device).
+        Returns dict(feat [M,F], coords [M,4] i32 (b,z,y,x), num_points [M] i32,
+        num_voxels [B] i32, voxels [M,max_points,F] | None)."""
+        points = _dev(points, torch.float32, "points")
+        point_offsets = _dev(point_offsets, torch.int64, "point_offsets")
+        B = point_offsets.numel() - 1
+        if B > self.max_batch:
+            raise lib.Al3dError(f"batch {B} exceeds max_batch {self.max_batch}")
+        npts, F = points.shape
+        dev = points.device
+        rows = B * self.max_voxels
+        ws = torch.empty(lib.load().al3d_voxelize_workspace_bytes(npts, B, self.max_voxels),
+                         dtype=torch.uint8, device=dev)
+        feat = torch.empty((rows, F), dtype=torch.float32, device=dev)
+        coords = torch.empty((rows, 4), dtype=torch.int32, device=dev)
+        num_points = torch.empty((rows,), dtype=torch.int32, device=dev)
+        voxels = torch.empty((rows, self.max_points, F), dtype=torch.float32, device=dev) \
+            if want_voxels else None
+        num_voxels = torch.empty((B,), dtype=torch.int32, device=dev)
+        row_base = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+        lib.call("al3d_voxelize_mean_f32", _ptr(points), _ptr(point_offsets), npts, B, F,
+                 self.range_min, self.voxel_size, self.grid_c, self.max_points, self.max_voxels,
+                 _ptr(self.grid), _ptr(ws), _ptr(feat), _ptr(coords), _ptr(num_points), _ptr(voxels),
+                 _ptr(num_voxels), _ptr(row_base), _stream())
+        m = int(row_base[-1].item())            # one small D2H per batch
+        return dict(feat=feat[:m], coords=coords[:m], num_points=num_points[:m],
+                    num_voxels=num_voxels, row_base=row_base,
+                    voxels=None if voxels is None else voxels[:m])

@@ -39,6 +39,11 @@ SIGNATURES = {
     "al3d_knn_2d_f64": (c_int, [c_p, c_i64, c_int, c_p, c_p, c_p]),
     "al3d_apsp_workspace_bytes": (c_i64, [c_i64, c_int]),
     "al3d_apsp_knn_f64": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p]),
+    "al3d_voxelize_grid_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "al3d_voxelize_grid_init": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p]),
+    "al3d_voxelize_workspace_bytes": (c_i64, [c_i64, c_int, c_int]),
+    "al3d_voxelize_mean_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_int, c_int,
+                                       c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "al3d_conv2d_nhwc_f32": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p]),
     "al3d_deconv2x2_nhwc_f32": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_gap_nhwc_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p]),

@@ -82,6 +82,38 @@ def make_embeddings(n, c=512, seed=0, scale=1.0):
     return (base * np.float32(scale)).astype(np.float32)
 
 
+def seeded_init_(module, seed=0):
+    """Fill every parameter/buffer of ``module`` from a per-tensor seeded generator.
+
+    Independent of construction order and of the global RNG: tensor ``name`` uses seed
+    ``seed + crc32(name)``.  Conv / linear weights ~ N(0, 1/fan_in), biases and BN means
+    ~ N(0, 0.1), BN scales and variances ~ U(0.5, 1.5) so that BatchNorm is not the
+    identity.  There are no checkpoints offline; bench.py and the
+    parity fixtures both use this.
+    """
+    import zlib
+
+    import torch
+    with torch.no_grad():
+        for name, t in sorted(module.state_dict().items()):
+            if not t.dtype.is_floating_point:
+                continue
+            g = torch.Generator().manual_seed(int(seed) + zlib.crc32(name.encode()))
+            if t.dim() >= 2:
+                fan_in = int(np.prod(t.shape[1:])) if t.dim() > 2 else int(t.shape[1])
+                if "deblocks" in name and t.dim() == 4 and t.shape[2] == 2:
+                    fan_in = int(t.shape[0])          # ConvTranspose2d [Cin,Cout,2,2]
+                if t.dim() == 5:                       # spconv layout [kz,ky,kx,Cin,Cout]
+                    fan_in = int(np.prod(t.shape[:4]))
+                v = torch.randn(t.shape, generator=g) / float(max(fan_in, 1)) ** 0.5
+            elif name.endswith("running_var") or (name.endswith("weight") and t.dim() == 1):
+                v = torch.rand(t.shape, generator=g) + 0.5
+            else:
+                v = torch.randn(t.shape, generator=g) * 0.1
+            t.copy_(v.to(t.dtype))
+    return module
+
+
 def make_point_cloud(frame_index, nsweeps=10, beams=32, azimuths=1085,
                      n_boxes=30, max_range=54.0):
     """Synthetic 10-sweep lidar frame: ``[P,5] f32`` (x, y, z, intensity, dt).

@@ -115,6 +115,32 @@ int64_t al3d_apsp_workspace_bytes(int64_t n, int kq);
 int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
                       double* out, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------- detector: voxelize */
+
+/* Voxelise a batch of point clouds and reduce each voxel to its mean point (VFE).
+ * Replaces Voxelization/VoxelGenerator.generate -> points_to_voxel_new
+ * (det3d/datasets/pipelines/preprocess.py:275-304,
+ *  det3d/ops/point_cloud/point_cloud_ops.py:213-296) for every frame of the batch,
+ * collate_kitti's concatenation with a batch index (det3d/torchie/parallel/collate.py:118-131)
+ * and VoxelFeatureExtractorV3.forward (det3d/models/readers/voxel_encoder.py:206-211).
+ *   points        [npts, nfeat] f32, frames concatenated; point_offsets [B+1] i64 (device)
+ *   range_min / voxel_size / grid_size   HOST arrays of 3 (x, y, z)
+ *   first_grid    persistent i32 scratch of al3d_voxelize_grid_bytes() bytes, initialised
+ *                 once with al3d_voxelize_grid_init(); left clean by every call
+ *   feat          [B*max_voxels, nfeat] f32 mean features (rows >= total are untouched)
+ *   coords        [B*max_voxels, 4] i32 (batch, z, y, x), first-appearance order per frame
+ *   num_points    [B*max_voxels] i32 clipped counts; voxels [B*max_voxels, max_points, nfeat]
+ *                 zero-padded point slots or NULL; num_voxels [B] i32; row_base [B+1] i32
+ *                 (row_base[B] = total voxels). */
+int64_t al3d_voxelize_grid_bytes(int B, int gx, int gy, int gz);
+int al3d_voxelize_grid_init(void* grid, int B, int gx, int gy, int gz, void* stream);
+int64_t al3d_voxelize_workspace_bytes(int64_t npts, int B, int max_voxels);
+int al3d_voxelize_mean_f32(const float* points, const int64_t* point_offsets, int64_t npts, int B,
+                           int nfeat, const float* range_min, const float* voxel_size,
+                           const int* grid_size, int max_points, int max_voxels, void* first_grid,
+                           void* workspace, float* feat, int* coords, int* num_points, float* voxels,
+                           int* num_voxels, int* row_base, void* stream);
+
 /* ---------------------------------------------------------------- detector: dense */
 
 /* NHWC f32 convolution on the fp32 matrix cores with fused per-channel

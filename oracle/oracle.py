@@ -171,3 +171,22 @@ def greedy(D, seeded, first, box_cost, cost_f, start_cost, budget_int, seed_map=
             _p(box_cost), c_dbl(cost_f), c_dbl(start_cost), c_dbl(budget_int),
             c_int(1 if check_seeded else 0), _p(out), c_i64(cap), ctypes.byref(cnt))
     return int(rc), out[:cnt.value].copy()
+
+
+# ------------------------------------------------------------------ detector side
+def voxelize(points, range_min, voxel_size, grid, max_points, max_voxels):
+    """One frame: returns (voxels [M,max_points,F], coords_zyx [M,3] i32, num_points [M] i32,
+    feat [M,F])."""
+    pts = _c(points, np.float32)
+    n, f = pts.shape
+    rm = _c(range_min, np.float32); vs = _c(voxel_size, np.float32)
+    g = _c(grid, np.int32)
+    voxels = np.zeros((max_voxels, max_points, f), dtype=np.float32)
+    coords = np.zeros((max_voxels, 3), dtype=np.int32)
+    npo = np.zeros(max_voxels, dtype=np.int32)
+    feat = np.zeros((max_voxels, f), dtype=np.float32)
+    fn = lib().al3d_oracle_voxelize
+    fn.restype = c_i64
+    m = fn(_p(pts), c_i64(n), c_int(f), _p(rm), _p(vs), _p(g), c_int(max_points), c_int(max_voxels),
+           _p(voxels), _p(coords), _p(npo), _p(feat))
+    return voxels[:m].copy(), coords[:m].copy(), npo[:m].copy(), feat[:m].copy()

@@ -1,0 +1,72 @@
+"""GPU suite: HIP voxelizer + mean VFE against the CPU oracle (bit-exact: integer
+coordinates/counts, copied point slots, and the same slot-order float32 mean) and the
+reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from al3d import synthetic
+from test_voxel_oracle import GRID, RANGE_MIN, VSIZE, check_against_golden, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+
+def run_hip(frames, max_points, max_voxels, want_voxels=True):
+    from al3d import detector_ops as D
+    vox = D.Voxelizer(RANGE, VSIZE, max_points, max_voxels, max_batch=max(1, len(frames)), device=DEV)
+    off = np.concatenate([[0], np.cumsum([len(f) for f in frames])]).astype(np.int64)
+    pts = np.concatenate(frames, axis=0) if len(frames) else np.zeros((0, 5), np.float32)
+    outs = []
+    for _ in range(2):          # second call checks that the persistent grid was left clean
+        outs.append(vox(torch.from_numpy(pts).to(DEV), torch.from_numpy(off).to(DEV),
+                        want_voxels=want_voxels))
+    a, b = outs
+    for k in ("feat", "coords", "num_points"):
+        assert torch.equal(a[k], b[k]), k
+    return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in a.items()}
+
+
+@pytest.mark.parametrize("name", ["small", "capped", "full"])
+def test_hip_voxelizer_matches_reference_and_oracle(oracle, name):
+    fx, pts = load(name)
+    mp, mv = int(fx["max_points"]), int(fx["max_voxels"])
+    out = run_hip([pts], mp, mv)
+    assert np.all(out["coords"][:, 0] == 0)
+    check_against_golden(fx, out["voxels"], out["coords"][:, 1:], out["num_points"], out["feat"])
+    v, c, n, f = oracle.voxelize(pts, RANGE_MIN, VSIZE, GRID, mp, mv)
+    assert np.array_equal(out["coords"][:, 1:], c) and np.array_equal(out["num_points"], n)
+    assert np.array_equal(out["voxels"].view(np.int32), v.view(np.int32))
+    assert np.array_equal(out["feat"].view(np.int32), f.view(np.int32))
+
+
+def test_hip_voxelizer_batch_concatenation(oracle):
+    """Three ragged frames in one launch == three single-frame oracle runs concatenated with
+    a batch index (collate_kitti semantics)."""
+    frames = [synthetic.make_point_cloud(20, nsweeps=1), np.zeros((0, 5), np.float32),
+              synthetic.make_point_cloud(21, nsweeps=2)]
+    out = run_hip(frames, 10, 9000)
+    row = 0
+    for b, pts in enumerate(frames):
+        v, c, n, f = oracle.voxelize(pts, RANGE_MIN, VSIZE, GRID, 10, 9000)
+        m = len(c)
+        assert out["num_voxels"][b] == m
+        sl = slice(row, row + m)
+        assert np.all(out["coords"][sl, 0] == b)
+        assert np.array_equal(out["coords"][sl, 1:], c)
+        assert np.array_equal(out["num_points"][sl], n)
+        assert np.array_equal(out["feat"][sl].view(np.int32), f.view(np.int32))
+        row += m
+    assert row == len(out["coords"])
+
+
+def test_hip_voxelizer_out_of_range_and_nan():
+    far = np.full((7, 5), 1e4, dtype=np.float32)
+    far[3, 0] = np.nan
+    out = run_hip([far], 10, 100)
+    assert len(out["coords"]) == 0
+    p = np.array([[-51.2, -51.2, -5.0, 1, 0], [51.2, 0, 0, 1, 0], [51.19999, 51.19999, 2.9999, 2, 0]],
+                 dtype=np.float32)
+    out = run_hip([p], 10, 100)
+    assert out["coords"].tolist() == [[0, 0, 0, 0], [0, 39, 1023, 1023]]
