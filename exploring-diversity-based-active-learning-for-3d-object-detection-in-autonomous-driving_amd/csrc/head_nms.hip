@@ -1,0 +1,373 @@
+// Anchor-head post-processing on device: box decode, sigmoid score + class max,
+// score threshold, top-k, rotated (exact polygon) NMS and the per-frame assembly.
+//
+// Reference: MultiGroupHead.predict / get_task_detections
+// (det3d/models/bbox_heads/mg_head.py:697-803,805-1085), second_box_decode
+// (det3d/core/bbox/box_torch_ops.py:80-148), rotate_nms (box_torch_ops.py:528-550),
+// rotate_nms_cc (det3d/ops/nms/nms_cpu.py:34-45) and rotate_non_max_suppression_cpu
+// (det3d/ops/nms/nms_cpu.h:73-168).  The reference round-trips every (task, sample) pair
+// through the host (D2H -> boost::geometry loop -> H2D); here one workgroup per
+// (sample, task) does select + sort + NMS entirely in LDS.
+//
+// Selection order is made deterministic: higher score first, equal scores -> lower anchor
+// index (torch.topk / numpy argsort leave ties unspecified).
+#include "al3d_common.h"
+
+#define HN_THREADS 1024
+#define HN_MAXK 1024            // nms_pre_max_size <= 1024
+
+struct HeadTask {
+    const float* anchors;   // [A, 9] x y z w l h vx vy r
+    int A;                  // anchors = H*W*na
+    int na, nc;             // anchors per location, classes
+    int box_off, cls_off;   // channel offsets inside the fused head output
+    int label_off;          // class-id offset of this task in the merged label space
+};
+
+struct HeadParams {
+    const float* hout;      // [B, H*W, CH] fused head output (NHWC)
+    int B, HW, CH, ntasks;
+    float score_thresh, iou_thresh;
+    int pre_max, post_max;
+    float range[6];         // post_center_limit_range
+    HeadTask task[8];
+    // outputs, [B, ntasks, post_max, *]
+    float* boxes;           // 9 floats
+    float* scores;
+    int* labels;
+    int* counts;            // [B, ntasks]
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// second_box_decode with encode_angle_to_vector=True, smooth_dim=False, norm_velo=False
+__device__ __forceinline__ void decode_box(const float* __restrict__ t, const float* __restrict__ a,
+                                           float* __restrict__ o)
+{
+    const float xa = a[0], ya = a[1], za = a[2], wa = a[3], la = a[4], ha = a[5], vxa = a[6], vya = a[7],
+                ra = a[8];
+    const float diag = sqrtf(la * la + wa * wa);
+    o[0] = t[0] * diag + xa;
+    o[1] = t[1] * diag + ya;
+    o[2] = t[2] * ha + za;
+    o[3] = expf(t[3]) * wa;
+    o[4] = expf(t[4]) * la;
+    o[5] = expf(t[5]) * ha;
+    o[6] = t[6] + vxa;
+    o[7] = t[7] + vya;
+    o[8] = atan2f(t[9] + sinf(ra), t[8] + cosf(ra));
+}
+
+// corners of (x, y, w, l, r): unit square (0,0),(0,1),(1,1),(1,0) minus 0.5, scaled by (w,l),
+// rotated by [[cos,-sin],[sin,cos]] applied as row-vector @ R^T ... the reference's
+// rotation_2d: einsum("aij,jka->aik", points, [[c,-s],[s,c]])  => x' = x*c + y*s, y' = -x*s + y*c
+__device__ __forceinline__ void box_corners(float x, float y, float w, float l, float r, float* cx,
+                                            float* cy)
+{
+    const float c = cosf(r), s = sinf(r);
+    const float ux[4] = {-0.5f, -0.5f, 0.5f, 0.5f}, uy[4] = {-0.5f, 0.5f, 0.5f, -0.5f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float px = ux[k] * w, py = uy[k] * l;
+        cx[k] = px * c + py * s + x;
+        cy[k] = -px * s + py * c + y;
+    }
+}
+
+// area of the intersection of two convex quadrilaterals (Sutherland-Hodgman clip + shoelace)
+__device__ float quad_intersection_area(const float* ax, const float* ay, const float* bx, const float* by)
+{
+    float px[10], py[10], qx[10], qy[10];
+    int n = 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { px[k] = ax[k]; py[k] = ay[k]; }
+    // orientation of the clip polygon
+    float barea = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int k2 = (k + 1) & 3; barea += bx[k] * by[k2] - bx[k2] * by[k]; }
+    const float sgn = barea >= 0.f ? 1.f : -1.f;
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const int e2 = (e + 1) & 3;
+        const float ex = bx[e2] - bx[e], ey = by[e2] - by[e];
+        int m = 0;
+        for (int k = 0; k < n; ++k) {
+            const int k2 = k + 1 == n ? 0 : k + 1;
+            const float d1 = sgn * (ex * (py[k] - by[e]) - ey * (px[k] - bx[e]));
+            const float d2 = sgn * (ex * (py[k2] - by[e]) - ey * (px[k2] - bx[e]));
+            if (d1 >= 0.f) { qx[m] = px[k]; qy[m] = py[k]; ++m; }
+            if ((d1 >= 0.f) != (d2 >= 0.f)) {
+                const float tt = d1 / (d1 - d2);
+                qx[m] = px[k] + tt * (px[k2] - px[k]);
+                qy[m] = py[k] + tt * (py[k2] - py[k]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int k = 0; k < n; ++k) { px[k] = qx[k]; py[k] = qy[k]; }
+    }
+    if (n < 3) return 0.f;
+    float area = 0.f;
+    for (int k = 0; k < n; ++k) { const int k2 = k + 1 == n ? 0 : k + 1; area += px[k] * py[k2] - px[k2] * py[k]; }
+    return 0.5f * fabsf(area);
+}
+
+__device__ __forceinline__ float quad_area(const float* x, const float* y)
+{
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int k2 = (k + 1) & 3; a += x[k] * y[k2] - x[k2] * y[k]; }
+    return 0.5f * fabsf(a);
+}
+
+__global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
+{
+    const int b = blockIdx.x / p.ntasks, t = blockIdx.x % p.ntasks;
+    const HeadTask tk = p.task[t];
+    const int tid = threadIdx.x;
+    const float* hb = p.hout + (int64_t)b * p.HW * p.CH;
+
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need, s_sel_cnt, s_eq_seen;
+    __shared__ unsigned long long key_s[HN_MAXK];       // (score bits << 32) | ~anchor
+    __shared__ float cx_s[HN_MAXK][4], cy_s[HN_MAXK][4];
+    __shared__ float sb_s[HN_MAXK][4];                  // standup box x1,y1,x2,y2
+    __shared__ float area_s[HN_MAXK];
+    __shared__ unsigned char sup_s[HN_MAXK];
+    __shared__ int keep_s[128];
+    __shared__ int s_next, s_kept;
+
+    // score of anchor a: max over classes of sigmoid(cls); label = first argmax
+    auto anchor_score = [&](int a, int& label) -> float {
+        const int loc = a / tk.na, j = a % tk.na;
+        const float* c = hb + (int64_t)loc * p.CH + tk.cls_off + j * tk.nc;
+        float best = sigmoidf_(c[0]);
+        label = 0;
+        for (int q = 1; q < tk.nc; ++q) { const float s = sigmoidf_(c[q]); if (s > best) { best = s; label = q; } }
+        return best;
+    };
+
+    // ---- radix select of the pre_max largest scores among those >= score_thresh
+    // scores are in (0,1): positive floats order like their bit patterns.
+    const int K = p.pre_max < HN_MAXK ? p.pre_max : HN_MAXK;
+    unsigned prefix = 0, need = K;
+    if (tid == 0) { s_sel_cnt = 0; s_eq_seen = 0; }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int q = tid; q < 256; q += HN_THREADS) hist[q] = 0;
+        __syncthreads();
+        for (int a = tid; a < tk.A; a += HN_THREADS) {
+            int lab;
+            const float s = anchor_score(a, lab);
+            if (!(s >= p.score_thresh)) continue;
+            const unsigned bits = __float_as_uint(s);
+            if (pass == 0 || (bits >> (shift + 8)) == (prefix >> (shift + 8)))
+                atomicAdd(&hist[(bits >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0; int bin = 255;
+            for (; bin >= 0; --bin) { if (acc + hist[bin] >= need) break; acc += hist[bin]; }
+            if (bin < 0) { bin = 0; s_need = 0xffffffffu; }   // fewer than `need` candidates: take all
+            else s_need = need - acc;
+            s_prefix = prefix | ((unsigned)bin << shift);
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        if (s_need == 0xffffffffu) { prefix = 0; need = 0xffffffffu; break; }
+        need = s_need;
+        __syncthreads();
+    }
+    // prefix = bit pattern of the K-th largest score (or 0 = take everything); `need` = how many
+    // entries equal to it still fit (ties -> lower anchor index first).
+    __syncthreads();
+    const unsigned thr_bits = prefix;
+    // strictly-greater entries first
+    for (int a0 = 0; a0 < tk.A; a0 += HN_THREADS) {
+        const int a = a0 + tid;
+        bool take = false, eq = false;
+        unsigned bits = 0;
+        if (a < tk.A) {
+            int lab;
+            const float s = anchor_score(a, lab);
+            if (s >= p.score_thresh) {
+                bits = __float_as_uint(s);
+                if (need == 0xffffffffu || bits > thr_bits) take = true;
+                else if (bits == thr_bits) eq = true;
+            }
+        }
+        // equal-to-threshold entries are admitted in ascending anchor order: wave ballots give
+        // the rank inside the chunk, s_eq_seen carries it across chunks.
+        __shared__ unsigned eq_wave[HN_THREADS / 64];
+        const unsigned long long em = __ballot(eq);
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane == 0) eq_wave[wv] = (unsigned)__popcll(em);
+        __syncthreads();
+        if (eq) {
+            unsigned rank = s_eq_seen + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wv; ++w) rank += eq_wave[w];
+            if (rank < need) take = true;
+        }
+        __syncthreads();
+        if (tid == 0) { unsigned tot = 0; for (int w = 0; w < HN_THREADS / 64; ++w) tot += eq_wave[w]; s_eq_seen += tot; }
+        if (take) {
+            const unsigned slot = atomicAdd(&s_sel_cnt, 1u);
+            if (slot < HN_MAXK) key_s[slot] = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)a);
+        }
+        __syncthreads();
+    }
+    const int n = (int)(s_sel_cnt < (unsigned)K ? s_sel_cnt : (unsigned)K);
+    // ---- bitonic sort of the (<= 1024) keys, descending
+    for (int q = n + tid; q < HN_MAXK; q += HN_THREADS) key_s[q] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= HN_MAXK; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int i = tid, j = i ^ stride;
+            if (j > i) {
+                const bool desc = (i & size) == 0;
+                const unsigned long long x = key_s[i], y = key_s[j];
+                if (desc ? x < y : x > y) { key_s[i] = y; key_s[j] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- decode the selected boxes, corners, standup boxes
+    float box[9];
+    int my_label = 0;
+    float my_score = 0.f;
+    if (tid < n) {
+        const unsigned long long key = key_s[tid];
+        const int a = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+        my_score = __uint_as_float((unsigned)(key >> 32));
+        int lab;
+        anchor_score(a, lab);
+        my_label = lab;
+        const int loc = a / tk.na, j = a % tk.na;
+        decode_box(hb + (int64_t)loc * p.CH + tk.box_off + j * 10, tk.anchors + (int64_t)a * 9, box);
+        box_corners(box[0], box[1], box[3], box[4], box[8], cx_s[tid], cy_s[tid]);
+        float x1 = cx_s[tid][0], x2 = x1, y1 = cy_s[tid][0], y2 = y1;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            x1 = fminf(x1, cx_s[tid][k]); x2 = fmaxf(x2, cx_s[tid][k]);
+            y1 = fminf(y1, cy_s[tid][k]); y2 = fmaxf(y2, cy_s[tid][k]);
+        }
+        sb_s[tid][0] = x1; sb_s[tid][1] = y1; sb_s[tid][2] = x2; sb_s[tid][3] = y2;
+        area_s[tid] = quad_area(cx_s[tid], cy_s[tid]);
+        sup_s[tid] = 0;
+    }
+    if (tid == 0) { s_kept = 0; s_next = n > 0 ? 0 : -1; }
+    __syncthreads();
+    // ---- greedy rotated NMS; only the first post_max survivors are needed
+    const int post = p.post_max < 128 ? p.post_max : 128;
+    while (true) {
+        const int i = s_next;
+        if (i < 0 || s_kept >= post) break;
+        __syncthreads();
+        if (tid == 0) keep_s[s_kept++] = i;
+        bool sup = false;
+        if (tid > i && tid < n && !sup_s[tid]) {
+            // standup-box prefilter (iou_jit, eps = 0): overlap must be strictly positive
+            const float iw = fminf(sb_s[i][2], sb_s[tid][2]) - fmaxf(sb_s[i][0], sb_s[tid][0]);
+            const float ih = fminf(sb_s[i][3], sb_s[tid][3]) - fmaxf(sb_s[i][1], sb_s[tid][1]);
+            if (iw > 0.f && ih > 0.f) {
+                const float inter = quad_intersection_area(cx_s[i], cy_s[i], cx_s[tid], cy_s[tid]);
+                if (inter > 0.f) {
+                    const float uni = area_s[i] + area_s[tid] - inter;
+                    if (uni > 0.f && inter / uni >= p.iou_thresh) sup = true;
+                }
+            }
+        }
+        if (sup) sup_s[tid] = 1;
+        __syncthreads();
+        // next unsuppressed index after i
+        if (tid == 0) s_next = n;       // sentinel
+        __syncthreads();
+        if (tid > i && tid < n && !sup_s[tid]) atomicMin(&s_next, tid);
+        __syncthreads();
+        if (tid == 0 && s_next >= n) s_next = -1;
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- write survivors (kept order), applying the centre range mask; compact in order
+    const int kept = s_kept;
+    __shared__ int pass_s[128];
+    if (tid < 128) pass_s[tid] = 0;
+    __syncthreads();
+    // each kept box is owned by the thread that decoded it (tid == candidate rank)
+    bool mine = false; int kpos = -1;
+    for (int q = 0; q < kept; ++q) if (keep_s[q] == tid) { mine = true; kpos = q; }
+    bool ok = false;
+    if (mine) {
+        ok = box[0] >= p.range[0] && box[1] >= p.range[1] && box[2] >= p.range[2] &&
+             box[0] <= p.range[3] && box[1] <= p.range[4] && box[2] <= p.range[5];
+        pass_s[kpos] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (mine && ok) {
+        int dst = 0;
+        for (int q = 0; q < kpos; ++q) dst += pass_s[q];
+        const int64_t o = ((int64_t)b * p.ntasks + t) * p.post_max + dst;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p.boxes[o * 9 + k] = box[k];
+        p.scores[o] = my_score;
+        p.labels[o] = my_label + tk.label_off;
+    }
+    if (tid == 0) {
+        int c = 0;
+        for (int q = 0; q < kept; ++q) c += pass_s[q];
+        p.counts[b * p.ntasks + t] = c;
+    }
+}
+
+extern "C" int al3d_head_decode_nms(const float* hout, int B, int HW, int CH, int ntasks,
+                                    const float* const* anchors, const int* task_A, const int* task_na,
+                                    const int* task_nc, const int* box_off, const int* cls_off,
+                                    const int* label_off, float score_thresh, float iou_thresh,
+                                    int pre_max, int post_max, const float* range6, float* boxes,
+                                    float* scores, int* labels, int* counts, void* stream)
+{
+    AL3D_REQUIRE(hout && anchors && task_A && task_na && task_nc && box_off && cls_off && label_off &&
+                     range6 && boxes && scores && labels && counts, "al3d_head_decode_nms: null pointer");
+    AL3D_REQUIRE(ntasks >= 1 && ntasks <= 8, "al3d_head_decode_nms: ntasks must be in [1,8]");
+    AL3D_REQUIRE(pre_max >= 1 && pre_max <= HN_MAXK, "al3d_head_decode_nms: pre_max must be in [1,%d]", HN_MAXK);
+    AL3D_REQUIRE(post_max >= 1 && post_max <= 128, "al3d_head_decode_nms: post_max must be in [1,128]");
+    HeadParams p;
+    p.hout = hout; p.B = B; p.HW = HW; p.CH = CH; p.ntasks = ntasks;
+    p.score_thresh = score_thresh; p.iou_thresh = iou_thresh; p.pre_max = pre_max; p.post_max = post_max;
+    for (int k = 0; k < 6; ++k) p.range[k] = range6[k];
+    for (int t = 0; t < ntasks; ++t) {
+        AL3D_REQUIRE(task_A[t] == HW * task_na[t], "al3d_head_decode_nms: task %d anchor count mismatch", t);
+        p.task[t].anchors = anchors[t]; p.task[t].A = task_A[t]; p.task[t].na = task_na[t];
+        p.task[t].nc = task_nc[t]; p.task[t].box_off = box_off[t]; p.task[t].cls_off = cls_off[t];
+        p.task[t].label_off = label_off[t];
+        AL3D_REQUIRE(box_off[t] + task_na[t] * 10 <= CH && cls_off[t] + task_na[t] * task_nc[t] <= CH,
+                     "al3d_head_decode_nms: task %d channel window exceeds CH", t);
+    }
+    p.boxes = boxes; p.scores = scores; p.labels = labels; p.counts = counts;
+    hipLaunchKernelGGL(head_nms_kernel, dim3((unsigned)(B * ntasks)), dim3(HN_THREADS), 0,
+                       (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("head_nms_kernel");
+    return AL3D_OK;
+}
+
+// Stand-alone decode (GroundBox3dCoderTorch.decode_torch, det3d/core/bbox/box_coders.py:106-109).
+__global__ void box_decode_kernel(const float* __restrict__ enc, const float* __restrict__ anc, int64_t n,
+                                  float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[9];
+    decode_box(enc + 10 * i, anc + 9 * i, o);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[9 * i + k] = o[k];
+}
+
+extern "C" int al3d_box_decode_f32(const float* enc, const float* anchors, int64_t n, float* out,
+                                   void* stream)
+{
+    AL3D_REQUIRE(enc && anchors && out && n >= 0, "al3d_box_decode_f32: bad arguments");
+    if (n == 0) return AL3D_OK;
+    hipLaunchKernelGGL(box_decode_kernel, dim3((unsigned)al3d_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, enc, anchors, n, out);
+    AL3D_CHECK_LAUNCH("box_decode_kernel");
+    return AL3D_OK;
+}

@@ -1,0 +1,283 @@
+// 3-D sparse convolution middle encoder (submanifold + strided), gfx950.
+//
+// Semantics follow spconv (call sites det3d/models/backbones/scn.py:28-97,316-392; the
+// in-tree statement of the rulebook is the vendored spconv-1.0 under
+// bevfusion/mmdet3d/ops/spconv/include/spconv/geometry.h:25-82,145-194,248-298 and
+// spconv_ops.h:260-361):
+//     out[o] = sum_k  W[k]^T . in[o*stride - pad + k]          (k over kz,ky,kx, x fastest)
+//   * SubMConv3d: output sites == input sites (pad = k/2, stride 1)
+//   * SparseConv3d: output sites = every in-bounds o reached by at least one input
+// MI355X design: instead of spconv's per-offset gather -> GEMM -> scatter-add (27
+// launches, atomics, run-to-run summation order), the rulebook is stored output-major
+// (nbr[o][k] = input row or -1, built from a dense per-level index grid that lives in
+// HBM) and ONE kernel per layer walks k for a tile of output rows: gathered input rows are
+// staged in LDS, products accumulate in registers in a fixed (k, ci) order, and the
+// BN(eval)/bias/residual/ReLU epilogue is fused, so every activation row makes one HBM
+// round trip and results are deterministic.
+#include "al3d_common.h"
+
+struct SpDims { int B, D, H, W; };
+
+__device__ __forceinline__ int64_t sp_cell(const SpDims& g, int b, int z, int y, int x)
+{
+    return (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
+}
+
+// grid[cell(coords[i])] = (mode ? i : -1)
+__global__ void sp_scatter_index_kernel(const int* __restrict__ coords, int n, SpDims g,
+                                        int* __restrict__ grid, int mode)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int* c = coords + 4 * i;
+    grid[sp_cell(g, c[0], c[1], c[2], c[3])] = mode ? i : -1;
+}
+
+// Output-major rulebook for a submanifold conv: nbr[i][k] = row at coords[i] + (k - k/2).
+__global__ void sp_subm_table_kernel(const int* __restrict__ coords, int n, SpDims g,
+                                     const int* __restrict__ grid, int kd, int kh, int kw,
+                                     int* __restrict__ nbr)
+{
+    const int K = kd * kh * kw;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * K) return;
+    const int i = (int)(e / K), k = (int)(e % K);
+    const int kx = k % kw, ky = (k / kw) % kh, kz = k / (kw * kh);
+    const int* c = coords + 4 * i;
+    const int z = c[1] + kz - kd / 2, y = c[2] + ky - kh / 2, x = c[3] + kx - kw / 2;
+    int v = -1;
+    if (z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) v = grid[sp_cell(g, c[0], z, y, x)];
+    nbr[e] = v;
+}
+
+struct SpConvGeom { int kd, kh, kw, sd, sh, sw, pd, ph, pw; };
+
+// Strided conv, step 1: every (input, k) pair claims its output site; the first claimer
+// appends the site to coords_out (row order is arbitrary; nothing downstream depends on it).
+__global__ void sp_down_claim_kernel(const int* __restrict__ coords_in, int n_in, SpConvGeom q,
+                                     SpDims go, int* __restrict__ grid_out,
+                                     int* __restrict__ coords_out, int* __restrict__ counter, int cap)
+{
+    const int K = q.kd * q.kh * q.kw;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n_in * K) return;
+    const int i = (int)(e / K), k = (int)(e % K);
+    const int kx = k % q.kw, ky = (k / q.kw) % q.kh, kz = k / (q.kw * q.kh);
+    const int* c = coords_in + 4 * i;
+    const int tz = c[1] + q.pd - kz, ty = c[2] + q.ph - ky, tx = c[3] + q.pw - kx;
+    if (tz < 0 || ty < 0 || tx < 0 || tz % q.sd || ty % q.sh || tx % q.sw) return;
+    const int oz = tz / q.sd, oy = ty / q.sh, ox = tx / q.sw;
+    if (oz >= go.D || oy >= go.H || ox >= go.W) return;
+    int* cell = grid_out + sp_cell(go, c[0], oz, oy, ox);
+    if (atomicCAS(cell, -1, -2) == -1) {
+        const int row = atomicAdd(counter, 1);
+        if (row < cap) {
+            coords_out[4 * row + 0] = c[0]; coords_out[4 * row + 1] = oz;
+            coords_out[4 * row + 2] = oy; coords_out[4 * row + 3] = ox;
+        }
+        atomicExch(cell, row);      // the site's row id, read by the next level's rulebook
+    }
+}
+
+// Strided conv, step 2: nbr[o][k] = input row at o*stride - pad + k (grid_in lookup).
+__global__ void sp_down_table_kernel(const int* __restrict__ coords_out, int n_out, SpConvGeom q,
+                                     SpDims gi, const int* __restrict__ grid_in, int* __restrict__ nbr)
+{
+    const int K = q.kd * q.kh * q.kw;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n_out * K) return;
+    const int o = (int)(e / K), k = (int)(e % K);
+    const int kx = k % q.kw, ky = (k / q.kw) % q.kh, kz = k / (q.kw * q.kh);
+    const int* c = coords_out + 4 * o;
+    const int z = c[1] * q.sd - q.pd + kz, y = c[2] * q.sh - q.ph + ky, x = c[3] * q.sw - q.pw + kx;
+    int v = -1;
+    if (z >= 0 && z < gi.D && y >= 0 && y < gi.H && x >= 0 && x < gi.W) v = grid_in[sp_cell(gi, c[0], z, y, x)];
+    nbr[e] = v;
+}
+
+// ------------------------------------------------------------------ the conv itself
+// 32 output rows x COUT per 256-thread workgroup.  Thread -> one output channel and
+// 32*COUT/256 rows; per kernel offset the 32 gathered input rows sit in LDS (broadcast
+// float4 reads), the weight slice streams from L2 (coalesced over the output channel).
+#define SP_TM 32
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void sp_conv_kernel(const float* __restrict__ fin,
+                                                      const int* __restrict__ nbr, int K,
+                                                      const float* __restrict__ wgt,   // [K][CIN][COUT]
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift,
+                                                      const float* __restrict__ residual, int relu,
+                                                      float* __restrict__ fout, int n_out)
+{
+    constexpr int CPAD = (CIN + 3) & ~3;
+    constexpr int GROUPS = 256 / COUT;          // row groups
+    constexpr int RPT = SP_TM / GROUPS;         // rows per thread
+    __shared__ __attribute__((aligned(16))) float a_s[SP_TM][CPAD];
+    __shared__ int idx_s[SP_TM];
+    const int tid = threadIdx.x;
+    const int co = tid % COUT, rg = tid / COUT;
+    const int row0 = blockIdx.x * SP_TM;
+    float acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
+
+    for (int k = 0; k < K; ++k) {
+        int have = 0;
+        if (tid < SP_TM) {
+            const int row = row0 + tid;
+            const int v = row < n_out ? nbr[(int64_t)row * K + k] : -1;
+            idx_s[tid] = v;
+            have = v >= 0;
+        }
+        if (!__syncthreads_or(have)) continue;       // nobody in this tile has offset k
+        for (int e = tid; e < SP_TM * CPAD; e += 256) {
+            const int r = e / CPAD, ci = e % CPAD;
+            const int src = idx_s[r];
+            a_s[r][ci] = (src >= 0 && ci < CIN) ? fin[(int64_t)src * CIN + ci] : 0.f;
+        }
+        __syncthreads();
+        const float* wk = wgt + (int64_t)k * CIN * COUT + co;
+#pragma unroll 4
+        for (int ci = 0; ci < CPAD; ci += 4) {
+            const float w0 = ci + 0 < CIN ? wk[(ci + 0) * COUT] : 0.f;
+            const float w1 = ci + 1 < CIN ? wk[(ci + 1) * COUT] : 0.f;
+            const float w2 = ci + 2 < CIN ? wk[(ci + 2) * COUT] : 0.f;
+            const float w3 = ci + 3 < CIN ? wk[(ci + 3) * COUT] : 0.f;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const float4 a = *reinterpret_cast<const float4*>(&a_s[rg * RPT + r][ci]);
+                acc[r] = fmaf(a.x, w0, acc[r]);
+                acc[r] = fmaf(a.y, w1, acc[r]);
+                acc[r] = fmaf(a.z, w2, acc[r]);
+                acc[r] = fmaf(a.w, w3, acc[r]);
+            }
+        }
+        __syncthreads();
+    }
+    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int row = row0 + rg * RPT + r;
+        if (row >= n_out) continue;
+        float v = acc[r] * sc + sh;
+        if (residual) v += residual[(int64_t)row * COUT + co];
+        if (relu) v = v > 0.f ? v : 0.f;
+        fout[(int64_t)row * COUT + co] = v;
+    }
+}
+
+// sparse -> dense NHWC: out[b][y][x][c*D + z] = feat[row][c]  (SparseConvTensor.dense() then
+// view(N, C*D, H, W), scn.py:387-390); `out` must be zero-filled by the caller.
+__global__ void sp_to_dense_nhwc_kernel(const float* __restrict__ feat, const int* __restrict__ coords,
+                                        int n, int C, SpDims g, float* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * C) return;
+    const int row = (int)(e / C), c = (int)(e % C);
+    const int* q = coords + 4 * row;
+    out[((((int64_t)q[0] * g.H + q[2]) * g.W + q[3]) * C + c) * g.D + q[1]] = feat[e];
+}
+
+// ------------------------------------------------------------------ C ABI
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)al3d_cdiv(n > 0 ? n : 1, per); }
+
+extern "C" int al3d_sp_fill_i32(int* buf, int64_t count, int value, void* stream)
+{
+    AL3D_REQUIRE(buf && count >= 0, "al3d_sp_fill_i32: bad arguments");
+    if (value == 0 || value == -1) {
+        if (hipMemsetAsync(buf, value == 0 ? 0 : 0xff, (size_t)count * 4, (hipStream_t)stream) != hipSuccess)
+            return al3d_fail(AL3D_ELAUNCH, "al3d_sp_fill_i32: memset failed");
+        return AL3D_OK;
+    }
+    return al3d_fail(AL3D_EINVAL, "al3d_sp_fill_i32: only 0 and -1 are supported");
+}
+
+extern "C" int al3d_sp_scatter_index(const int* coords, int n, int B, int D, int H, int W, int* grid,
+                                     int mode, void* stream)
+{
+    if (n == 0) return AL3D_OK;
+    AL3D_REQUIRE(coords && grid && n > 0, "al3d_sp_scatter_index: bad arguments");
+    SpDims g = {B, D, H, W};
+    hipLaunchKernelGGL(sp_scatter_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       coords, n, g, grid, mode);
+    AL3D_CHECK_LAUNCH("sp_scatter_index_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_sp_subm_table(const int* coords, int n, int B, int D, int H, int W, const int* grid,
+                                  int kd, int kh, int kw, int* nbr, void* stream)
+{
+    if (n == 0) return AL3D_OK;
+    AL3D_REQUIRE(coords && grid && nbr && n > 0, "al3d_sp_subm_table: bad arguments");
+    AL3D_REQUIRE(kd % 2 == 1 && kh % 2 == 1 && kw % 2 == 1, "al3d_sp_subm_table: odd kernel sizes only");
+    if (n == 0) return AL3D_OK;
+    SpDims g = {B, D, H, W};
+    hipLaunchKernelGGL(sp_subm_table_kernel, dim3(blocks_for((int64_t)n * kd * kh * kw, 256)), dim3(256), 0,
+                       (hipStream_t)stream, coords, n, g, grid, kd, kh, kw, nbr);
+    AL3D_CHECK_LAUNCH("sp_subm_table_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_sp_down_claim(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                                  const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                                  int* coords_out, int* counter, int cap, void* stream)
+{
+    if (n_in == 0) return AL3D_OK;
+    AL3D_REQUIRE(coords_in && ksize && stride && pad && grid_out && coords_out && counter,
+                 "al3d_sp_down_claim: null pointer");
+    SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
+    SpDims go = {B, OD, OH, OW};
+    hipLaunchKernelGGL(sp_down_claim_kernel, dim3(blocks_for((int64_t)n_in * q.kd * q.kh * q.kw, 256)),
+                       dim3(256), 0, (hipStream_t)stream, coords_in, n_in, q, go, grid_out, coords_out,
+                       counter, cap);
+    AL3D_CHECK_LAUNCH("sp_down_claim_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_sp_down_table(const int* coords_out, int n_out, const int* ksize, const int* stride,
+                                  const int* pad, int B, int ID, int IH, int IW, const int* grid_in,
+                                  int* nbr, void* stream)
+{
+    if (n_out == 0) return AL3D_OK;
+    AL3D_REQUIRE(coords_out && ksize && stride && pad && grid_in && nbr, "al3d_sp_down_table: null pointer");
+    SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
+    SpDims gi = {B, ID, IH, IW};
+    hipLaunchKernelGGL(sp_down_table_kernel, dim3(blocks_for((int64_t)n_out * q.kd * q.kh * q.kw, 256)),
+                       dim3(256), 0, (hipStream_t)stream, coords_out, n_out, q, gi, grid_in, nbr);
+    AL3D_CHECK_LAUNCH("sp_down_table_kernel");
+    return AL3D_OK;
+}
+
+#define SP_DISPATCH(CI, CO)                                                                        \
+    if (cin == CI && cout == CO) {                                                                 \
+        hipLaunchKernelGGL((sp_conv_kernel<CI, CO>), dim3(blocks_for(n_out, SP_TM)), dim3(256), 0, s, \
+                           fin, nbr, K, wgt, scale, shift, residual, relu, fout, n_out);           \
+        AL3D_CHECK_LAUNCH("sp_conv_kernel");                                                       \
+        return AL3D_OK;                                                                            \
+    }
+
+extern "C" int al3d_sp_conv_f32(const float* fin, const int* nbr, int K, const float* wgt, int cin,
+                                int cout, const float* scale, const float* shift,
+                                const float* residual, int relu, float* fout, int n_out, void* stream)
+{
+    AL3D_REQUIRE(K >= 1 && n_out >= 0, "al3d_sp_conv_f32: bad sizes");
+    if (n_out == 0) return AL3D_OK;
+    AL3D_REQUIRE(fin && nbr && wgt && fout, "al3d_sp_conv_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    SP_DISPATCH(5, 16) SP_DISPATCH(4, 16) SP_DISPATCH(16, 16) SP_DISPATCH(16, 32) SP_DISPATCH(32, 32)
+    SP_DISPATCH(32, 64) SP_DISPATCH(64, 64) SP_DISPATCH(64, 128) SP_DISPATCH(128, 128)
+    return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_f32: unsupported channel pair %d -> %d", cin, cout);
+}
+
+extern "C" int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D,
+                                     int H, int W, float* out, void* stream)
+{
+    if (n == 0) return AL3D_OK;
+    AL3D_REQUIRE(feat && coords && out && n > 0, "al3d_sp_to_dense_nhwc: bad arguments");
+    SpDims g = {B, D, H, W};
+    hipLaunchKernelGGL(sp_to_dense_nhwc_kernel, dim3(blocks_for((int64_t)n * C, 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, coords, n, C, g, out);
+    AL3D_CHECK_LAUNCH("sp_to_dense_nhwc_kernel");
+    return AL3D_OK;
+}

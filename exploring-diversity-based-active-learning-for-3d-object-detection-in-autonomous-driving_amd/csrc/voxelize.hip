@@ -258,3 +258,27 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
     AL3D_CHECK_LAUNCH("voxelize");
     return AL3D_OK;
 }
+
+// VoxelFeatureExtractorV3 on reference-format input (padded voxels [M,max_points,F] + counts):
+// features[:, :, :F].sum(1) / num_points  (det3d/models/readers/voxel_encoder.py:206-211).
+__global__ void vfe_mean_kernel(const float* __restrict__ voxels, const int* __restrict__ num, int m,
+                                int max_points, int nfeat, float* __restrict__ feat)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)m * nfeat) return;
+    const int row = (int)(e / nfeat), f = (int)(e % nfeat);
+    float s = 0.f;
+    for (int t = 0; t < max_points; ++t) s += voxels[((int64_t)row * max_points + t) * nfeat + f];
+    feat[e] = s / (float)num[row];
+}
+
+extern "C" int al3d_vfe_mean_f32(const float* voxels, const int* num_points, int m, int max_points,
+                                 int nfeat, float* feat, void* stream)
+{
+    AL3D_REQUIRE(voxels && num_points && feat && m >= 0, "al3d_vfe_mean_f32: bad arguments");
+    if (m == 0) return AL3D_OK;
+    hipLaunchKernelGGL(vfe_mean_kernel, dim3((unsigned)al3d_cdiv((int64_t)m * nfeat, 256)), dim3(256), 0,
+                       (hipStream_t)stream, voxels, num_points, m, max_points, nfeat, feat);
+    AL3D_CHECK_LAUNCH("vfe_mean_kernel");
+    return AL3D_OK;
+}

@@ -1,0 +1,89 @@
+"""Device-resident unlabeled pool + sweep loader.
+
+The reference feeds the sweep through 8 DataLoader worker processes that read ten ``.bin``
+sweeps per frame, voxelize with numpy/numba and regenerate the anchors for every sample
+(SURVEY 3.2).  Here the pool's point clouds live in HBM (288 GB holds the whole nuScenes
+train split), voxelization runs on device per batch, and anchors are constants.
+
+``PoolFrames`` is the storage: a list of ``[P_i,5]`` float32 device tensors.  ``from_synthetic``
+builds nuScenes-shaped frames (there is no dataset offline): a handful of ring-scan base clouds
+from ``synthetic.make_point_cloud`` rotated/shifted per frame so every frame is distinct.
+``from_files`` reads real 10-sweep frames through the reference's loading rules (a1).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import synthetic
+from ..detector_ops import Voxelizer
+
+
+class PoolFrames:
+    def __init__(self, frames, tokens=None):
+        self.frames = frames
+        self.tokens = tokens or [f"frame{i:06d}" for i in range(len(frames))]
+
+    def __len__(self):
+        return len(self.frames)
+
+    @classmethod
+    def from_synthetic(cls, num_frames, device, num_base=16, seed=0, nsweeps=10):
+        base = [torch.from_numpy(synthetic.make_point_cloud(1000 + b, nsweeps=nsweeps)).to(device)
+                for b in range(min(num_base, max(1, num_frames)))]
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        yaw = torch.rand(num_frames, generator=g) * 2 * math.pi
+        shift = torch.randn(num_frames, 2, generator=g) * 0.5
+        frames = []
+        for i in range(num_frames):
+            p = base[i % len(base)].clone()
+            c, s = math.cos(float(yaw[i])), math.sin(float(yaw[i]))
+            x, y = p[:, 0].clone(), p[:, 1].clone()
+            p[:, 0] = c * x - s * y + float(shift[i, 0])
+            p[:, 1] = s * x + c * y + float(shift[i, 1])
+            frames.append(p.contiguous())
+        return cls(frames)
+
+    @classmethod
+    def from_numpy(cls, arrays, device):
+        return cls([torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+                    for a in arrays])
+
+
+class DeviceSweepLoader:
+    """Iterates the pool in dataset order (or a rank's shard) yielding ``example`` dicts with the
+    keys the detector reads (voxelnet.py:84-97, mg_head.py:710-724): ``voxel_features``,
+    ``coordinates``, ``num_points``, ``num_voxels``, ``shape``, ``anchors``, ``metadata``."""
+
+    def __init__(self, pool, voxel_cfg, anchors, batch_size=4, indices=None, device="cuda"):
+        self.pool = pool
+        self.batch_size = int(batch_size)
+        self.device = torch.device(device)
+        self.indices = list(range(len(pool))) if indices is None else list(indices)
+        self.voxelizer = Voxelizer(voxel_cfg["range"], voxel_cfg["voxel_size"],
+                                   voxel_cfg["max_points_in_voxel"], voxel_cfg["max_voxel_num"],
+                                   max_batch=self.batch_size, device=self.device)
+        self.anchors = [torch.as_tensor(a, dtype=torch.float32, device=self.device) for a in anchors]
+        self.dataset = pool          # len(loader.dataset) like a torch DataLoader
+        self.sampler = self.indices
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        gs = self.voxelizer.grid_size
+        for s in range(0, len(self.indices), self.batch_size):
+            ids = self.indices[s:s + self.batch_size]
+            frames = [self.pool.frames[i] for i in ids]
+            off = torch.tensor([0] + list(np.cumsum([f.shape[0] for f in frames])), dtype=torch.int64,
+                               device=self.device)
+            pts = torch.cat(frames, dim=0) if len(frames) > 1 else frames[0]
+            v = self.voxelizer(pts, off)
+            B = len(ids)
+            yield {
+                "voxel_features": v["feat"], "coordinates": v["coords"], "num_points": v["num_points"],
+                "num_voxels": v["num_voxels"],
+                "shape": np.tile(np.asarray(gs, dtype=np.int64)[None], (B, 1)),
+                "anchors": self.anchors,
+                "metadata": [{"token": self.pool.tokens[i], "index": i} for i in ids],
+            }

@@ -130,3 +130,55 @@ class Voxelizer:
         return dict(feat=feat[:m], coords=coords[:m], num_points=num_points[:m],
                     num_voxels=num_voxels, row_base=row_base,
                     voxels=None if voxels is None else voxels[:m])
+
+
+# ------------------------------------------------------------------ single sparse conv layer
+def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad, subm,
+                      scale=None, shift=None, residual=None, relu=False):
+    """One spconv layer on device (building block of the encoder, also used by the tests).
+    feats [n,Cin] f32, coords [n,4] i32 (b,z,y,x), weight [kz,ky,kx,Cin,Cout].
+    Returns (fout [n_out,Cout], coords_out [n_out,4], out_shape)."""
+    import ctypes
+    import numpy as np
+    dev = feats.device
+    st = _stream()
+    k = [int(v) for v in ksize]
+    n, cin = feats.shape
+    cout = weight.shape[-1]
+    K = k[0] * k[1] * k[2]
+    w = weight.reshape(K, cin, cout).contiguous().float()
+    D_, H_, W_ = [int(v) for v in in_shape]
+    grid_in = torch.full((batch * D_ * H_ * W_,), -1, dtype=torch.int32, device=dev)
+    lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch, D_, H_, W_, _ptr(grid_in), 1, st)
+    if subm:
+        nbr = torch.empty((max(n, 1), K), dtype=torch.int32, device=dev)
+        lib.call("al3d_sp_subm_table", _ptr(coords), n, batch, D_, H_, W_, _ptr(grid_in), k[0], k[1], k[2],
+                 _ptr(nbr), st)
+        ocoords, n_out, oshape = coords, n, [D_, H_, W_]
+    else:
+        s3, p3 = [int(v) for v in stride], [int(v) for v in pad]
+        oshape = [(in_shape[d] + 2 * p3[d] - (k[d] - 1) - 1) // s3[d] + 1 for d in range(3)]
+        grid_out = torch.full((batch * oshape[0] * oshape[1] * oshape[2],), -1, dtype=torch.int32, device=dev)
+        cap = min(n * K, grid_out.numel())
+        ocoords = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        I3 = ctypes.c_int * 3
+        lib.call("al3d_sp_down_claim", _ptr(coords), n, I3(*k), I3(*s3), I3(*p3), batch, *oshape,
+                 _ptr(grid_out), _ptr(ocoords), _ptr(counter), cap, st)
+        n_out = int(counter.item())
+        ocoords = ocoords[:n_out].contiguous()
+        nbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
+        lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
+                 _ptr(grid_in), _ptr(nbr), st)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    lib.call("al3d_sp_conv_f32", _ptr(feats), _ptr(nbr), K, _ptr(w), cin, cout, _ptr(scale), _ptr(shift),
+             _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+    return out, ocoords, oshape
+
+
+def box_decode(enc, anchors):
+    enc = _dev(enc, torch.float32, "enc").reshape(-1, 10)
+    anchors = _dev(anchors, torch.float32, "anchors").reshape(-1, 9)
+    out = torch.empty((enc.shape[0], 9), dtype=torch.float32, device=enc.device)
+    lib.call("al3d_box_decode_f32", _ptr(enc), _ptr(anchors), enc.shape[0], _ptr(out), _stream())
+    return out

@@ -44,6 +44,21 @@ SIGNATURES = {
     "al3d_voxelize_workspace_bytes": (c_i64, [c_i64, c_int, c_int]),
     "al3d_voxelize_mean_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_int, c_int,
                                        c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "al3d_sp_fill_i32": (c_int, [c_p, c_i64, c_int, c_p]),
+    "al3d_sp_scatter_index": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p]),
+    "al3d_sp_subm_table": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_int,
+                                   c_p, c_p]),
+    "al3d_sp_down_claim": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
+                                   c_p, c_int, c_p]),
+    "al3d_sp_down_table": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
+                                   c_p]),
+    "al3d_sp_conv_f32": (c_int, [c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int, c_p, c_int,
+                                 c_p]),
+    "al3d_sp_to_dense_nhwc": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_head_decode_nms": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                     c_flt, c_flt, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "al3d_box_decode_f32": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
+    "al3d_vfe_mean_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
     "al3d_conv2d_nhwc_f32": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p]),
     "al3d_deconv2x2_nhwc_f32": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_gap_nhwc_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p]),

@@ -1,0 +1,243 @@
+"""Sparse 3-D ResNet middle encoder (reference det3d/models/backbones/scn.py:54-97,316-392).
+
+Module tree and parameter names/layouts match the reference + spconv 1.2.1 so its
+checkpoints load: ``middle_conv{0..3}.<i>.weight [kz,ky,kx,Cin,Cout]``, SparseBasicBlock
+``conv{1,2}.{weight,bias}`` / ``bn{1,2}.*``.  The forward pass is a list of fused HIP layers
+(csrc/spconv.hip): conv + bias + BN(eval) (+residual) (+ReLU) per launch.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import lib
+from ..detector_ops import fold_bn
+from ..selector_ops import _ptr, _stream
+from .registry import BACKBONES
+
+
+class _SpConvParams(nn.Module):
+    """Parameter holder with spconv's layout ``weight [*k, Cin, Cout]``."""
+
+    def __init__(self, cin, cout, ksize, stride=1, padding=0, bias=False, subm=False):
+        super().__init__()
+        k = tuple(ksize) if isinstance(ksize, (tuple, list)) else (ksize,) * 3
+        s = tuple(stride) if isinstance(stride, (tuple, list)) else (stride,) * 3
+        p = tuple(padding) if isinstance(padding, (tuple, list)) else (padding,) * 3
+        self.in_channels, self.out_channels = cin, cout
+        self.kernel_size, self.stride, self.padding, self.subm = k, s, p, subm
+        self.weight = nn.Parameter(torch.empty(*k, cin, cout))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout))
+        else:
+            self.register_parameter("bias", None)
+        fan = cin * int(np.prod(k))
+        nn.init.uniform_(self.weight, -1.0 / fan ** 0.5, 1.0 / fan ** 0.5)
+
+
+class SubMConv3d(_SpConvParams):
+    def __init__(self, cin, cout, ksize, bias=True, indice_key=None):
+        super().__init__(cin, cout, ksize, 1, 0, bias, subm=True)
+        self.indice_key = indice_key
+
+
+class SparseConv3d(_SpConvParams):
+    def __init__(self, cin, cout, ksize, stride=1, padding=0, bias=True):
+        super().__init__(cin, cout, ksize, stride, padding, bias, subm=False)
+
+
+class SparseBasicBlock(nn.Module):
+    """conv1-bn1-relu-conv2-bn2-(+identity)-relu; the convs carry a bias (scn.py:68-73)."""
+
+    def __init__(self, inplanes, planes, indice_key=None):
+        super().__init__()
+        self.conv1 = SubMConv3d(inplanes, planes, 3, bias=True, indice_key=indice_key)
+        self.bn1 = nn.BatchNorm1d(planes, eps=1e-3, momentum=0.01)
+        self.relu = nn.ReLU()
+        self.conv2 = SubMConv3d(planes, planes, 3, bias=True, indice_key=indice_key)
+        self.bn2 = nn.BatchNorm1d(planes, eps=1e-3, momentum=0.01)
+
+
+class SparseTensor:
+    """Minimal stand-in for spconv.SparseConvTensor: features [N,C], indices [N,4] i32."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size):
+        self.features, self.indices = features, indices
+        self.spatial_shape, self.batch_size = list(spatial_shape), batch_size
+
+
+def _bn(c):
+    return nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+
+
+class _Level:
+    """Dense index grid of one resolution level, kept in HBM across calls."""
+
+    def __init__(self, shape, max_batch, device):
+        self.D, self.H, self.W = [int(s) for s in shape]
+        self.max_batch = max_batch
+        self.grid = torch.full((max_batch * self.D * self.H * self.W,), -1, dtype=torch.int32,
+                               device=device)
+
+
+def _i3(v):
+    return (ctypes.c_int * 3)(*[int(x) for x in v])
+
+
+class _SparseEncoderBase(nn.Module):
+    def _stages(self):
+        raise NotImplementedError
+
+    def _prepare(self, device):
+        """Pack weights / fold BN once per device (eval only)."""
+        if getattr(self, "_packed_dev", None) == device:
+            return
+        plan = []
+        for seq in self._stages():
+            mods = list(seq.children())
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, _SpConvParams):
+                    bn = mods[i + 1]
+                    scale, shift = fold_bn(bn)
+                    plan.append(dict(kind="subm" if m.subm else "down", mod=m,
+                                     w=m.weight.detach().reshape(-1, m.in_channels, m.out_channels)
+                                     .contiguous().float().to(device),
+                                     scale=scale.to(device), shift=shift.to(device), relu=True,
+                                     residual=False))
+                    i += 3  # conv, bn, relu
+                elif isinstance(m, SparseBasicBlock):
+                    for conv, bn, last in ((m.conv1, m.bn1, False), (m.conv2, m.bn2, True)):
+                        scale, shift = fold_bn(bn)
+                        if conv.bias is not None:   # (x + b) * s + t
+                            shift = shift + conv.bias.detach().float().to(scale.device) * scale
+                        plan.append(dict(kind="subm", mod=conv,
+                                         w=conv.weight.detach().reshape(-1, conv.in_channels,
+                                                                         conv.out_channels)
+                                         .contiguous().float().to(device),
+                                         scale=scale.to(device), shift=shift.to(device), relu=True,
+                                         residual=last, block_start=not last))
+                    i += 1
+                else:
+                    i += 1
+            plan.append(dict(kind="stage_end"))
+        self._plan = plan
+        self._packed_dev = device
+        self._levels = {}
+
+    def _level(self, shape, batch, device):
+        key = tuple(int(s) for s in shape)
+        lv = self._levels.get(key)
+        if lv is None or lv.max_batch < batch:
+            lv = _Level(key, max(batch, 1), device)
+            self._levels[key] = lv
+        return lv
+
+    @staticmethod
+    def _out_shape(shape, k, s, p):
+        return [(shape[d] + 2 * p[d] - (k[d] - 1) - 1) // s[d] + 1 for d in range(3)]
+
+    def _run(self, feats, coords, batch_size, spatial_shape):
+        """Returns (final SparseTensor, [SparseTensor per stage])."""
+        if self.training:
+            raise RuntimeError("al3d sparse encoder implements the eval() sweep only")
+        dev = feats.device
+        self._prepare(dev)
+        st = _stream()
+        coords = coords.to(torch.int32).contiguous()
+        feats = feats.float().contiguous()
+        shape = [int(s) for s in spatial_shape]
+        n = feats.shape[0]
+        lv = self._level(shape, batch_size, dev)
+        lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W, _ptr(lv.grid),
+                 1, st)
+        used = [(lv, coords, n)]
+        nbr, nbr_key = None, None
+        middle = []
+        identity = None
+        for step in self._plan:
+            if step["kind"] == "stage_end":
+                middle.append(SparseTensor(feats, coords, shape, batch_size))
+                continue
+            m = step["mod"]
+            K = int(np.prod(m.kernel_size))
+            if step["kind"] == "subm":
+                key = (id(lv), m.kernel_size)
+                if nbr_key != key:
+                    nbr = torch.empty((max(n, 1), K), dtype=torch.int32, device=dev)
+                    lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
+                             _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
+                    nbr_key = key
+                if step.get("block_start"):
+                    identity = feats
+                out = torch.empty((n, m.out_channels), dtype=torch.float32, device=dev)
+                lib.call("al3d_sp_conv_f32", _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels,
+                         m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]),
+                         _ptr(identity) if step["residual"] else None, 1, _ptr(out), n, st)
+                feats = out
+            else:
+                oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
+                olv = self._level(oshape, batch_size, dev)
+                cap = min(n * K, batch_size * olv.D * olv.H * olv.W)
+                ocoords = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
+                counter = torch.zeros(1, dtype=torch.int32, device=dev)
+                ks, ss, ps = _i3(m.kernel_size), _i3(m.stride), _i3(m.padding)
+                lib.call("al3d_sp_down_claim", _ptr(coords), n, ks, ss, ps, batch_size, olv.D, olv.H,
+                         olv.W, _ptr(olv.grid), _ptr(ocoords), _ptr(counter), cap, st)
+                n_out = int(counter.item())      # one small D2H per stage
+                ocoords = ocoords[:n_out]
+                used.append((olv, ocoords, n_out))
+                dnbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
+                lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
+                         lv.W, _ptr(lv.grid), _ptr(dnbr), st)
+                out = torch.empty((n_out, m.out_channels), dtype=torch.float32, device=dev)
+                lib.call("al3d_sp_conv_f32", _ptr(feats), _ptr(dnbr), K, _ptr(step["w"]), m.in_channels,
+                         m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), None, 1, _ptr(out),
+                         n_out, st)
+                feats, coords, n, shape, lv = out, ocoords, n_out, oshape, olv
+                nbr_key = None
+        for g, c, cnt in used:      # leave every level grid clean for the next call
+            lib.call("al3d_sp_scatter_index", _ptr(c), cnt, batch_size, g.D, g.H, g.W, _ptr(g.grid), 0, st)
+        return SparseTensor(feats, coords, shape, batch_size), middle
+
+    @staticmethod
+    def dense_nhwc(sp):
+        """``ret.dense()`` + ``view(N, C*D, H, W)`` in NHWC: [B, H, W, C*D], channel = c*D + z."""
+        D, H, W = sp.spatial_shape
+        C = sp.features.shape[1]
+        out = torch.zeros((sp.batch_size, H, W, C * D), dtype=torch.float32, device=sp.features.device)
+        lib.call("al3d_sp_to_dense_nhwc", _ptr(sp.features), _ptr(sp.indices), sp.features.shape[0], C,
+                 sp.batch_size, D, H, W, _ptr(out), _stream())
+        return out
+
+
+@BACKBONES.register_module
+class FPNSpMiddleResNetFHD(_SparseEncoderBase):
+    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", **kwargs):
+        super().__init__()
+        self.name = name
+        self.middle_conv0 = nn.Sequential(
+            SubMConv3d(num_input_features, 16, 3, bias=False, indice_key="res0"), _bn(16), nn.ReLU(),
+            SparseBasicBlock(16, 16, indice_key="res0"), SparseBasicBlock(16, 16, indice_key="res0"),
+            SparseConv3d(16, 32, 3, 2, padding=1, bias=False), _bn(32), nn.ReLU())
+        self.middle_conv1 = nn.Sequential(
+            SparseBasicBlock(32, 32, indice_key="res1"), SparseBasicBlock(32, 32, indice_key="res1"),
+            SparseConv3d(32, 64, 3, 2, padding=1, bias=False), _bn(64), nn.ReLU())
+        self.middle_conv2 = nn.Sequential(
+            SparseBasicBlock(64, 64, indice_key="res2"), SparseBasicBlock(64, 64, indice_key="res2"),
+            SparseConv3d(64, 128, 3, 2, padding=[0, 1, 1], bias=False), _bn(128), nn.ReLU())
+        self.middle_conv3 = nn.Sequential(
+            SparseBasicBlock(128, 128, indice_key="res3"), SparseBasicBlock(128, 128, indice_key="res3"),
+            SparseConv3d(128, 128, (3, 1, 1), (2, 1, 1), bias=False), _bn(128), nn.ReLU())
+
+    def _stages(self):
+        return [self.middle_conv0, self.middle_conv1, self.middle_conv2, self.middle_conv3]
+
+    def forward(self, voxel_features, coors, batch_size, input_shape):
+        """-> (dense NHWC [B,128,128,256], middle list of 4 SparseTensor) -- the reference
+        returns NCHW (scn.py:371-392); this build keeps activations channels-last."""
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        final, middle = self._run(voxel_features, coors, batch_size, sparse_shape)
+        return self.dense_nhwc(final), middle

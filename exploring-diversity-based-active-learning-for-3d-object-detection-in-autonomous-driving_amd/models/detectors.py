@@ -1,0 +1,92 @@
+"""Detector graphs (reference det3d/models/detectors/{single_stage,voxelnet}.py).
+
+Call contract kept: ``detector(example, return_loss=False, estimate=True)`` returns
+``(list[dict(box3d_lidar, scores, label_preds, metadata)], middle)`` with ``middle[-1]`` the
+neck output (voxelnet.py:73-81,115-116).  Activations are channels-last in this build, so
+``middle[-1]`` is wrapped in ``NHWCFeature`` whose ``mean(-1).mean(-1)`` -- the expression the
+selectors apply to it (feature_selector.py:68-71) -- runs the device GAP kernel.
+"""
+import torch
+from torch import nn
+
+from .. import detector_ops as D
+from . import builder
+from .registry import DETECTORS
+
+
+class NHWCFeature:
+    """A ``[B,C,H,W]``-shaped view of an NHWC buffer for the selectors' embedding tap."""
+
+    def __init__(self, nhwc):
+        self.nhwc = nhwc
+        B, H, W, C = nhwc.shape
+        self.shape = torch.Size((B, C, H, W))
+        self.device = nhwc.device
+        self._w_reduced = False
+
+    def mean(self, dim=-1):
+        if not self._w_reduced:
+            r = NHWCFeature.__new__(NHWCFeature)
+            r.nhwc, r.shape, r.device, r._w_reduced = self.nhwc, self.shape[:3], self.device, True
+            return r
+        return D.gap_nhwc(self.nhwc)          # mean over W, then over H, in one kernel
+
+    def nchw(self):
+        return self.nhwc.permute(0, 3, 1, 2)
+
+
+@DETECTORS.register_module
+class SingleStageDetector(nn.Module):
+    def __init__(self, reader, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__()
+        self.reader = builder.build_reader(reader)
+        self.backbone = builder.build_backbone(backbone)
+        if neck is not None:
+            self.neck = builder.build_neck(neck)
+        self.bbox_head = builder.build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+
+    @property
+    def with_neck(self):
+        return hasattr(self, "neck") and self.neck is not None
+
+
+@DETECTORS.register_module
+class FPNVoxelNet(SingleStageDetector):
+    def extract_feat(self, data):
+        if data.get("mean_features") is not None:     # device voxelizer already reduced the points
+            input_features = data["mean_features"]
+        else:
+            input_features = self.reader(data["features"], data["num_voxels"])
+        x, middle = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+        if self.with_neck:
+            x = self.neck(x)
+            middle.append(NHWCFeature(x))
+        return x, middle
+
+    def forward(self, example, return_loss=True, finetune=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError("al3d implements the inference sweep, not training")
+        num_voxels = example["num_voxels"]
+        data = dict(features=example.get("voxels"), num_voxels=example.get("num_points"),
+                    mean_features=example.get("voxel_features"), coors=example["coordinates"],
+                    batch_size=len(num_voxels), input_shape=example["shape"][0])
+        x, middle = self.extract_feat(data)
+        preds = self.bbox_head(x, finetune=finetune)
+        if kwargs.get("get_preds", False):
+            return preds
+        out = self.bbox_head.predict(example, preds, self.test_cfg)
+        if kwargs.get("estimate", False):
+            return out, middle
+        return out
+
+
+@DETECTORS.register_module
+class VoxelNet(FPNVoxelNet):
+    """Same graph; ``forward`` returns detections only (voxelnet.py:8-55)."""
+
+    def forward(self, example, return_loss=True, **kwargs):
+        kwargs.pop("estimate", None)
+        return super().forward(example, return_loss=return_loss, **kwargs)

@@ -1,0 +1,125 @@
+"""SECOND-style dense neck (reference det3d/models/necks/rpn.py:22-159).
+
+Same module tree / parameter names as the reference (``blocks.<b>.<i>``, ``deblocks.<b>.<i>``)
+so its state dicts load; the forward pass runs the fused conv+BN+ReLU MFMA kernels on
+NHWC activations and writes both deblock outputs straight into the concatenated
+``[B,128,128,512]`` buffer (no ``torch.cat`` copy).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import detector_ops as D
+from .registry import NECKS
+
+
+@NECKS.register_module
+class RPN(nn.Module):
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides,
+                 us_num_filters, num_input_features, norm_cfg=None, name="rpn", logger=None,
+                 **kwargs):
+        super().__init__()
+        self._layer_strides = ds_layer_strides
+        self._num_filters = ds_num_filters
+        self._layer_nums = layer_nums
+        self._upsample_strides = us_layer_strides
+        self._num_upsample_filters = us_num_filters
+        self._num_input_features = num_input_features
+        assert len(ds_layer_strides) == len(layer_nums) == len(ds_num_filters)
+        assert len(us_num_filters) == len(us_layer_strides)
+        self._upsample_start_idx = len(layer_nums) - len(us_layer_strides)
+        eps = 1e-3 if norm_cfg is None else norm_cfg.get("eps", 1e-5)
+        mom = 0.01 if norm_cfg is None else norm_cfg.get("momentum", 0.1)
+
+        def bn(c):
+            return nn.BatchNorm2d(c, eps=eps, momentum=mom)
+
+        in_filters = [num_input_features, *ds_num_filters[:-1]]
+        blocks, deblocks = [], []
+        for i, layer_num in enumerate(layer_nums):
+            planes = ds_num_filters[i]
+            layers = [nn.ZeroPad2d(1), nn.Conv2d(in_filters[i], planes, 3, stride=ds_layer_strides[i], bias=False),
+                      bn(planes), nn.ReLU()]
+            for _ in range(layer_num):
+                layers += [nn.Conv2d(planes, planes, 3, padding=1, bias=False), bn(planes), nn.ReLU()]
+            blocks.append(nn.Sequential(*layers))
+            if i - self._upsample_start_idx >= 0:
+                stride = us_layer_strides[i - self._upsample_start_idx]
+                cout = us_num_filters[i - self._upsample_start_idx]
+                if stride > 1:
+                    up = nn.ConvTranspose2d(planes, cout, stride, stride=stride, bias=False)
+                else:
+                    s = int(np.round(1 / stride))
+                    up = nn.Conv2d(planes, cout, s, stride=s, bias=False)
+                deblocks.append(nn.Sequential(up, bn(cout), nn.ReLU()))
+        self.blocks = nn.ModuleList(blocks)
+        self.deblocks = nn.ModuleList(deblocks)
+        if logger is not None:
+            logger.info("Finish RPN Initialization")
+
+    @property
+    def downsample_factor(self):
+        factor = np.prod(self._layer_strides)
+        if len(self._upsample_strides) > 0:
+            factor /= self._upsample_strides[-1]
+        return factor
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+
+    def _prepare(self, device):
+        if getattr(self, "_packed_dev", None) == device:
+            return
+        self._blocks_p, self._deblocks_p = [], []
+        for blk in self.blocks:
+            mods = list(blk.children())
+            convs = []
+            for j, m in enumerate(mods):
+                if isinstance(m, nn.Conv2d):
+                    scale, shift = D.fold_bn(mods[j + 1])
+                    pad = 1 if (j > 0 and isinstance(mods[j - 1], nn.ZeroPad2d)) else m.padding[0]
+                    convs.append(dict(w=D.pack_conv_weight(m.weight).to(device), scale=scale.to(device),
+                                      shift=shift.to(device), k=m.kernel_size[0], s=m.stride[0], p=pad))
+            self._blocks_p.append(convs)
+        for de in self.deblocks:
+            up, bn = de[0], de[1]
+            scale, shift = D.fold_bn(bn)
+            if isinstance(up, nn.ConvTranspose2d):
+                assert up.kernel_size == (2, 2) and up.stride == (2, 2), "only 2x2/s2 deconv is built"
+                self._deblocks_p.append(dict(deconv=True, w=D.pack_deconv_weight(up.weight).to(device),
+                                             scale=scale.to(device), shift=shift.to(device)))
+            else:
+                self._deblocks_p.append(dict(deconv=False, w=D.pack_conv_weight(up.weight).to(device),
+                                             scale=scale.to(device), shift=shift.to(device),
+                                             k=up.kernel_size[0], s=up.stride[0]))
+        self._packed_dev = device
+
+    def forward(self, x):
+        """x NHWC [B,H,W,Cin] -> NHWC [B,H',W',sum(us_num_filters)]."""
+        if self.training:
+            raise RuntimeError("al3d RPN implements the eval() sweep only")
+        self._prepare(x.device)
+        out, coff = None, 0
+        ctot = sum(self._num_upsample_filters)
+        for i, convs in enumerate(self._blocks_p):
+            for c in convs:
+                x = D.conv2d_nhwc(x, c["w"], c["scale"], c["shift"], c["k"], c["s"], c["p"], True)
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                d = self._deblocks_p[j]
+                B, H, W, _ = x.shape
+                if d["deconv"]:
+                    if out is None:
+                        out = torch.empty((B, 2 * H, 2 * W, ctot), dtype=torch.float32, device=x.device)
+                    D.deconv2x2_nhwc(x, d["w"], d["scale"], d["shift"], True, out=out, coff=coff)
+                else:
+                    oh = (H - d["k"]) // d["s"] + 1
+                    ow = (W - d["k"]) // d["s"] + 1
+                    if out is None:
+                        out = torch.empty((B, oh, ow, ctot), dtype=torch.float32, device=x.device)
+                    D.conv2d_nhwc(x, d["w"], d["scale"], d["shift"], d["k"], d["s"], 0, True, out=out,
+                                  coff=coff)
+                coff += d["w"].shape[0]
+        return out if out is not None else x

@@ -141,6 +141,66 @@ int al3d_voxelize_mean_f32(const float* points, const int64_t* point_offsets, in
                            void* workspace, float* feat, int* coords, int* num_points, float* voxels,
                            int* num_voxels, int* row_base, void* stream);
 
+/* Mean VFE on reference-format input: voxels [m,max_points,nfeat] zero-padded, counts [m] i32
+ * -> feat [m,nfeat].  Replaces VoxelFeatureExtractorV3.forward
+ * (det3d/models/readers/voxel_encoder.py:206-211). */
+int al3d_vfe_mean_f32(const float* voxels, const int* num_points, int m, int max_points, int nfeat,
+                      float* feat, void* stream);
+
+/* ---------------------------------------------------------------- detector: head */
+
+/* Decode + score + top-k + rotated NMS + range mask for every (sample, task) pair, one
+ * workgroup each.  hout is the fused NHWC head output [B, HW, CH]; task t reads its box
+ * codes at channels [box_off[t], +na*10) and class logits at [cls_off[t], +na*nc).
+ * anchors: HOST array of ntasks DEVICE pointers to [A_t, 9]; the int arrays are HOST arrays.
+ * Outputs [B, ntasks, post_max, *] + counts [B, ntasks].
+ * Replaces MultiGroupHead.predict/get_task_detections (det3d/models/bbox_heads/mg_head.py:697-1085),
+ * second_box_decode (det3d/core/bbox/box_torch_ops.py:80-148), rotate_nms
+ * (box_torch_ops.py:528-550) and rotate_non_max_suppression_cpu (det3d/ops/nms/nms_cpu.h:73-168). */
+int al3d_head_decode_nms(const float* hout, int B, int HW, int CH, int ntasks,
+                         const float* const* anchors, const int* task_A, const int* task_na,
+                         const int* task_nc, const int* box_off, const int* cls_off,
+                         const int* label_off, float score_thresh, float iou_thresh, int pre_max,
+                         int post_max, const float* range6, float* boxes, float* scores, int* labels,
+                         int* counts, void* stream);
+
+/* Residual box decode (9-dim boxes, vector-encoded angle): enc [n,10], anchors [n,9] -> [n,9].
+ * Replaces GroundBox3dCoderTorch.decode_torch -> second_box_decode
+ * (det3d/core/bbox/box_coders.py:106-109, det3d/core/bbox/box_torch_ops.py:80-148). */
+int al3d_box_decode_f32(const float* enc, const float* anchors, int64_t n, float* out, void* stream);
+
+/* ---------------------------------------------------------------- detector: sparse encoder */
+
+/* Sparse 3-D convolution pieces.  Replace the spconv calls of FPNSpMiddleResNetFHD
+ * (det3d/models/backbones/scn.py:28-97,316-392: SubMConv3d / SparseConv3d /
+ * SparseConvTensor.dense()).  coords are [n,4] i32 (batch, z, y, x); `grid` is a dense
+ * per-level index grid [B,D,H,W] i32 holding the row id of every active site (-1 = empty)
+ * that the caller keeps in HBM across calls.  The rulebook is output-major:
+ * nbr[o][k] = input row feeding output o through kernel offset k = (kz*kh+ky)*kw+kx, or -1. */
+int al3d_sp_fill_i32(int* buf, int64_t count, int value, void* stream);          /* 0 or -1 */
+int al3d_sp_scatter_index(const int* coords, int n, int B, int D, int H, int W, int* grid,
+                          int mode /* 1: grid=row id, 0: grid=-1 */, void* stream);
+int al3d_sp_subm_table(const int* coords, int n, int B, int D, int H, int W, const int* grid,
+                       int kd, int kh, int kw, int* nbr, void* stream);
+/* strided conv: discover output sites (coords_out rows in arbitrary order, *counter = count,
+ * grid_out filled with their row ids) ... ksize/stride/pad are HOST int[3] (z, y, x). */
+int al3d_sp_down_claim(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                       const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                       int* coords_out, int* counter, int cap, void* stream);
+/* ... then its rulebook from the input level's grid */
+int al3d_sp_down_table(const int* coords_out, int n_out, const int* ksize, const int* stride,
+                       const int* pad, int B, int ID, int IH, int IW, const int* grid_in, int* nbr,
+                       void* stream);
+/* out[o] = relu?( (sum_k W[k]^T in[nbr[o][k]]) * scale + shift (+ residual[o]) ); wgt is the
+ * spconv layout [K, Cin, Cout] (= [kz,ky,kx,Cin,Cout] flattened).  One launch per layer. */
+int al3d_sp_conv_f32(const float* fin, const int* nbr, int K, const float* wgt, int cin, int cout,
+                     const float* scale, const float* shift, const float* residual, int relu,
+                     float* fout, int n_out, void* stream);
+/* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
+ * out must be zero-filled. */
+int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D, int H,
+                          int W, float* out, void* stream);
+
 /* ---------------------------------------------------------------- detector: dense */
 
 /* NHWC f32 convolution on the fp32 matrix cores with fused per-channel

@@ -70,3 +70,192 @@ int64_t al3d_oracle_voxelize(const float* pts, int64_t npts, int nfeat, const fl
     free(cell_to_voxel);
     return nvox;
 }
+
+/* ------------------------------------------------------------------ sparse conv
+ * Rulebook + conv in the spconv formulation: per kernel offset k a list of (in,out) pairs
+ * (getIndicePairsConv / getIndicePairsSubM, geometry.h:145-194,248-298) and
+ * out[o] += in[i] @ W[k] for every pair, k ascending (indiceConv, spconv_ops.h:260-361).
+ * Output sites of a strided conv are numbered in first-touch order like the CPU rulebook.
+ * coords: [n,4] (b,z,y,x).  Returns the number of output rows. */
+static int64_t cell_of(const int* c, const int* shape)
+{
+    return (((int64_t)c[0] * shape[0] + c[1]) * shape[1] + c[2]) * shape[2] + c[3];
+}
+
+int64_t al3d_oracle_spconv(const float* fin, const int* coords_in, int64_t n_in, int batch,
+                           const int* in_shape, const float* wgt, int cin, int cout,
+                           const int* ksize, const int* stride, const int* pad, int subm,
+                           float* fout, int* coords_out, int64_t cap_out, int* out_shape)
+{
+    int k3[3] = {ksize[0], ksize[1], ksize[2]};
+    int p3[3] = {pad[0], pad[1], pad[2]};
+    if (subm) for (int d = 0; d < 3; ++d) p3[d] = k3[d] / 2;
+    for (int d = 0; d < 3; ++d)
+        out_shape[d] = subm ? in_shape[d] : (in_shape[d] + 2 * p3[d] - (k3[d] - 1) - 1) / stride[d] + 1;
+    const int64_t ocells = (int64_t)batch * out_shape[0] * out_shape[1] * out_shape[2];
+    int* grid = (int*)malloc(sizeof(int) * (size_t)ocells);
+    memset(grid, 0xff, sizeof(int) * (size_t)ocells);
+    int64_t n_out = 0;
+    if (subm) {
+        for (int64_t i = 0; i < n_in; ++i) {
+            grid[cell_of(coords_in + 4 * i, out_shape)] = (int)i;
+            memcpy(coords_out + 4 * i, coords_in + 4 * i, sizeof(int) * 4);
+        }
+        n_out = n_in;
+    }
+    const int K = k3[0] * k3[1] * k3[2];
+    /* pairs per offset */
+    int64_t* cnt = (int64_t*)calloc((size_t)K, sizeof(int64_t));
+    int* pin = (int*)malloc(sizeof(int) * (size_t)(K * n_in + 1));
+    int* pout = (int*)malloc(sizeof(int) * (size_t)(K * n_in + 1));
+    for (int64_t i = 0; i < n_in; ++i) {
+        const int* c = coords_in + 4 * i;
+        for (int kz = 0; kz < k3[0]; ++kz) for (int ky = 0; ky < k3[1]; ++ky) for (int kx = 0; kx < k3[2]; ++kx) {
+            const int kk[3] = {kz, ky, kx};
+            int o[4] = {c[0], 0, 0, 0}, ok = 1;
+            for (int d = 0; d < 3; ++d) {
+                const int s = subm ? 1 : stride[d];
+                const int t = c[1 + d] + p3[d] - kk[d];
+                if (t < 0 || t % s) { ok = 0; break; }
+                o[1 + d] = t / s;
+                if (o[1 + d] >= out_shape[d]) { ok = 0; break; }
+            }
+            if (!ok) continue;
+            const int64_t cell = cell_of(o, out_shape);
+            if (grid[cell] == -1) {
+                if (subm) continue;                 /* SubM: only existing sites are outputs */
+                if (n_out >= cap_out) { free(grid); free(cnt); free(pin); free(pout); return -1; }
+                memcpy(coords_out + 4 * n_out, o, sizeof(int) * 4);
+                grid[cell] = (int)n_out++;
+            }
+            const int k = (kz * k3[1] + ky) * k3[2] + kx;
+            pin[k * n_in + cnt[k]] = (int)i;
+            pout[k * n_in + cnt[k]] = grid[cell];
+            cnt[k]++;
+        }
+    }
+    memset(fout, 0, sizeof(float) * (size_t)(n_out * cout));
+    for (int k = 0; k < K; ++k) {
+        const float* w = wgt + (int64_t)k * cin * cout;
+        for (int64_t q = 0; q < cnt[k]; ++q) {
+            const float* a = fin + (int64_t)pin[k * n_in + q] * cin;
+            float* o = fout + (int64_t)pout[k * n_in + q] * cout;
+            for (int co = 0; co < cout; ++co) {
+                float s = 0.f;
+                for (int ci = 0; ci < cin; ++ci) s += a[ci] * w[ci * cout + co];
+                o[co] += s;
+            }
+        }
+    }
+    free(grid); free(cnt); free(pin); free(pout);
+    return n_out;
+}
+
+/* ------------------------------------------------------------------ box decode
+ * second_box_decode, encode_angle_to_vector=True, smooth_dim=False, norm_velo=False
+ * (det3d/core/bbox/box_torch_ops.py:80-148). enc [n,10], anchors [n,9] -> out [n,9]. */
+void al3d_oracle_box_decode(const float* enc, const float* anc, int64_t n, float* out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float* t = enc + 10 * i; const float* a = anc + 9 * i; float* o = out + 9 * i;
+        const float diag = sqrtf(a[4] * a[4] + a[3] * a[3]);
+        o[0] = t[0] * diag + a[0];
+        o[1] = t[1] * diag + a[1];
+        o[2] = t[2] * a[5] + a[2];
+        o[3] = expf(t[3]) * a[3];
+        o[4] = expf(t[4]) * a[4];
+        o[5] = expf(t[5]) * a[5];
+        o[6] = t[6] + a[6];
+        o[7] = t[7] + a[7];
+        o[8] = atan2f(t[9] + sinf(a[8]), t[8] + cosf(a[8]));
+    }
+}
+
+/* ------------------------------------------------------------------ rotated NMS
+ * rotate_nms_cc + rotate_non_max_suppression_cpu (det3d/ops/nms/nms_cpu.py:34-45,
+ * det3d/ops/nms/nms_cpu.h:73-168): corners (box_np_ops.py:479-499), standup boxes, skip pairs
+ * with standup IoU <= 0, suppress when polygon IoU >= thresh.  boost::geometry is restated as
+ * a convex clip (both polygons are rectangles) + shoelace; union = |A| + |B| - |A n B|.
+ * dets [n,5] (x,y,w,l,r) ALREADY in descending score order.  Returns kept count. */
+static void corners_of(const float* d, float* cx, float* cy)
+{
+    const float c = cosf(d[4]), s = sinf(d[4]);
+    const float ux[4] = {-0.5f, -0.5f, 0.5f, 0.5f}, uy[4] = {-0.5f, 0.5f, 0.5f, -0.5f};
+    for (int k = 0; k < 4; ++k) {
+        const float px = ux[k] * d[2], py = uy[k] * d[3];
+        cx[k] = px * c + py * s + d[0];
+        cy[k] = -px * s + py * c + d[1];
+    }
+}
+
+static float poly_area(const float* x, const float* y, int n)
+{
+    float a = 0.f;
+    for (int k = 0; k < n; ++k) { int k2 = k + 1 == n ? 0 : k + 1; a += x[k] * y[k2] - x[k2] * y[k]; }
+    return 0.5f * fabsf(a);
+}
+
+static float clip_area(const float* ax, const float* ay, const float* bx, const float* by)
+{
+    float px[16], py[16], qx[16], qy[16];
+    int n = 4;
+    for (int k = 0; k < 4; ++k) { px[k] = ax[k]; py[k] = ay[k]; }
+    float barea = 0.f;
+    for (int k = 0; k < 4; ++k) { int k2 = (k + 1) & 3; barea += bx[k] * by[k2] - bx[k2] * by[k]; }
+    const float sgn = barea >= 0.f ? 1.f : -1.f;
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const int e2 = (e + 1) & 3;
+        const float ex = bx[e2] - bx[e], ey = by[e2] - by[e];
+        int m = 0;
+        for (int k = 0; k < n; ++k) {
+            const int k2 = k + 1 == n ? 0 : k + 1;
+            const float d1 = sgn * (ex * (py[k] - by[e]) - ey * (px[k] - bx[e]));
+            const float d2 = sgn * (ex * (py[k2] - by[e]) - ey * (px[k2] - bx[e]));
+            if (d1 >= 0.f) { qx[m] = px[k]; qy[m] = py[k]; ++m; }
+            if ((d1 >= 0.f) != (d2 >= 0.f)) {
+                const float tt = d1 / (d1 - d2);
+                qx[m] = px[k] + tt * (px[k2] - px[k]);
+                qy[m] = py[k] + tt * (py[k2] - py[k]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int k = 0; k < n; ++k) { px[k] = qx[k]; py[k] = qy[k]; }
+    }
+    return n < 3 ? 0.f : poly_area(px, py, n);
+}
+
+int64_t al3d_oracle_rotate_nms(const float* dets, int64_t n, float thresh, int64_t post_max, int* keep)
+{
+    float* cx = (float*)malloc(sizeof(float) * 4 * (size_t)(n + 1));
+    float* cy = (float*)malloc(sizeof(float) * 4 * (size_t)(n + 1));
+    float* sb = (float*)malloc(sizeof(float) * 4 * (size_t)(n + 1));
+    unsigned char* sup = (unsigned char*)calloc((size_t)(n + 1), 1);
+    for (int64_t i = 0; i < n; ++i) {
+        corners_of(dets + 5 * i, cx + 4 * i, cy + 4 * i);
+        float x1 = cx[4 * i], x2 = x1, y1 = cy[4 * i], y2 = y1;
+        for (int k = 1; k < 4; ++k) {
+            x1 = fminf(x1, cx[4 * i + k]); x2 = fmaxf(x2, cx[4 * i + k]);
+            y1 = fminf(y1, cy[4 * i + k]); y2 = fmaxf(y2, cy[4 * i + k]);
+        }
+        sb[4 * i] = x1; sb[4 * i + 1] = y1; sb[4 * i + 2] = x2; sb[4 * i + 3] = y2;
+    }
+    int64_t kept = 0;
+    for (int64_t i = 0; i < n && kept < post_max; ++i) {
+        if (sup[i]) continue;
+        keep[kept++] = (int)i;
+        const float ai = poly_area(cx + 4 * i, cy + 4 * i, 4);
+        for (int64_t j = i + 1; j < n; ++j) {
+            if (sup[j]) continue;
+            const float iw = fminf(sb[4 * i + 2], sb[4 * j + 2]) - fmaxf(sb[4 * i], sb[4 * j]);
+            const float ih = fminf(sb[4 * i + 3], sb[4 * j + 3]) - fmaxf(sb[4 * i + 1], sb[4 * j + 1]);
+            if (!(iw > 0.f && ih > 0.f)) continue;
+            const float inter = clip_area(cx + 4 * i, cy + 4 * i, cx + 4 * j, cy + 4 * j);
+            if (!(inter > 0.f)) continue;
+            const float uni = ai + poly_area(cx + 4 * j, cy + 4 * j, 4) - inter;
+            if (uni > 0.f && inter / uni >= thresh) sup[j] = 1;
+        }
+    }
+    free(cx); free(cy); free(sb); free(sup);
+    return kept;
+}

@@ -190,3 +190,58 @@ def voxelize(points, range_min, voxel_size, grid, max_points, max_voxels):
     m = fn(_p(pts), c_i64(n), c_int(f), _p(rm), _p(vs), _p(g), c_int(max_points), c_int(max_voxels),
            _p(voxels), _p(coords), _p(npo), _p(feat))
     return voxels[:m].copy(), coords[:m].copy(), npo[:m].copy(), feat[:m].copy()
+
+
+def spconv(fin, coords, batch, in_shape, wgt, ksize, stride, pad, subm):
+    """One sparse conv layer (no bias/BN).  wgt [kz,ky,kx,Cin,Cout].  Returns
+    (fout [n_out,Cout], coords_out [n_out,4], out_shape)."""
+    fin = _c(fin, np.float32); coords = _c(coords, np.int32); wgt = _c(wgt, np.float32)
+    n, cin = fin.shape
+    cout = wgt.shape[-1]
+    K = int(np.prod(wgt.shape[:3]))
+    cap = n if subm else n * K
+    fout = np.zeros((max(cap, 1), cout), dtype=np.float32)
+    cout_c = np.zeros((max(cap, 1), 4), dtype=np.int32)
+    oshape = np.zeros(3, dtype=np.int32)
+    fn = lib().al3d_oracle_spconv
+    fn.restype = c_i64
+    m = fn(_p(fin), _p(coords), c_i64(n), c_int(batch), _p(_c(in_shape, np.int32)), _p(wgt),
+           c_int(cin), c_int(cout), _p(_c(ksize, np.int32)), _p(_c(stride, np.int32)),
+           _p(_c(pad, np.int32)), c_int(1 if subm else 0), _p(fout), _p(cout_c), c_i64(cap), _p(oshape))
+    assert m >= 0
+    return fout[:m].copy(), cout_c[:m].copy(), oshape.tolist()
+
+
+def box_decode(enc, anchors):
+    enc = _c(enc, np.float32).reshape(-1, 10); anc = _c(anchors, np.float32).reshape(-1, 9)
+    out = np.empty((enc.shape[0], 9), dtype=np.float32)
+    lib().al3d_oracle_box_decode(_p(enc), _p(anc), c_i64(enc.shape[0]), _p(out))
+    return out
+
+
+def rotate_nms(dets_sorted, thresh, post_max):
+    """dets [n,5] (x,y,w,l,r) in descending score order -> kept indices."""
+    d = _c(dets_sorted, np.float32)
+    keep = np.zeros(max(len(d), 1), dtype=np.int32)
+    fn = lib().al3d_oracle_rotate_nms
+    fn.restype = c_i64
+    k = fn(_p(d), c_i64(len(d)), ctypes.c_float(thresh), c_i64(post_max), _p(keep))
+    return keep[:k].copy()
+
+
+def head_predict(hout, anchors, na, nc, box_off, cls_off, score_thresh, iou_thresh, pre_max,
+                 post_max, rng):
+    """One (sample, task): numpy restatement of get_task_detections around the C pieces.
+    hout [HW, CH].  Returns (boxes [K,9], scores [K], labels [K])."""
+    hw = hout.shape[0]
+    cls = hout[:, cls_off:cls_off + na * nc].reshape(hw * na, nc).astype(np.float32)
+    sc = (1.0 / (1.0 + np.exp(-cls.astype(np.float64)))).astype(np.float32)
+    top = sc.max(1); lab = sc.argmax(1)
+    idx = np.nonzero(top >= np.float32(score_thresh))[0]
+    order = idx[np.lexsort((idx, -top[idx].astype(np.float64)))][:pre_max]   # score desc, index asc
+    enc = hout[:, box_off:box_off + na * 10].reshape(hw * na, 10)[order]
+    boxes = box_decode(enc, anchors[order])
+    keep = rotate_nms(boxes[:, [0, 1, 3, 4, 8]], iou_thresh, post_max)
+    b, s, l = boxes[keep], top[order][keep], lab[order][keep]
+    m = np.all(b[:, :3] >= np.asarray(rng[:3], np.float32), 1) & np.all(b[:, :3] <= np.asarray(rng[3:], np.float32), 1)
+    return b[m], s[m], l[m]

@@ -141,6 +141,11 @@ def import_box_torch_ops():
 
 def import_box_np_ops():
     install_standins()
+    if "spconv" not in sys.modules:
+        # box_np_ops only *names* two spconv.utils helpers at import time (box_np_ops.py:10);
+        # the anchor / corner functions used for golden vectors never call them.
+        sp = _mod("spconv")
+        sp.utils = _mod("spconv.utils", rbbox_intersection=None, rbbox_iou=None)
     for pkg in ("det3d.core", "det3d.core.bbox", "det3d.ops", "det3d.ops.nms"):
         if pkg not in sys.modules:
             _pkg(pkg, os.path.join(REFERENCE_ROOT, *pkg.split(".")))

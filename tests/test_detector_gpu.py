@@ -1,0 +1,257 @@
+"""GPU suite: detector-side HIP kernels against the CPU oracle, independent torch fp32
+references and the reference's golden vectors.  Floating point throughout: tolerances are
+stated per test (fp32 accumulate in a different order than the reference)."""
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_detector_oracle import G, random_sparse, to_dense
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+# ---------------------------------------------------------------- sparse conv layers
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("subm,k,s,p", [(True, (3, 3, 3), (1, 1, 1), (0, 0, 0)),
+                                         (False, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                         (False, (3, 3, 3), (2, 2, 2), (0, 1, 1)),
+                                         (False, (3, 1, 1), (2, 1, 1), (0, 0, 0))])
+def test_sparse_conv_layer_vs_oracle(oracle, cin, cout, subm, k, s, p):
+    from al3d import detector_ops as D
+    rng = np.random.default_rng(cin * 131 + cout)
+    shape, batch = [11, 14, 12], 2
+    feats, coords = random_sparse(rng, batch, shape, 333, cin)
+    w = (rng.normal(size=(*k, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+    scale = (rng.uniform(0.5, 1.5, cout)).astype(np.float32)
+    shift = rng.normal(0, 0.1, cout).astype(np.float32)
+    fo, co, oshape = oracle.spconv(feats, coords, batch, shape, w, k, s, p, subm)
+    ref = np.maximum(fo * scale + shift, 0)
+    got, gco, gshape = D.sparse_conv_layer(_t(feats), _t(coords), batch, shape, _t(w), k, s, p, subm,
+                                           scale=_t(scale), shift=_t(shift), relu=True)
+    assert gshape == oshape
+    got, gco = got.cpu().numpy(), gco.cpu().numpy()
+    assert len(gco) == len(co)
+    # row order of a strided conv's outputs is free: compare through the dense scatter
+    np.testing.assert_allclose(to_dense(got, gco, batch, oshape), to_dense(ref, co, batch, oshape),
+                               rtol=2e-5, atol=2e-5)
+
+
+def test_sparse_conv_residual_and_empty(oracle):
+    from al3d import detector_ops as D
+    rng = np.random.default_rng(2)
+    feats, coords = random_sparse(rng, 1, [5, 6, 7], 40, 16)
+    w = rng.normal(size=(3, 3, 3, 16, 16)).astype(np.float32) * 0.1
+    res = rng.normal(size=(40, 16)).astype(np.float32)
+    fo, _, _ = oracle.spconv(feats, coords, 1, [5, 6, 7], w, (3, 3, 3), (1, 1, 1), (0, 0, 0), True)
+    got, _, _ = D.sparse_conv_layer(_t(feats), _t(coords), 1, [5, 6, 7], _t(w), (3, 3, 3), (1, 1, 1),
+                                    (0, 0, 0), True, residual=_t(res), relu=True)
+    np.testing.assert_allclose(got.cpu().numpy(), np.maximum(fo + res, 0), rtol=2e-5, atol=2e-5)
+    e, ec, _ = D.sparse_conv_layer(torch.zeros((0, 16), device=DEV), torch.zeros((0, 4), dtype=torch.int32,
+                                   device=DEV), 1, [5, 6, 7], _t(w), (3, 3, 3), (2, 2, 2), (1, 1, 1), False)
+    assert e.shape[0] == 0 and ec.shape[0] == 0
+
+
+# ---------------------------------------------------------------- full encoder vs dense torch
+def _dense_encoder_reference(model, feats, coords, batch, shape):
+    """FPNSpMiddleResNetFHD emulated with dense conv3d + site masks on CPU (independent of the
+    rulebook code): SubM = conv3d(pad 1) masked to the active sites; SparseConv3d = strided
+    conv3d, active sites = max-pooled mask; BN(eval)/ReLU applied on active sites only."""
+    x = torch.from_numpy(to_dense(feats, coords, batch, shape))
+    mask = torch.from_numpy(to_dense(np.ones((len(coords), 1), np.float32), coords, batch, shape))
+
+    def conv(mod, x):
+        w = mod.weight.detach().permute(4, 3, 0, 1, 2).contiguous()
+        pad = [q // 2 for q in mod.kernel_size] if mod.subm else list(mod.padding)
+        y = F.conv3d(x, w, stride=mod.stride, padding=pad)
+        if mod.bias is not None:
+            y = y + mod.bias.detach().view(1, -1, 1, 1, 1)
+        return y
+
+    def bn(mod, y):
+        sh = (1, -1, 1, 1, 1)
+        return (y - mod.running_mean.view(sh)) / torch.sqrt(mod.running_var.view(sh) + mod.eps) \
+            * mod.weight.detach().view(sh) + mod.bias.detach().view(sh)
+
+    for seq in model._stages():
+        mods = list(seq.children())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            name = type(m).__name__
+            if name in ("SubMConv3d", "SparseConv3d"):
+                if not m.subm:
+                    mask = (F.max_pool3d(mask, m.kernel_size, m.stride, m.padding) > 0).float()
+                x = torch.relu(bn(mods[i + 1], conv(m, x))) * mask
+                i += 3
+            elif name == "SparseBasicBlock":
+                idt = x
+                y = torch.relu(bn(m.bn1, conv(m.conv1, x))) * mask
+                y = bn(m.bn2, conv(m.conv2, y)) * mask
+                x = torch.relu(y + idt) * mask
+                i += 1
+            else:
+                i += 1
+    B, C, D_, H_, W_ = x.shape
+    return x.reshape(B, C * D_, H_, W_).permute(0, 2, 3, 1).contiguous().numpy()   # NHWC, ch = c*D+z
+
+
+def test_sparse_encoder_vs_dense_torch():
+    from al3d import synthetic
+    from al3d.models.backbones import FPNSpMiddleResNetFHD
+    rng = np.random.default_rng(4)
+    grid_xyz = [32, 32, 40]
+    shape = [41, 32, 32]
+    batch = 2
+    feats, coords = random_sparse(rng, batch, [40, 32, 32], 2500, 5)
+    enc = FPNSpMiddleResNetFHD(num_input_features=5)
+    synthetic.seeded_init_(enc, seed=3)
+    enc.eval()
+    ref = _dense_encoder_reference(enc, feats, coords, batch, shape)
+    enc = enc.to(DEV)
+    with torch.no_grad():
+        out, middle = enc(_t(feats), _t(coords), batch, np.array(grid_xyz))
+        out2, _ = enc(_t(feats), _t(coords), batch, np.array(grid_xyz))   # level grids left clean?
+    assert out.shape == (batch, 4, 4, 256) and len(middle) == 4
+    assert torch.equal(out, out2)                                         # deterministic, bitwise
+    # 21 stacked fp32 convs; activations are O(1): absolute tolerance dominates
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-3, atol=2e-4)
+
+
+# ---------------------------------------------------------------- dense neck vs the reference RPN
+def test_rpn_matches_reference_golden():
+    from al3d import synthetic
+    from al3d.models.necks import RPN
+    z = np.load(os.path.join(G, "rpn.npz"))
+    net = RPN(layer_nums=[5, 5], ds_layer_strides=[1, 2], ds_num_filters=[128, 256],
+              us_layer_strides=[1, 2], us_num_filters=[256, 256], num_input_features=256,
+              norm_cfg=None, logger=logging.getLogger("RPN"))
+    synthetic.seeded_init_(net, seed=1234)
+    import hashlib
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    digest = hashlib.sha256(np.concatenate([sd[k].ravel().astype(np.float64) for k in sorted(sd)]).tobytes())
+    assert digest.hexdigest() == str(z["state_sha256"]), "weights differ from the golden run"
+    net = net.to(DEV).eval()
+    x = torch.from_numpy(z["x"].astype(np.float32)).permute(0, 2, 3, 1).contiguous().to(DEV)
+    with torch.no_grad():
+        y = net(x)                                         # NHWC [1,32,48,512]
+    from al3d import detector_ops as D
+    emb = D.gap_nhwc(y).cpu().numpy()
+    y = y.permute(0, 3, 1, 2).cpu().numpy()
+    # 7 stacked 3x3 fp32 convs with BN: values O(1); reference ran on CPU torch
+    np.testing.assert_allclose(y[0, ::16, ::4, ::4], z["y_slice"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(emb, z["emb"], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- head: decode, fused convs, NMS
+def test_box_decode_matches_reference_golden(oracle):
+    from al3d import detector_ops as D
+    z = np.load(os.path.join(G, "decode.npz"))
+    got = D.box_decode(_t(z["enc"]), _t(z["anchors"])).cpu().numpy()
+    ref = z["dec"].reshape(-1, 9)
+    np.testing.assert_allclose(got[:, :8], ref[:, :8], rtol=2e-6, atol=2e-6)
+    d = np.abs(got[:, 8] - ref[:, 8])
+    assert np.minimum(d, 2 * np.pi - d).max() < 1e-5
+    orc = oracle.box_decode(z["enc"].reshape(-1, 10), z["anchors"].reshape(-1, 9))
+    np.testing.assert_allclose(got, orc, rtol=2e-6, atol=2e-6)
+
+
+def _head_setup(seed, H=16, W=16, score_bias=0.0):
+    from al3d import synthetic
+    from al3d.datasets.anchors import generate_task_anchors
+    from al3d.models import build_head
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal.py"))
+    head = build_head(cfg.model.bbox_head)
+    synthetic.seeded_init_(head, seed=seed)
+    with torch.no_grad():
+        for t in head.tasks:
+            t.conv_cls.bias.add_(score_bias)
+    # anchors of a small BEV map: same generator, smaller feature map
+    gens = [dict(g, anchor_ranges=[-12.8, -12.8, g["anchor_ranges"][2], 12.8, 12.8, g["anchor_ranges"][5]])
+            for g in cfg.target_assigner.anchor_generators]
+    anchors = generate_task_anchors(cfg.tasks, gens, [1, H, W])
+    return cfg, head.to(DEV).eval(), anchors
+
+
+@pytest.mark.parametrize("score_bias", [0.0, -4.0])
+def test_head_predict_vs_oracle(oracle, score_bias):
+    """score_bias 0: nearly every anchor passes the 0.1 threshold (top-k of 1000 and heavy
+    suppression are exercised); -4: few candidates, some tasks empty."""
+    B, H, W = 2, 16, 16
+    cfg, head, anchors = _head_setup(7, H, W, score_bias)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, 512, generator=g).to(DEV)
+    tc = cfg.test_cfg
+    with torch.no_grad():
+        preds = head(x)
+        fused = preds[0]["_fused"]
+        # fused 1x1 convs == the twelve separate Conv2d of the reference head
+        xn = x.permute(0, 3, 1, 2).cpu()
+        for t, task in enumerate(head.tasks):
+            ref = F.conv2d(xn, task.conv_box.weight.cpu(), task.conv_box.bias.cpu()).permute(0, 2, 3, 1)
+            torch.testing.assert_close(preds[t]["box_preds"].cpu(), ref, rtol=1e-4, atol=1e-4)
+        out = head.predict({"anchors": [_t(a) for a in anchors], "metadata": [{"i": i} for i in range(B)]},
+                           preds, tc)
+    fused = fused.cpu().numpy().reshape(B, H * W, -1)
+    label_off = np.concatenate([[0], np.cumsum(head.num_classes)])
+    for b in range(B):
+        bb, ss, ll = [], [], []
+        for t in range(len(head.tasks)):
+            bx, sc, lb = oracle.head_predict(fused[b], anchors[t], head.num_anchor_per_locs[t],
+                                             head.num_classes[t], head._box_off[t], head._cls_off[t],
+                                             tc.score_threshold, tc.nms.nms_iou_threshold,
+                                             tc.nms.nms_pre_max_size, tc.nms.nms_post_max_size,
+                                             tc.post_center_limit_range)
+            bb.append(bx); ss.append(sc); ll.append(lb + label_off[t])
+        bb, ss, ll = np.concatenate(bb), np.concatenate(ss), np.concatenate(ll)
+        got = out[b]
+        assert got["metadata"] == {"i": b}
+        assert got["label_preds"].dtype == torch.int64
+        # discrete outcome (which boxes survive, in which order) must agree exactly
+        assert got["label_preds"].cpu().numpy().tolist() == ll.tolist()
+        np.testing.assert_allclose(got["scores"].cpu().numpy(), ss, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got["box3d_lidar"].cpu().numpy()[:, :8], bb[:, :8], rtol=1e-4, atol=1e-4)
+        if score_bias == 0.0:
+            assert len(ss) > 50
+
+
+# ---------------------------------------------------------------- detector end to end
+def test_detector_batch_invariance_and_determinism():
+    from al3d import synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.sweep import sweep_embeddings
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    pool = PoolFrames.from_numpy([synthetic.make_point_cloud(30 + i, nsweeps=3) for i in range(3)], DEV)
+    e1 = sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 1, device=DEV), DEV, 3)
+    e3 = sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 3, device=DEV), DEV, 3)
+    e3b = sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 3, device=DEV), DEV, 3)
+    assert e1.shape == (3, 512) and torch.isfinite(e1).all()
+    assert torch.equal(e3, e3b)                      # run-to-run bitwise reproducible
+    # batching only changes row numbering of the sparse tensors, not any per-row arithmetic
+    assert torch.equal(e1, e3)
+    ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 3, device=DEV)))
+    with torch.no_grad():
+        preds, middle = model(ex, return_loss=False, estimate=True)
+    assert len(preds) == 3 and tuple(middle[-1].shape) == (3, 512, 128, 128)
+    for p in preds:
+        k = p["box3d_lidar"].shape[0]
+        assert p["box3d_lidar"].shape == (k, 9) and p["scores"].shape == (k,) and k <= 6 * 83
+        assert p["label_preds"].dtype == torch.int64 and int(p["label_preds"].max()) <= 9
+        assert p["metadata"]["token"].startswith("frame")
