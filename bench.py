@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Whole-hot-path benchmark: unlabeled-pool sweep + diversity selection (BASELINE.json metric
+"unlabeled scenes scored+selected/sec", reported in frames/s; 1 scene = 40 frames).
+
+One *step* = one full pass of the hot path over the rank's pool: every frame is voxelized,
+run through the FPNVoxelNet detector (sparse encoder, MFMA neck/head, decode + rotated NMS)
+and reduced to its 512-d BEV embedding; embeddings are all-gathered (RCCL) when N > 1; then
+SpatialTemporalFeatureSelector builds the spatial (kNN geodesic), temporal and feature (L1)
+maps and runs the greedy k-center under the cost budget.  Workload at N=1 = BASELINE.json
+configs[1]: the 64-scene pool (2,560 frames), budget 600.  Point clouds are synthetic and
+resident in HBM before the timed region; weights are seeded random-init (no checkpoints
+offline).  With N ranks every rank sweeps its own 2,560 frames (weak scaling), the pool seen
+by the selector is N x 2,560 frames.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]   (N > 1 under torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import pickle
+import random
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+SCENES_PER_RANK = 64
+FRAMES_PER_SCENE = 40
+BUDGET = 600
+DENSE_GFLOP_PER_FRAME = 67.6      # neck 63.7 + heads 3.96 (2*MAC, fp32)
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scenes", type=int, default=SCENES_PER_RANK, help="scenes per rank")
+    ap.add_argument("--batch", type=int, default=8, help="frames per detector launch")
+    ap.add_argument("--budget", type=int, default=None,
+                    help="cost budget (default 600; scaled down for pools under 64 scenes, whose "
+                         "total labelling cost is below 600)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+class ConvTimer:
+    """HIP-event timing of the dominant kernel family (conv2d_mfma_kernel) on the stream it is
+    launched on; events bracket each neck+head region, which launches nothing else."""
+
+    def __init__(self):
+        self.pairs, self.launches, self.frames = [], 0, 0
+        self.enabled = False
+
+    def wrap(self, model):
+        neck_fwd, head_fwd = model.neck.forward, model.bbox_head.forward
+        timer = self
+
+        def neck(x):
+            if not timer.enabled:
+                return neck_fwd(x)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = neck_fwd(x)
+            timer._e0, timer._b = e0, x.shape[0]
+            return y
+
+        def head(x, finetune=False):
+            r = head_fwd(x, finetune=finetune)
+            if timer.enabled:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                timer.pairs.append((timer._e0, e1))
+                timer.launches += 12 + 1 + 1 + 1      # 12 conv3x3, conv1x1, deconv (4 phases), fused head
+                timer.frames += timer._b
+            return r
+
+        model.neck.forward = neck
+        model.bbox_head.forward = head
+
+    def result(self):
+        if not self.pairs:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        flops = self.frames * DENSE_GFLOP_PER_FRAME * 1e9
+        tf = flops / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                    kernel="conv2d_mfma_kernel", launches=self.launches,
+                    avg_launch_us=round(ms * 1e3 / max(self.launches, 1), 2),
+                    gflop_per_frame=DENSE_GFLOP_PER_FRAME)
+
+
+def write_pool_files(tmp, infos, logs):
+    ip = os.path.join(tmp, "infos.pkl")
+    with open(ip, "wb") as f:
+        pickle.dump(infos, f)
+    lp = os.path.join(tmp, "log.json")
+    with open(lp, "w") as f:
+        json.dump(logs, f)
+    bp = os.path.join(tmp, "buffer.json")
+    with open(bp, "w") as f:
+        json.dump({"0": []}, f)
+    return ip, lp, bp
+
+
+def cpu_baseline(cfg, model_cpu_state, infos, feats, sample_frames=2):
+    """Oracle (CPU port) timed on the host: a bounded sample of the same workload.
+    sweep: `sample_frames` synthetic frames through oracle voxelize + oracle sparse encoder +
+    torch-CPU dense neck/head + oracle NMS; selection: the oracle selector on the full pool
+    metadata with the device embeddings.  Reported as pool-frames / (N * t_frame + t_select)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    oracle.build()
+    import cpu_port
+    return cpu_port.run(cfg, model_cpu_state, infos, feats, sample_frames)
+
+
+def main():
+    args = parse()
+    global BUDGET
+    if args.budget is not None:
+        BUDGET = args.budget
+    elif args.scenes < SCENES_PER_RANK:
+        BUDGET = max(10, BUDGET * args.scenes // SCENES_PER_RANK)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", init_method="env://",
+                                device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from al3d import synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.selectors import build_selector
+    from al3d.utils import Config
+
+    cfg = Config.fromfile(os.path.join(ROOT, "examples", "active", "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    timer = ConvTimer()
+    timer.wrap(model)
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+
+    per_rank = args.scenes * FRAMES_PER_SCENE
+    n_total = per_rank * world
+    infos, logs = synthetic.make_pool(args.scenes * world, seed=0)
+    # every rank holds its contiguous shard of the pool in HBM (seeded per rank)
+    pool = PoolFrames.from_synthetic(per_rank, dev, num_base=16, seed=1000 + rank)
+    my_index = list(range(rank * per_rank, (rank + 1) * per_rank))
+
+    class ShardLoader(DeviceSweepLoader):
+        """Local frame j is dataset frame my_index[j] (contiguous block per rank)."""
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.sampler = my_index
+
+    loader = ShardLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
+    tmp = tempfile.mkdtemp(prefix="al3d_bench_")
+    ip, lp, bp = write_pool_files(tmp, infos, logs)
+    sel_cfg = dict(cfg.selector)
+    sel_cfg.update(budget=BUDGET, buffer_file=bp, infos_origin=ip, logs_file=lp, buffer_path="",
+                   distance_store_file=None, pred=True)
+
+    state = {}
+
+    def step():
+        random.seed(3407)                       # tools/active_select.py:76-80 of the reference
+        sel = build_selector(dict(sel_cfg, detector=model, dataloader=loader))
+        t0 = time.perf_counter()
+        feats = sel.buffer_pred(local_rank=dev.index)
+        sel.pred = False
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sel._features = lambda device, kwargs: feats      # reuse the swept embeddings
+        sel.select_samples(local_rank=dev.index)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        state.update(feats=feats, selected=sel.selected_index[sel.current_budget],
+                     sweep_s=t1 - t0, select_s=t2 - t1)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = rank == 0
+    t0 = time.perf_counter()
+    sweep_s = select_s = 0.0
+    for _ in range(args.steps):
+        step()
+        sweep_s += state["sweep_s"]
+        select_s += state["select_s"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        out = {
+            "metric": "unlabeled frames scored+selected/sec (whole node; 40 frames = 1 scene); selected-set equals ref",
+            "value": round(value, 2), "unit": "frames/s", "scenes_per_s": round(value / FRAMES_PER_SCENE, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scenes * world}-scene nuScenes-shaped pool ({n_total} frames, "
+                                   f"10-sweep ~250k-point clouds resident in HBM), FPNVoxelNet sweep + "
+                                   f"SpatialTemporalFeatureSelector budget {BUDGET} (BASELINE configs[1] per GPU)",
+                       "frames_per_rank": per_rank, "batch": args.batch,
+                       "weights": "seeded random-init (al3d.synthetic.seeded_init_, seed 0)"},
+            "breakdown_s_per_step": {"sweep+allgather": round(sweep_s / args.steps, 4),
+                                     "select": round(select_s / args.steps, 4)},
+            "selected_frames": len(state["selected"]),
+        }
+        roof = timer.result()
+        if roof:
+            out["roofline"] = roof
+        if not args.no_verify:
+            out["selected_equals_oracle"] = verify_selection(infos, state["feats"], state["selected"])
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, cpu_state, infos, state["feats"].cpu().numpy())
+            except Exception as e:       # the baseline is a report, never a reason to lose the line
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def verify_selection(infos, feats, selected):
+    """Checker (not timed): the oracle selector on the same embeddings must pick the same frames."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    oracle.build()
+    from al3d import synthetic
+    cfgm, run_id, n_boxes = synthetic.pool_arrays(infos)
+    n = len(infos)
+    xy = np.stack([(-(c[:3, 3].T @ c[:3, :3]))[:2] for c in cfgm])
+    F = oracle.l1_map_f32(feats.cpu().numpy(), 2)
+    S = oracle.spatial_map(xy, 8)
+    D = oracle.combine(n, spatial=S, temporal_id=run_id, feat=F, normalize="exp", aggregate="sum",
+                       lambda_t=1.0, lambda_f=1.0)
+    random.seed(3407)
+    first = random.choice(range(n))
+    box = np.array([int(b) * 0.04 for b in n_boxes], dtype=np.float64)
+    rc, picks = oracle.greedy(D, [], first, box, 0.12, 0.0, float(BUDGET))
+    return bool(rc == 0 and picks.tolist() == list(selected))
+
+
+if __name__ == "__main__":
+    main()

@@ -133,8 +133,11 @@ class Voxelizer:
 
 
 # ------------------------------------------------------------------ single sparse conv layer
+MFMA_PAIRS = {(16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)}
+
+
 def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad, subm,
-                      scale=None, shift=None, residual=None, relu=False):
+                      scale=None, shift=None, residual=None, relu=False, mfma=None):
     """One spconv layer on device (building block of the encoder, also used by the tests).
     feats [n,Cin] f32, coords [n,4] i32 (b,z,y,x), weight [kz,ky,kx,Cin,Cout].
     Returns (fout [n_out,Cout], coords_out [n_out,4], out_shape)."""
@@ -171,8 +174,15 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
         lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
                  _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    lib.call("al3d_sp_conv_f32", _ptr(feats), _ptr(nbr), K, _ptr(w), cin, cout, _ptr(scale), _ptr(shift),
-             _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+    if mfma is None:
+        mfma = (cin, cout) in MFMA_PAIRS
+    if mfma:
+        w_ock = w.permute(2, 0, 1).contiguous()          # [Cout, K, Cin]
+        lib.call("al3d_sp_conv_mfma_f32", _ptr(feats), _ptr(nbr), K, _ptr(w_ock), cin, cout, _ptr(scale),
+                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+    else:
+        lib.call("al3d_sp_conv_f32", _ptr(feats), _ptr(nbr), K, _ptr(w), cin, cout, _ptr(scale),
+                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
     return out, ocoords, oshape
 
 

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import lib
-from ..detector_ops import fold_bn
+from ..detector_ops import MFMA_PAIRS, fold_bn
 from ..selector_ops import _ptr, _stream
 from .registry import BACKBONES
 
@@ -103,8 +103,7 @@ class _SparseEncoderBase(nn.Module):
                     bn = mods[i + 1]
                     scale, shift = fold_bn(bn)
                     plan.append(dict(kind="subm" if m.subm else "down", mod=m,
-                                     w=m.weight.detach().reshape(-1, m.in_channels, m.out_channels)
-                                     .contiguous().float().to(device),
+                                     w=self._pack(m, device),
                                      scale=scale.to(device), shift=shift.to(device), relu=True,
                                      residual=False))
                     i += 3  # conv, bn, relu
@@ -114,9 +113,7 @@ class _SparseEncoderBase(nn.Module):
                         if conv.bias is not None:   # (x + b) * s + t
                             shift = shift + conv.bias.detach().float().to(scale.device) * scale
                         plan.append(dict(kind="subm", mod=conv,
-                                         w=conv.weight.detach().reshape(-1, conv.in_channels,
-                                                                         conv.out_channels)
-                                         .contiguous().float().to(device),
+                                         w=self._pack(conv, device),
                                          scale=scale.to(device), shift=shift.to(device), relu=True,
                                          residual=last, block_start=not last))
                     i += 1
@@ -126,6 +123,20 @@ class _SparseEncoderBase(nn.Module):
         self._plan = plan
         self._packed_dev = device
         self._levels = {}
+
+    @staticmethod
+    def _pack(m, device):
+        """[kz,ky,kx,Cin,Cout] -> [K,Cin,Cout] (VALU kernel) or [Cout,K,Cin] (MFMA kernel)."""
+        w = m.weight.detach().reshape(-1, m.in_channels, m.out_channels).float()
+        if (m.in_channels, m.out_channels) in MFMA_PAIRS:
+            w = w.permute(2, 0, 1)
+        return w.contiguous().to(device)
+
+    @staticmethod
+    def _conv(m, feats, nbr, K, step, residual, out, n, st):
+        fn = "al3d_sp_conv_mfma_f32" if (m.in_channels, m.out_channels) in MFMA_PAIRS else "al3d_sp_conv_f32"
+        lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
+                 _ptr(step["scale"]), _ptr(step["shift"]), residual, 1, _ptr(out), n, st)
 
     def _level(self, shape, batch, device):
         key = tuple(int(s) for s in shape)
@@ -173,9 +184,7 @@ class _SparseEncoderBase(nn.Module):
                 if step.get("block_start"):
                     identity = feats
                 out = torch.empty((n, m.out_channels), dtype=torch.float32, device=dev)
-                lib.call("al3d_sp_conv_f32", _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels,
-                         m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]),
-                         _ptr(identity) if step["residual"] else None, 1, _ptr(out), n, st)
+                self._conv(m, feats, nbr, K, step, _ptr(identity) if step["residual"] else None, out, n, st)
                 feats = out
             else:
                 oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
@@ -193,9 +202,7 @@ class _SparseEncoderBase(nn.Module):
                 lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
                          lv.W, _ptr(lv.grid), _ptr(dnbr), st)
                 out = torch.empty((n_out, m.out_channels), dtype=torch.float32, device=dev)
-                lib.call("al3d_sp_conv_f32", _ptr(feats), _ptr(dnbr), K, _ptr(step["w"]), m.in_channels,
-                         m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), None, 1, _ptr(out),
-                         n_out, st)
+                self._conv(m, feats, dnbr, K, step, None, out, n_out, st)
                 feats, coords, n, shape, lv = out, ocoords, n_out, oshape, olv
                 nbr_key = None
         for g, c, cnt in used:      # leave every level grid clean for the next call

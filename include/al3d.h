@@ -196,6 +196,13 @@ int al3d_sp_down_table(const int* coords_out, int n_out, const int* ksize, const
 int al3d_sp_conv_f32(const float* fin, const int* nbr, int K, const float* wgt, int cin, int cout,
                      const float* scale, const float* shift, const float* residual, int relu,
                      float* fout, int n_out, void* stream);
+/* Same layer on the fp32 matrix cores (implicit GEMM over 128-row tiles; the rulebook gather
+ * is the A-operand address).  wgt_ock is the weight re-packed [Cout, K, Cin].  Channel pairs:
+ * 16->32, 32->32, 32->64, 64->64, 64->128, 128->128 (the 16-wide layers stay on the VALU
+ * kernel above). */
+int al3d_sp_conv_mfma_f32(const float* fin, const int* nbr, int K, const float* wgt_ock, int cin,
+                          int cout, const float* scale, const float* shift, const float* residual,
+                          int relu, float* fout, int n_out, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
  * out must be zero-filled. */
 int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D, int H,

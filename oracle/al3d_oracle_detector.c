@@ -21,6 +21,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
+
+void al3d_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 /* points_to_voxel_new + select_voxels (det3d/ops/point_cloud/point_cloud_ops.py:187-296)
  * + VoxelFeatureExtractorV3 (det3d/models/readers/voxel_encoder.py:206-211), one frame.
@@ -137,14 +140,19 @@ int64_t al3d_oracle_spconv(const float* fin, const int* coords_in, int64_t n_in,
     memset(fout, 0, sizeof(float) * (size_t)(n_out * cout));
     for (int k = 0; k < K; ++k) {
         const float* w = wgt + (int64_t)k * cin * cout;
+        /* within one offset every output row appears at most once: pairs are independent */
+#pragma omp parallel for schedule(static)
         for (int64_t q = 0; q < cnt[k]; ++q) {
             const float* a = fin + (int64_t)pin[k * n_in + q] * cin;
             float* o = fout + (int64_t)pout[k * n_in + q] * cout;
-            for (int co = 0; co < cout; ++co) {
-                float s = 0.f;
-                for (int ci = 0; ci < cin; ++ci) s += a[ci] * w[ci * cout + co];
-                o[co] += s;
+            float acc[128];
+            for (int co = 0; co < cout; ++co) acc[co] = 0.f;
+            for (int ci = 0; ci < cin; ++ci) {             /* in_row @ W[k], ci-major (row-major W) */
+                const float av = a[ci];
+                const float* wr = w + (int64_t)ci * cout;
+                for (int co = 0; co < cout; ++co) acc[co] += av * wr[co];
             }
+            for (int co = 0; co < cout; ++co) o[co] += acc[co];
         }
     }
     free(grid); free(cnt); free(pin); free(pout);

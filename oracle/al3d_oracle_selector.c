@@ -80,6 +80,7 @@ void al3d_oracle_ego_xy(const double* car_from_global, int64_t n, double* xy)
  * d = sqrt(dx*dx + dy*dy), sums in dimension order. */
 void al3d_oracle_knn(const double* xy, int64_t n, int kq, double* knn_d, int64_t* knn_i)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double* bd = knn_d + (int64_t)kq * i;
         int64_t* bi = knn_i + (int64_t)kq * i;
@@ -178,7 +179,10 @@ void al3d_oracle_apsp(const int64_t* indptr, const int64_t* indices, const doubl
                       int64_t n, int64_t row0, int64_t row1, double* out)
 {
     int64_t nnz = indptr[n];
+#pragma omp parallel
+    {
     heap_item* heap = (heap_item*)malloc(sizeof(heap_item) * (size_t)(nnz + n + 1));
+#pragma omp for schedule(dynamic, 8)
     for (int64_t s = row0; s < row1; ++s) {
         double* dist = out + (s - row0) * n;
         for (int64_t i = 0; i < n; ++i) dist[i] = INFINITY;
@@ -196,6 +200,7 @@ void al3d_oracle_apsp(const int64_t* indptr, const int64_t* indices, const doubl
         }
     }
     free(heap);
+    }
 }
 
 /* EuSpatialSelector map (euclidean_spatial_selector.py:95-106):
@@ -261,6 +266,7 @@ void al3d_oracle_combine(const double* spatial, const int64_t* temporal_id, cons
                          double spatial_scale, double temporal_scale, double* out)
 {
     float lf = (float)lambda_f;
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         for (int64_t j = 0; j < n; ++j) {
             int64_t e = i * n + j;
@@ -306,6 +312,7 @@ void al3d_oracle_combine(const double* spatial, const int64_t* temporal_id, cons
  * Canonical summation order of this build: c = 0..C-1 into one f32 accumulator. */
 void al3d_oracle_l1_map_f32(const float* feats, int64_t n, int64_t c, int p, float* out)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         const float* a = feats + i * c;
         for (int64_t j = 0; j < n; ++j) {

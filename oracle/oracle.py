@@ -245,3 +245,8 @@ def head_predict(hout, anchors, na, nc, box_off, cls_off, score_thresh, iou_thre
     b, s, l = boxes[keep], top[order][keep], lab[order][keep]
     m = np.all(b[:, :3] >= np.asarray(rng[:3], np.float32), 1) & np.all(b[:, :3] <= np.asarray(rng[3:], np.float32), 1)
     return b[m], s[m], l[m]
+
+
+def set_threads(n):
+    """OpenMP thread count of the oracle (cpu_baseline reports it as `cores`)."""
+    lib().al3d_oracle_set_threads(c_int(int(n)))

@@ -25,8 +25,12 @@ def _t(a):
                                          (False, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
                                          (False, (3, 3, 3), (2, 2, 2), (0, 1, 1)),
                                          (False, (3, 1, 1), (2, 1, 1), (0, 0, 0))])
-def test_sparse_conv_layer_vs_oracle(oracle, cin, cout, subm, k, s, p):
+@pytest.mark.parametrize("mfma", [False, True])
+def test_sparse_conv_layer_vs_oracle(oracle, cin, cout, subm, k, s, p, mfma):
     from al3d import detector_ops as D
+    from al3d.detector_ops import MFMA_PAIRS
+    if mfma and (cin, cout) not in MFMA_PAIRS:
+        pytest.skip("16-wide layers run on the VALU kernel")
     rng = np.random.default_rng(cin * 131 + cout)
     shape, batch = [11, 14, 12], 2
     feats, coords = random_sparse(rng, batch, shape, 333, cin)
@@ -36,7 +40,7 @@ def test_sparse_conv_layer_vs_oracle(oracle, cin, cout, subm, k, s, p):
     fo, co, oshape = oracle.spconv(feats, coords, batch, shape, w, k, s, p, subm)
     ref = np.maximum(fo * scale + shift, 0)
     got, gco, gshape = D.sparse_conv_layer(_t(feats), _t(coords), batch, shape, _t(w), k, s, p, subm,
-                                           scale=_t(scale), shift=_t(shift), relu=True)
+                                           scale=_t(scale), shift=_t(shift), relu=True, mfma=mfma)
     assert gshape == oshape
     got, gco = got.cpu().numpy(), gco.cpu().numpy()
     assert len(gco) == len(co)
