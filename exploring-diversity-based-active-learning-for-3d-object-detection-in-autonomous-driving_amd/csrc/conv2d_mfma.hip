@@ -218,36 +218,43 @@ extern "C" int al3d_deconv2x2_nhwc_f32(const float* in, const float* wgt, const 
 // x.mean(-1).mean(-1) of the NCHW neck output == per channel: mean over W, then mean
 // over H (feature_selector.py:68-71).  NHWC input [B,H,W,C] -> [B,C].  One workgroup
 // per (image, 64-channel slab); rows are reduced left-to-right, then top-to-bottom.
-__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, int H, int W, int C,
-                                                  float* __restrict__ out)
+// stage 1: one workgroup per image row (b, y): rowmean[b][y][c] = (sum_x x[b,y,x,c]) / W,
+// lanes run over channels so every load is a full 1 KiB line; HBM-bound (reads the map once).
+__global__ __launch_bounds__(256) void gap_rows_kernel(const float* __restrict__ x, int W, int C,
+                                                       float* __restrict__ rowmean)
 {
-    __shared__ float part[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    float col = 0.f;  // sum over this thread's rows of the per-row means
-    if (c < C) {
-        for (int y = q; y < H; y += 4) {
-            const float* row = x + (((int64_t)b * H + y) * W) * C + c;
-            float s = 0.f;
-            for (int xx = 0; xx < W; ++xx) s += row[(int64_t)xx * C];
-            col += s / (float)W;
-        }
-    }
-    part[q][threadIdx.x & 63] = col;
-    __syncthreads();
-    if (q == 0 && c < C) {
-        float s = part[0][threadIdx.x] + part[1][threadIdx.x];
-        s += part[2][threadIdx.x];
-        s += part[3][threadIdx.x];
-        out[(int64_t)b * C + c] = s / (float)H;
+    const int64_t by = blockIdx.x;
+    const float* row = x + by * W * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int xx = 0; xx < W; ++xx) s += row[(int64_t)xx * C + c];
+        rowmean[by * C + c] = s / (float)W;
     }
 }
 
-extern "C" int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out, void* stream)
+// stage 2: out[b][c] = (sum_y rowmean[b][y][c]) / H, top to bottom
+__global__ __launch_bounds__(256) void gap_cols_kernel(const float* __restrict__ rowmean, int H, int C,
+                                                       float* __restrict__ out)
 {
-    AL3D_REQUIRE(x && out, "al3d_gap_nhwc_f32: null pointer");
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int y = 0; y < H; ++y) s += rowmean[((int64_t)b * H + y) * C + c];
+    out[(int64_t)b * C + c] = s / (float)H;
+}
+
+extern "C" int64_t al3d_gap_workspace_bytes(int B, int H, int C) { return (int64_t)B * H * C * 4; }
+
+extern "C" int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out,
+                                 void* workspace, void* stream)
+{
+    AL3D_REQUIRE(x && out && workspace, "al3d_gap_nhwc_f32: null pointer");
     AL3D_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, "al3d_gap_nhwc_f32: bad shape");
-    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)al3d_cdiv(C, 64), (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, x, H, W, C, out);
+    float* rowmean = (float*)workspace;
+    hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, x, W, C,
+                       rowmean);
+    hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)al3d_cdiv(C, 256), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, rowmean, H, C, out);
     AL3D_CHECK_LAUNCH("gap_kernel");
     return AL3D_OK;
 }

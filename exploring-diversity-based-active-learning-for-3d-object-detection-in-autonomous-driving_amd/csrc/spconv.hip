@@ -52,30 +52,40 @@ __global__ void sp_subm_table_kernel(const int* __restrict__ coords, int n, SpDi
 
 struct SpConvGeom { int kd, kh, kw, sd, sh, sw, pd, ph, pw; };
 
-// Strided conv, step 1: every (input, k) pair claims its output site; the first claimer
+// Strided conv, step 1: every input site claims the output sites it feeds; the first claimer
 // appends the site to coords_out (row order is arbitrary; nothing downstream depends on it).
+// One thread per input: along each axis only the offsets k = (c + pad) mod stride (+ stride..)
+// land on an integer output coordinate, so the loop visits exactly the valid pairs.
 __global__ void sp_down_claim_kernel(const int* __restrict__ coords_in, int n_in, SpConvGeom q,
                                      SpDims go, int* __restrict__ grid_out,
                                      int* __restrict__ coords_out, int* __restrict__ counter, int cap)
 {
-    const int K = q.kd * q.kh * q.kw;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)n_in * K) return;
-    const int i = (int)(e / K), k = (int)(e % K);
-    const int kx = k % q.kw, ky = (k / q.kw) % q.kh, kz = k / (q.kw * q.kh);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
     const int* c = coords_in + 4 * i;
-    const int tz = c[1] + q.pd - kz, ty = c[2] + q.ph - ky, tx = c[3] + q.pw - kx;
-    if (tz < 0 || ty < 0 || tx < 0 || tz % q.sd || ty % q.sh || tx % q.sw) return;
-    const int oz = tz / q.sd, oy = ty / q.sh, ox = tx / q.sw;
-    if (oz >= go.D || oy >= go.H || ox >= go.W) return;
-    int* cell = grid_out + sp_cell(go, c[0], oz, oy, ox);
-    if (atomicCAS(cell, -1, -2) == -1) {
-        const int row = atomicAdd(counter, 1);
-        if (row < cap) {
-            coords_out[4 * row + 0] = c[0]; coords_out[4 * row + 1] = oz;
-            coords_out[4 * row + 2] = oy; coords_out[4 * row + 3] = ox;
+    const int b = c[0], az = c[1] + q.pd, ay = c[2] + q.ph, ax = c[3] + q.pw;
+    for (int kz = az % q.sd; kz < q.kd; kz += q.sd) {
+        const int oz = (az - kz) / q.sd;
+        if (az - kz < 0 || oz >= go.D) continue;
+        for (int ky = ay % q.sh; ky < q.kh; ky += q.sh) {
+            const int oy = (ay - ky) / q.sh;
+            if (ay - ky < 0 || oy >= go.H) continue;
+            for (int kx = ax % q.sw; kx < q.kw; kx += q.sw) {
+                const int ox = (ax - kx) / q.sw;
+                if (ax - kx < 0 || ox >= go.W) continue;
+                int* cell = grid_out + sp_cell(go, b, oz, oy, ox);
+                // cheap read first: most sites are already claimed by a neighbouring input
+                if (__hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) continue;
+                if (atomicCAS(cell, -1, -2) == -1) {
+                    const int row = atomicAdd(counter, 1);
+                    if (row < cap) {
+                        coords_out[4 * row + 0] = b; coords_out[4 * row + 1] = oz;
+                        coords_out[4 * row + 2] = oy; coords_out[4 * row + 3] = ox;
+                    }
+                    atomicExch(cell, row);      // the site's row id, read by the next level's rulebook
+                }
+            }
         }
-        atomicExch(cell, row);      // the site's row id, read by the next level's rulebook
     }
 }
 
@@ -228,9 +238,8 @@ extern "C" int al3d_sp_down_claim(const int* coords_in, int n_in, const int* ksi
                  "al3d_sp_down_claim: null pointer");
     SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
     SpDims go = {B, OD, OH, OW};
-    hipLaunchKernelGGL(sp_down_claim_kernel, dim3(blocks_for((int64_t)n_in * q.kd * q.kh * q.kw, 256)),
-                       dim3(256), 0, (hipStream_t)stream, coords_in, n_in, q, go, grid_out, coords_out,
-                       counter, cap);
+    hipLaunchKernelGGL(sp_down_claim_kernel, dim3(blocks_for(n_in, 256)), dim3(256), 0,
+                       (hipStream_t)stream, coords_in, n_in, q, go, grid_out, coords_out, counter, cap);
     AL3D_CHECK_LAUNCH("sp_down_claim_kernel");
     return AL3D_OK;
 }

@@ -67,7 +67,8 @@ def gap_nhwc(x):
     x = _dev(x, torch.float32, "x")
     B, H, W, C = x.shape
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
-    lib.call("al3d_gap_nhwc_f32", _ptr(x), B, H, W, C, _ptr(out), _stream())
+    ws = torch.empty((B, H, C), dtype=torch.float32, device=x.device)
+    lib.call("al3d_gap_nhwc_f32", _ptr(x), B, H, W, C, _ptr(out), _ptr(ws), _stream())
     return out
 
 

@@ -63,7 +63,8 @@ SIGNATURES = {
     "al3d_vfe_mean_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
     "al3d_conv2d_nhwc_f32": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p]),
     "al3d_deconv2x2_nhwc_f32": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
-    "al3d_gap_nhwc_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_gap_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "al3d_gap_nhwc_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p]),
 }
 
 _lib = None

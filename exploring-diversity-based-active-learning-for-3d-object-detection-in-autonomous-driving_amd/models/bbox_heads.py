@@ -14,6 +14,44 @@ from ..selector_ops import _ptr, _stream
 from .registry import HEADS
 
 
+class LazyDetections:
+    """``list[dict(box3d_lidar, scores, label_preds, metadata)]`` whose device->host hand-off
+    (one copy of the per-(sample, task) counts) happens on first access."""
+
+    def __init__(self, boxes, scores, labels, counts, done, meta):
+        self._raw = (boxes, scores, labels, counts, done, meta)
+        self._list = None
+
+    def _materialize(self):
+        if self._list is None:
+            boxes, scores, labels, counts, done, meta = self._raw
+            done.synchronize()
+            torch.cuda.current_stream(boxes.device).wait_event(done)
+            cnt = counts.cpu()
+            B, nt = cnt.shape
+            out = []
+            for b in range(B):
+                bb, ss, ll = [], [], []
+                for t in range(nt):
+                    c = int(cnt[b, t])
+                    bb.append(boxes[b, t, :c])
+                    ss.append(scores[b, t, :c])
+                    ll.append(labels[b, t, :c].long())
+                out.append({"box3d_lidar": torch.cat(bb), "scores": torch.cat(ss),
+                            "label_preds": torch.cat(ll), "metadata": meta[b]})
+            self._list = out
+        return self._list
+
+    def __len__(self):
+        return self._raw[3].shape[0]
+
+    def __getitem__(self, i):
+        return self._materialize()[i]
+
+    def __iter__(self):
+        return iter(self._materialize())
+
+
 @HEADS.register_module
 class Head(nn.Module):
     def __init__(self, num_input, num_pred, num_cls, use_dir=False, num_dir=0, header=True, name="",
@@ -122,27 +160,31 @@ class MultiGroupHead(nn.Module):
             label_off.append(acc)
             acc += nc
         rng = test_cfg["post_center_limit_range"]
-        boxes = torch.empty((B, nt, post, 9), dtype=torch.float32, device=dev)
-        scores = torch.empty((B, nt, post), dtype=torch.float32, device=dev)
-        labels = torch.empty((B, nt, post), dtype=torch.int32, device=dev)
-        counts = torch.empty((B, nt), dtype=torch.int32, device=dev)
-        lib.call("al3d_head_decode_nms", _ptr(fused), B, H * W, CH, nt,
-                 (ctypes.c_void_p * nt)(*[a.data_ptr() for a in a_dev]),
-                 IntA(*[a.shape[0] for a in a_dev]), IntA(*self.num_anchor_per_locs),
-                 IntA(*self.num_classes), IntA(*self._box_off), IntA(*self._cls_off), IntA(*label_off),
-                 float(test_cfg["score_threshold"]), float(nms["nms_iou_threshold"]),
-                 int(nms["nms_pre_max_size"]), post, (ctypes.c_float * 6)(*[float(v) for v in rng]),
-                 _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), _stream())
-        cnt = counts.cpu()                        # one D2H per batch
+        # The decode+NMS kernel is latency-bound (one workgroup per (sample, task)); it runs on a
+        # side stream so the next batch's voxelizer / sparse encoder overlap it, and the host
+        # only waits for it when somebody actually reads the detections.
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_side", None) is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            boxes = torch.empty((B, nt, post, 9), dtype=torch.float32, device=dev)
+            scores = torch.empty((B, nt, post), dtype=torch.float32, device=dev)
+            labels = torch.empty((B, nt, post), dtype=torch.int32, device=dev)
+            counts = torch.empty((B, nt), dtype=torch.int32, device=dev)
+            fused.record_stream(self._side)
+            for a in a_dev:
+                a.record_stream(self._side)
+            lib.call("al3d_head_decode_nms", _ptr(fused), B, H * W, CH, nt,
+                     (ctypes.c_void_p * nt)(*[a.data_ptr() for a in a_dev]),
+                     IntA(*[a.shape[0] for a in a_dev]), IntA(*self.num_anchor_per_locs),
+                     IntA(*self.num_classes), IntA(*self._box_off), IntA(*self._cls_off), IntA(*label_off),
+                     float(test_cfg["score_threshold"]), float(nms["nms_iou_threshold"]),
+                     int(nms["nms_pre_max_size"]), post, (ctypes.c_float * 6)(*[float(v) for v in rng]),
+                     _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), self._side.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self._side)
         meta = example.get("metadata") or [None] * B
-        out = []
-        for b in range(B):
-            bb, ss, ll = [], [], []
-            for t in range(nt):
-                c = int(cnt[b, t])
-                bb.append(boxes[b, t, :c])
-                ss.append(scores[b, t, :c])
-                ll.append(labels[b, t, :c].long())
-            out.append({"box3d_lidar": torch.cat(bb), "scores": torch.cat(ss),
-                        "label_preds": torch.cat(ll), "metadata": meta[b]})
-        return out
+        return LazyDetections(boxes, scores, labels, counts, done, meta)

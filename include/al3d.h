@@ -229,7 +229,9 @@ int al3d_deconv2x2_nhwc_f32(const float* in, const float* wgt, const float* scal
 
 /* BEV embedding: mean over W then over H of an NHWC map, [B,H,W,C] -> [B,C].
  * Replaces `fpn_feats[-1].mean(-1).mean(-1)` (det3d/selectors/feature_selector.py:68-71). */
-int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out, void* stream);
+int64_t al3d_gap_workspace_bytes(int B, int H, int C);
+int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out, void* workspace,
+                      void* stream);
 
 #ifdef __cplusplus
 }
