@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Selection CLI -- same flags and flow as the reference's tools/active_select.py:22-163.
+
+    python tools/active_select.py --config examples/active/cbgs_spatial_temporal.py --budget 600
+    torchrun --nproc-per-node 8 tools/active_select.py --config … --pred       # sharded sweep
+
+Seeds (3407), the empty-buffer bootstrap, ``build_detector`` / ``build_selector`` /
+``select_samples(local_rank=…)`` / ``dump_file()`` follow the reference.  Differences: the
+detector is only built when the selector sweeps (``--pred``) -- the reference builds it and calls
+``.cuda()`` even for metadata-only selectors; the pool is staged in HBM
+(``--synthetic-scenes`` generates one, otherwise ``cfg.selector.infos_origin`` + ``cfg.data_root``
+are read with the reference's loading rules); under torch.distributed every rank sweeps a
+contiguous shard and the embeddings are all-gathered.
+"""
+import argparse
+import logging
+import os
+import pickle
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="Active-learning sample selection")
+    p.add_argument("--config", default="examples/active/cbgs_spatial_temporal.py")
+    p.add_argument("--work_dir")
+    p.add_argument("--checkpoint", default=None)
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--budget", type=int, default=None)
+    p.add_argument("--pred", action="store_true", help="sweep the pool and save the embeddings")
+    p.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="pytorch")
+    p.add_argument("--local_rank", type=int, default=0)
+    p.add_argument("--synthetic-scenes", type=int, default=0,
+                   help="generate a synthetic pool of this many scenes (writes infos/log files)")
+    p.add_argument("--batch", type=int, default=8)
+    args = p.parse_args()
+    os.environ.setdefault("LOCAL_RANK", str(args.local_rank))
+    return args
+
+
+def main():
+    torch.manual_seed(3407)
+    np.random.seed(3407)
+    random.seed(3407)
+    args = parse_args()
+    from al3d import synthetic
+    from al3d.selectors import build_selector
+    from al3d.utils import Config, fileio
+
+    cfg = Config.fromfile(args.config)
+    local_rank = int(os.environ.get("LOCAL_RANK", args.local_rank))
+    if args.budget is not None:
+        cfg.selector.budget = args.budget
+    distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if distributed:
+        torch.cuda.set_device(local_rank)
+        torch.distributed.init_process_group(backend="nccl", init_method="env://")
+    rank = torch.distributed.get_rank() if distributed else 0
+    world = torch.distributed.get_world_size() if distributed else 1
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.ERROR)
+    logger = logging.getLogger("active_select")
+    logger.info("Distributed testing: %s", distributed)
+
+    sel_cfg = cfg.selector
+    if args.synthetic_scenes:
+        infos, logs = synthetic.make_pool(args.synthetic_scenes, seed=0)
+        os.makedirs(os.path.dirname(sel_cfg.infos_origin) or ".", exist_ok=True)
+        if rank == 0:
+            with open(sel_cfg.infos_origin, "wb") as f:
+                pickle.dump(infos, f)
+            fileio.dump(logs, os.path.join(os.path.dirname(sel_cfg.infos_origin), "log.json"))
+        if distributed:
+            torch.distributed.barrier()
+        sel_cfg["logs_file"] = os.path.join(os.path.dirname(sel_cfg.infos_origin), "log.json")
+        sel_cfg.setdefault("distance_store_file", None)
+    os.makedirs(os.path.dirname(sel_cfg.buffer_file) or ".", exist_ok=True)
+    if not os.path.exists(sel_cfg.buffer_file):
+        # first round: empty buffer (reference init_sample_dataset, active_select.py:68-71)
+        if rank == 0:
+            fileio.dump({"0": []}, sel_cfg.buffer_file, indent=4)
+        logger.info("init a empty buffer, and save as %s", sel_cfg.buffer_file)
+        return
+
+    model = loader = None
+    if args.pred:
+        from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+        from al3d.datasets.nusc_files import load_frame_points
+        from al3d.models import build_detector
+        dev = torch.device("cuda", local_rank)
+        model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+        if args.checkpoint:
+            sd = torch.load(args.checkpoint, map_location="cpu", weights_only=True)
+            sd = sd.get("state_dict", sd)
+            sd = {k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}
+            missing, unexpected = model.load_state_dict(sd, strict=False)
+            logger.info("checkpoint loaded (missing %d, unexpected %d)", len(missing), len(unexpected))
+        else:
+            synthetic.seeded_init_(model, seed=0)
+        model = model.to(dev).eval()
+        infos = fileio.load(sel_cfg.infos_origin)
+        n = len(infos)
+        per = (n + world - 1) // world
+        mine = list(range(rank * per, min(n, (rank + 1) * per)))
+        if args.synthetic_scenes:
+            pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
+        else:
+            pool = PoolFrames.from_numpy([load_frame_points(infos[i], cfg.nsweeps, cfg.data_root)
+                                          for i in mine], dev)
+        anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+        loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
+        loader.sampler = mine
+
+    sel_cfg.update({"detector": model, "dataloader": loader, "logger": logger, "pred": args.pred})
+    selector = build_selector(dict(sel_cfg))
+    logger.info("begin selection")
+    selector.select_samples(local_rank=local_rank)
+    selector.dump_file()
+
+
+if __name__ == "__main__":
+    main()
