@@ -154,31 +154,38 @@ __global__ void adj_fill_kernel(const double* __restrict__ knn_d, const int64_t*
 // ------------------------------------------------------------------ SSSP sweeps
 // One workgroup per source.  Labels are the f64 bit patterns (non-negative, so
 // unsigned integer order == numeric order) lowered with integer atomic-min.
-// `cur`/`nxt` are byte frontiers; a thread owns the bytes of the nodes it scans
-// and clears them as it reads, so one barrier per round is enough.
-// LDS_DIST: labels live in LDS (10 B/node); otherwise in the output row itself.
+// Per round: the frontier flags (one byte per node, owned by the scanning thread) are
+// compacted into a 16-bit node list, then 16-lane groups relax the edges of one
+// frontier node each (edge-parallel: the dependent atomic round trips of a node's ~16
+// edges overlap instead of queueing in one lane).  Two barriers per round.
+// LDS_DIST: labels live in LDS (12 B/node incl. flags + list); otherwise in the
+// output row itself (global atomics at L2), 4 B/node of LDS.
 #define SSSP_THREADS 256
 
 template <bool LDS_DIST>
 __global__ __launch_bounds__(SSSP_THREADS) void sssp_kernel(const int* __restrict__ indptr,
                                                             const int* __restrict__ adj_v,
                                                             const double* __restrict__ adj_w,
-                                                            int64_t n, double* __restrict__ out)
+                                                            int64_t n, int64_t row0,
+                                                            double* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_cnt;
     const int tid = threadIdx.x;
-    const int64_t src = blockIdx.x;
+    const int64_t src = row0 + blockIdx.x;
+    double* orow = out + (int64_t)blockIdx.x * n;
     unsigned long long* dist;
     unsigned char* fl;
     if (LDS_DIST) {
         dist = reinterpret_cast<unsigned long long*>(smem);
         fl = smem + sizeof(unsigned long long) * (size_t)n;
     } else {
-        dist = reinterpret_cast<unsigned long long*>(out + src * n);
+        dist = reinterpret_cast<unsigned long long*>(orow);
         fl = smem;
     }
     unsigned char* cur = fl;
     unsigned char* nxt = fl + n;
+    unsigned short* list = reinterpret_cast<unsigned short*>(fl + 2 * n);
     const unsigned long long INF_BITS = 0x7ff0000000000000ULL;
     for (int64_t v = tid; v < n; v += SSSP_THREADS) {
         const unsigned long long init = v == src ? 0ULL : INF_BITS;
@@ -187,32 +194,41 @@ __global__ __launch_bounds__(SSSP_THREADS) void sssp_kernel(const int* __restric
         cur[v] = v == src ? 1 : 0;
         nxt[v] = 0;
     }
+    if (tid == 0) s_cnt = 0;
     __syncthreads();
+    const int grp = tid >> 4, gl = tid & 15;          // 16 groups of 16 lanes
     for (int64_t round = 0; round <= n; ++round) {
-        int changed = 0;
         for (int64_t v = tid; v < n; v += SSSP_THREADS) {
             if (!cur[v]) continue;
             cur[v] = 0;
-            unsigned long long dvb = LDS_DIST ? dist[v]
-                                              : __hip_atomic_load(&dist[v], __ATOMIC_RELAXED,
-                                                                  __HIP_MEMORY_SCOPE_AGENT);
+            list[atomicAdd(&s_cnt, 1)] = (unsigned short)v;
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        if (cnt == 0) break;
+        for (int b = grp; b < cnt; b += SSSP_THREADS / 16) {
+            const int v = list[b];
+            const unsigned long long dvb = LDS_DIST ? dist[v]
+                                                    : __hip_atomic_load(&dist[v], __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_AGENT);
             const double dv = __longlong_as_double((long long)dvb);
             const int e1 = indptr[v + 1];
-            for (int e = indptr[v]; e < e1; ++e) {
+            for (int e = indptr[v] + gl; e < e1; e += 16) {
                 const int u = adj_v[e];
                 const double nd = dv + adj_w[e];
                 const unsigned long long nb = (unsigned long long)__double_as_longlong(nd);
                 const unsigned long long old = atomicMin(&dist[u], nb);
-                if (nb < old) { nxt[u] = 1; changed = 1; }
+                if (nb < old) nxt[u] = 1;
             }
         }
-        const int any = __syncthreads_or(changed);
-        if (!any) break;
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
         unsigned char* t = cur; cur = nxt; nxt = t;
+        __syncthreads();
     }
     if (LDS_DIST) {
         for (int64_t v = tid; v < n; v += SSSP_THREADS)
-            out[src * n + v] = __longlong_as_double((long long)dist[v]);
+            orow[v] = __longlong_as_double((long long)dist[v]);
     }
 }
 
@@ -223,13 +239,15 @@ extern "C" int64_t al3d_apsp_workspace_bytes(int64_t n, int kq)
     return ints + al3d_align(2 * n * kq * 8, 256);
 }
 
-extern "C" int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
-                                 double* out, void* workspace, void* stream)
+extern "C" int al3d_apsp_knn_rows_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
+                                      int64_t row0, int64_t nrows, double* out, void* workspace,
+                                      void* stream)
 {
     AL3D_REQUIRE(knn_d && knn_i && out && workspace, "al3d_apsp_knn_f64: null pointer");
     AL3D_REQUIRE(kq >= 1 && kq <= 32, "al3d_apsp_knn_f64: kq must be in [1,32] (got %d)", kq);
-    AL3D_REQUIRE(n >= 0 && n * (int64_t)kq < (1LL << 30), "al3d_apsp_knn_f64: bad n");
-    if (n == 0) return AL3D_OK;
+    AL3D_REQUIRE(n >= 0 && n < 65536 && n * (int64_t)kq < (1LL << 30), "al3d_apsp_knn_f64: n must be < 65536");
+    AL3D_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= n, "al3d_apsp_knn_f64: bad row range");
+    if (n == 0 || nrows == 0) return AL3D_OK;
     hipStream_t s = (hipStream_t)stream;
     unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
     int* deg = reinterpret_cast<int*>(w);
@@ -245,19 +263,25 @@ extern "C" int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int6
     hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(1024), 0, s, deg, n, indptr, cursor);
     hipLaunchKernelGGL(adj_fill_kernel, dim3(eb), dim3(256), 0, s, knn_d, knn_i, n, kq, cursor, adj_v,
                        adj_w);
-    const size_t lds_full = (size_t)n * 10, lds_flags = (size_t)n * 2;
+    const size_t lds_full = (size_t)n * 12, lds_flags = (size_t)n * 4;
     if (lds_full <= 150 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sssp_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
-        hipLaunchKernelGGL(sssp_kernel<true>, dim3((unsigned)n), dim3(SSSP_THREADS), lds_full, s, indptr,
-                           adj_v, adj_w, n, out);
+        hipLaunchKernelGGL(sssp_kernel<true>, dim3((unsigned)nrows), dim3(SSSP_THREADS), lds_full, s,
+                           indptr, adj_v, adj_w, n, row0, out);
     } else {
         AL3D_REQUIRE(lds_flags <= 150 * 1024, "al3d_apsp_knn_f64: n=%lld too large", (long long)n);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sssp_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_flags);
-        hipLaunchKernelGGL(sssp_kernel<false>, dim3((unsigned)n), dim3(SSSP_THREADS), lds_flags, s,
-                           indptr, adj_v, adj_w, n, out);
+        hipLaunchKernelGGL(sssp_kernel<false>, dim3((unsigned)nrows), dim3(SSSP_THREADS), lds_flags, s,
+                           indptr, adj_v, adj_w, n, row0, out);
     }
     AL3D_CHECK_LAUNCH("sssp_kernel");
     return AL3D_OK;
+}
+
+extern "C" int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
+                                 double* out, void* workspace, void* stream)
+{
+    return al3d_apsp_knn_rows_f64(knn_d, knn_i, n, kq, 0, n, out, workspace, stream);
 }

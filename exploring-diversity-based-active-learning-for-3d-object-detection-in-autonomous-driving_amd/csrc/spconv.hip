@@ -9,7 +9,7 @@
 //   * SparseConv3d: output sites = every in-bounds o reached by at least one input
 // MI355X design: instead of spconv's per-offset gather -> GEMM -> scatter-add (27
 // launches, atomics, run-to-run summation order), the rulebook is stored output-major
-// (nbr[o][k] = input row or -1, built from a dense per-level index grid that lives in
+// (nbr[k][o] = input row or -1, tap-major, built from a dense per-level index grid that lives in
 // HBM) and ONE kernel per layer walks k for a tile of output rows: gathered input rows are
 // staged in LDS, products accumulate in registers in a fixed (k, ci) order, and the
 // BN(eval)/bias/residual/ReLU epilogue is fused, so every activation row makes one HBM
@@ -41,7 +41,7 @@ __global__ void sp_subm_table_kernel(const int* __restrict__ coords, int n, SpDi
     const int K = kd * kh * kw;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)n * K) return;
-    const int i = (int)(e / K), k = (int)(e % K);
+    const int k = (int)(e / n), i = (int)(e % n);       // tap-major: nbr[k][i], coalesced over i
     const int kx = k % kw, ky = (k / kw) % kh, kz = k / (kw * kh);
     const int* c = coords + 4 * i;
     const int z = c[1] + kz - kd / 2, y = c[2] + ky - kh / 2, x = c[3] + kx - kw / 2;
@@ -96,7 +96,7 @@ __global__ void sp_down_table_kernel(const int* __restrict__ coords_out, int n_o
     const int K = q.kd * q.kh * q.kw;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)n_out * K) return;
-    const int o = (int)(e / K), k = (int)(e % K);
+    const int k = (int)(e / n_out), o = (int)(e % n_out);   // tap-major
     const int kx = k % q.kw, ky = (k / q.kw) % q.kh, kz = k / (q.kw * q.kh);
     const int* c = coords_out + 4 * o;
     const int z = c[1] * q.sd - q.pd + kz, y = c[2] * q.sh - q.ph + ky, x = c[3] * q.sw - q.pw + kx;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const float* __restrict__ 
         int have = 0;
         if (tid < SP_TM) {
             const int row = row0 + tid;
-            const int v = row < n_out ? nbr[(int64_t)row * K + k] : -1;
+            const int v = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
             idx_s[tid] = v;
             have = v >= 0;
         }

@@ -30,16 +30,17 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
     constexpr int QPR = BK / 4;                     // float4 pieces per row
     constexpr int RPP = 256 / QPR;                  // rows staged per pass
     constexpr int A_PASSES = SM_BM / RPP;
-    constexpr int B_PASSES = (COUT + RPP - 1) / RPP;
-    constexpr int WN = COUT >= 128 ? 64 : 32;       // columns per wave
-    constexpr int WAVES_N = COUT / WN;              // 2, 2, 1 for COUT = 128, 64, 32
+    constexpr int NP = COUT < 32 ? 32 : COUT;       // N padded to one MFMA tile (16-wide layers)
+    constexpr int B_PASSES = (NP + RPP - 1) / RPP;
+    constexpr int WN = NP >= 128 ? 64 : 32;         // columns per wave
+    constexpr int WAVES_N = NP / WN;                // 2, 2, 1, 1 for COUT = 128, 64, 32, 16
     constexpr int WAVES_M = 4 / WAVES_N;            // 2, 2, 4
     constexpr int WM = SM_BM / WAVES_M;             // 64, 64, 32 rows per wave
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int KCHUNKS = CIN / BK;
-    constexpr bool B_EXACT = (COUT % RPP) == 0;
+    constexpr bool B_EXACT = (NP % RPP) == 0;
     __shared__ __attribute__((aligned(16))) float As[2][SM_BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][COUT * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][NP * LD];
     __shared__ unsigned s_mask;
     __shared__ int s_taps[32];
     __shared__ int s_ntaps;
@@ -57,10 +58,10 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
     {
         unsigned m = 0u;
         const int rows = n_out - row0 < SM_BM ? n_out - row0 : SM_BM;
-        const int tot = rows * K;
-        const int* blk = nbr + (int64_t)row0 * K;
-        for (int e = tid; e < tot; e += 256)
-            if (blk[e] >= 0) m |= 1u << (e % K);
+        for (int e = tid; e < SM_BM * K; e += 256) {       // tap-major rulebook: nbr[k][row]
+            const int k = e / SM_BM, r = e % SM_BM;
+            if (r < rows && nbr[(int64_t)k * n_out + row0 + r] >= 0) m |= 1u << k;
+        }
         for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off);
         if (lane == 0 && m) atomicOr(&s_mask, m);
     }
@@ -83,17 +84,29 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[A_PASSES], rb[B_PASSES];
-    int src[A_PASSES];
-    int cur_tap = -1;
+    int src[A_PASSES], src_n[A_PASSES];
+    int cur_tap = -1, nxt_tap = -1;
+    auto fetch_idx = [&](int tap, int* dst) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int row = row0 + sr + RPP * i;
+            dst[i] = row < n_out ? nbr[(int64_t)tap * n_out + row] : -1;
+        }
+    };
     auto load_step = [&](int step) {
         const int tap = s_taps[step / KCHUNKS], c0 = (step % KCHUNKS) * BK;
         if (tap != cur_tap) {                       // wave-uniform: new kernel offset, new gather rows
-            cur_tap = tap;
+            if (tap == nxt_tap) {
 #pragma unroll
-            for (int i = 0; i < A_PASSES; ++i) {
-                const int row = row0 + sr + RPP * i;
-                src[i] = row < n_out ? nbr[(int64_t)row * K + tap] : -1;
+                for (int i = 0; i < A_PASSES; ++i) src[i] = src_n[i];
+            } else {
+                fetch_idx(tap, src);
             }
+            cur_tap = tap;
+            // gather ids of the following offset are requested one offset early, so the
+            // id -> row dependent-load chain is off the critical path
+            const int ti = step / KCHUNKS + 1;
+            if (ti < s_ntaps) { nxt_tap = s_taps[ti]; fetch_idx(nxt_tap, src_n); }
         }
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i)
@@ -102,8 +115,9 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int n = sr + RPP * i;
-            if (B_EXACT || n < COUT)
-                rb[i] = *reinterpret_cast<const float4*>(wgt + ((int64_t)n * K + tap) * CIN + c0 + 4 * sq);
+            if (B_EXACT || n < NP)
+                rb[i] = n < COUT ? *reinterpret_cast<const float4*>(wgt + ((int64_t)n * K + tap) * CIN + c0 + 4 * sq)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_step = [&](int buf) {
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int n = sr + RPP * i;
-            if (B_EXACT || n < COUT) *reinterpret_cast<float4*>(&Bs[buf][n * LD + 4 * sq]) = rb[i];
+            if (B_EXACT || n < NP) *reinterpret_cast<float4*>(&Bs[buf][n * LD + 4 * sq]) = rb[i];
         }
     };
 
@@ -155,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = wn * WN + j * 32 + fr;
+        if (n >= COUT) continue;
         const float sc = scale ? scale[n] : 1.0f;
         const float sh = shift ? shift[n] : 0.0f;
 #pragma unroll
@@ -190,7 +205,7 @@ extern "C" int al3d_sp_conv_mfma_f32(const float* fin, const int* nbr, int K, co
     AL3D_REQUIRE(fin && nbr && wgt_ock && fout, "al3d_sp_conv_mfma_f32: null pointer");
     const float* wgt = wgt_ock;
     hipStream_t s = (hipStream_t)stream;
-    SPM_DISPATCH(16, 32) SPM_DISPATCH(32, 32) SPM_DISPATCH(32, 64) SPM_DISPATCH(64, 64)
+    SPM_DISPATCH(16, 16) SPM_DISPATCH(16, 32) SPM_DISPATCH(32, 32) SPM_DISPATCH(32, 64) SPM_DISPATCH(64, 64)
     SPM_DISPATCH(64, 128) SPM_DISPATCH(128, 128)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_mfma_f32: unsupported channel pair %d -> %d", cin, cout);
 }

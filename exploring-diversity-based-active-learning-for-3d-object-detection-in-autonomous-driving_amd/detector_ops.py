@@ -134,7 +134,7 @@ class Voxelizer:
 
 
 # ------------------------------------------------------------------ single sparse conv layer
-MFMA_PAIRS = {(16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)}
+MFMA_PAIRS = {(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)}
 
 
 def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad, subm,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "al3d_knn_2d_f64": (c_int, [c_p, c_i64, c_int, c_p, c_p, c_p]),
     "al3d_apsp_workspace_bytes": (c_i64, [c_i64, c_int]),
     "al3d_apsp_knn_f64": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p]),
+    "al3d_apsp_knn_rows_f64": (c_int, [c_p, c_p, c_i64, c_int, c_i64, c_i64, c_p, c_p, c_p]),
     "al3d_voxelize_grid_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "al3d_voxelize_grid_init": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p]),
     "al3d_voxelize_workspace_bytes": (c_i64, [c_i64, c_int, c_int]),

@@ -80,21 +80,39 @@ def knn_2d(xy, kq):
     return d, i
 
 
-def apsp_knn(knn_d, knn_i):
+def apsp_knn(knn_d, knn_i, row0=0, nrows=None):
+    """Geodesic rows [row0, row0+nrows) of the kNN graph, f64 [nrows, n]."""
     knn_d = _dev(knn_d, torch.float64, "knn_d")
     knn_i = _dev(knn_i, torch.int64, "knn_i")
     n, kq = knn_d.shape
-    out = torch.empty((n, n), dtype=torch.float64, device=knn_d.device)
+    nrows = n - row0 if nrows is None else nrows
+    out = torch.empty((nrows, n), dtype=torch.float64, device=knn_d.device)
     ws = torch.empty(max(1, lib.load().al3d_apsp_workspace_bytes(n, kq)), dtype=torch.uint8,
                      device=knn_d.device)
-    lib.call("al3d_apsp_knn_f64", _ptr(knn_d), _ptr(knn_i), n, kq, _ptr(out), _ptr(ws), _stream())
+    lib.call("al3d_apsp_knn_rows_f64", _ptr(knn_d), _ptr(knn_i), n, kq, int(row0), int(nrows), _ptr(out),
+             _ptr(ws), _stream())
     return out
 
 
 def spatial_map(xy, k=8):
-    """kNN(k)-graph geodesic map, f64 [N,N] (spatial_temporal_selector.py:92-104)."""
+    """kNN(k)-graph geodesic map, f64 [N,N] (spatial_temporal_selector.py:92-104).
+
+    Under torch.distributed the N source rows are sharded over the ranks (each computes a
+    contiguous block) and all-gathered -- the sweeps are independent per source."""
+    import torch.distributed as dist
     d, i = knn_2d(xy, k + 1)
-    return apsp_knn(d, i)
+    n = d.shape[0]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or n < 4096:
+        return apsp_knn(d, i)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = (n + world - 1) // world
+    r0 = min(n, rank * per)
+    rows = apsp_knn(d, i, r0, min(n, r0 + per) - r0)
+    pad = torch.empty((per, n), dtype=torch.float64, device=d.device)
+    pad[: rows.shape[0]] = rows
+    full = torch.empty((world * per, n), dtype=torch.float64, device=d.device)
+    dist.all_gather_into_tensor(full, pad)
+    return full[:n]
 
 
 def greedy_kcenter(D, seeded, first, box_cost, cost_f, start_cost, budget_int, seed_map=None,

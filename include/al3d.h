@@ -114,6 +114,9 @@ int al3d_knn_2d_f64(const double* xy, int64_t n, int kq, double* knn_d, int64_t*
 int64_t al3d_apsp_workspace_bytes(int64_t n, int kq);
 int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
                       double* out, void* workspace, void* stream);
+/* Same, source rows [row0, row0+nrows) only -> out [nrows, n] (row-sharding across ranks). */
+int al3d_apsp_knn_rows_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
+                           int64_t row0, int64_t nrows, double* out, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------- detector: voxelize */
 
