@@ -15,6 +15,7 @@
 // BN(eval)/bias/residual/ReLU epilogue is fused, so every activation row makes one HBM
 // round trip and results are deterministic.
 #include "al3d_common.h"
+#include "al3d_scan.h"
 
 struct SpDims { int B, D, H, W; };
 
@@ -87,6 +88,57 @@ __global__ void sp_down_claim_kernel(const int* __restrict__ coords_in, int n_in
             }
         }
     }
+}
+
+// Deterministic alternative to the claim kernel: (1) every input marks the output sites it
+// feeds (plain idempotent stores), (2) an exclusive scan over the marked cells numbers the sites
+// in raster order (b, z, y, x), (3) the cells receive their row id and coords_out is written.
+// Raster order makes consecutive rows spatial neighbours, which the conv kernels exploit when
+// they skip kernel offsets that are empty for a whole 32-row tile.
+__global__ void sp_down_mark_kernel(const int* __restrict__ coords_in, int n_in, SpConvGeom q, SpDims go,
+                                    int* __restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    const int* c = coords_in + 4 * i;
+    const int b = c[0], az = c[1] + q.pd, ay = c[2] + q.ph, ax = c[3] + q.pw;
+    for (int kz = az % q.sd; kz < q.kd; kz += q.sd) {
+        const int oz = (az - kz) / q.sd;
+        if (az - kz < 0 || oz >= go.D) continue;
+        for (int ky = ay % q.sh; ky < q.kh; ky += q.sh) {
+            const int oy = (ay - ky) / q.sh;
+            if (ay - ky < 0 || oy >= go.H) continue;
+            for (int kx = ax % q.sw; kx < q.kw; kx += q.sw) {
+                const int ox = (ax - kx) / q.sw;
+                if (ax - kx < 0 || ox >= go.W) continue;
+                flags[sp_cell(go, b, oz, oy, ox)] = 1;
+            }
+        }
+    }
+}
+
+__global__ void sp_down_assign_kernel(const int* __restrict__ flags, const int* __restrict__ scan,
+                                      int64_t cells, SpDims go, int* __restrict__ grid_out,
+                                      int* __restrict__ coords_out, int cap)
+{
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= cells || !flags[cell]) return;
+    const int row = scan[cell];
+    grid_out[cell] = row;
+    if (row < cap) {
+        int64_t t = cell;
+        const int x = (int)(t % go.W); t /= go.W;
+        const int y = (int)(t % go.H); t /= go.H;
+        const int z = (int)(t % go.D); t /= go.D;
+        coords_out[4 * row + 0] = (int)t; coords_out[4 * row + 1] = z;
+        coords_out[4 * row + 2] = y; coords_out[4 * row + 3] = x;
+    }
+}
+
+__global__ void sp_count_tail_kernel(const int* __restrict__ flags, const int* __restrict__ scan,
+                                     int64_t cells, int* __restrict__ counter)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *counter = scan[cells - 1] + flags[cells - 1];
 }
 
 // Strided conv, step 2: nbr[o][k] = input row at o*stride - pad + k (grid_in lookup).
@@ -241,6 +293,44 @@ extern "C" int al3d_sp_down_claim(const int* coords_in, int n_in, const int* ksi
     hipLaunchKernelGGL(sp_down_claim_kernel, dim3(blocks_for(n_in, 256)), dim3(256), 0,
                        (hipStream_t)stream, coords_in, n_in, q, go, grid_out, coords_out, counter, cap);
     AL3D_CHECK_LAUNCH("sp_down_claim_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int64_t al3d_sp_down_sites_workspace_bytes(int B, int OD, int OH, int OW)
+{
+    const int64_t cells = (int64_t)B * OD * OH * OW;
+    return 2 * al3d_align(cells * 4, 256) + al3d_scan_workspace_bytes(cells);
+}
+
+extern "C" int al3d_sp_down_sites(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                                  const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                                  int* coords_out, int* counter, int cap, void* workspace, void* stream)
+{
+    AL3D_REQUIRE(ksize && stride && pad && grid_out && coords_out && counter && workspace,
+                 "al3d_sp_down_sites: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t cells = (int64_t)B * OD * OH * OW;
+    AL3D_REQUIRE(cells > 0 && cells < (1LL << 31), "al3d_sp_down_sites: bad grid");
+    int* flags = (int*)workspace;
+    int* scan = (int*)((unsigned char*)workspace + al3d_align(cells * 4, 256));
+    void* scan_ws = (unsigned char*)workspace + 2 * al3d_align(cells * 4, 256);
+    if (hipMemsetAsync(flags, 0, (size_t)cells * 4, s) != hipSuccess)
+        return al3d_fail(AL3D_ELAUNCH, "al3d_sp_down_sites: memset failed");
+    if (n_in > 0) {
+        AL3D_REQUIRE(coords_in, "al3d_sp_down_sites: null coords");
+        SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
+        SpDims go = {B, OD, OH, OW};
+        hipLaunchKernelGGL(sp_down_mark_kernel, dim3(blocks_for(n_in, 256)), dim3(256), 0, s, coords_in, n_in,
+                           q, go, flags);
+        int rc = al3d_exclusive_scan_i32(flags, scan, cells, scan_ws, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(sp_down_assign_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s, flags, scan,
+                           cells, go, grid_out, coords_out, cap);
+        hipLaunchKernelGGL(sp_count_tail_kernel, dim3(1), dim3(64), 0, s, flags, scan, cells, counter);
+    } else if (hipMemsetAsync(counter, 0, 4, s) != hipSuccess) {
+        return al3d_fail(AL3D_ELAUNCH, "al3d_sp_down_sites: memset failed");
+    }
+    AL3D_CHECK_LAUNCH("sp_down_sites");
     return AL3D_OK;
 }
 

@@ -74,6 +74,23 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
     }
     __syncthreads();
     const int nsteps = s_ntaps * KCHUNKS;
+    // per-wave refinement: offsets that are empty for one of this wave's 32-row sub-tiles are
+    // skipped for that sub-tile (rows are in raster order, so whole sub-tiles often miss the
+    // dz/dy != 0 offsets)
+    unsigned wmask[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        unsigned m = 0u;
+        const int row = row0 + wm * WM + i * 32 + fr;
+        for (int k0 = 0; k0 < K; k0 += 2) {            // all 64 lanes run every iteration
+            const int k = k0 + fh;                     // low half tests offset k0, high half k0+1
+            const bool v = k < K && row < n_out && nbr[(int64_t)k * n_out + row] >= 0;
+            const unsigned long long bal = __ballot(v);
+            if (bal & 0xffffffffull) m |= 1u << k0;
+            if (bal >> 32) m |= 1u << (k0 + 1);
+        }
+        wmask[i] = __builtin_amdgcn_readfirstlane(m);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -138,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
+        const int tap_now = s_taps[step / KCHUNKS];
         if (step + 1 < nsteps) load_step(step + 1);
         const float* Ab = &As[buf][(wm * WM + fr) * LD + 4 * fh];
         const float* Bb = &Bs[buf][(wn * WN + fr) * LD + 4 * fh];
@@ -155,12 +173,14 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
                 bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int i = 0; i < TM; ++i) {
+                if (!(wmask[i] >> tap_now & 1u)) continue;      // wave-uniform
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+            }
         }
         if (step + 1 < nsteps) store_step(buf ^ 1);
         __syncthreads();

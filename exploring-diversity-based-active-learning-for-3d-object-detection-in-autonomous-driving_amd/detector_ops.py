@@ -34,19 +34,40 @@ def fold_bn(bn):
     return scale.float().contiguous(), shift.float().contiguous()
 
 
+def split_bf16x3(w_packed):
+    """f32 packed weights (device) -> bf16 [3, *shape] exact three-way split (hi, mid, lo)."""
+    w = _dev(w_packed, torch.float32, "w")
+    out = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+    lib.call("al3d_split_bf16x3", _ptr(w), w.numel(), _ptr(out), _stream())
+    return out
+
+
+# Arithmetic of the MFMA conv kernels: "bf16x6" = fp32-faithful six-product split on the bf16
+# matrix cores (default), "f32" = fp32-input MFMA (bitwise an fp32 FMA chain).
+import os as _os
+MATH = _os.environ.get("AL3D_MATH", "bf16x6")
+
+
 # ------------------------------------------------------------------ kernels
 def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, coff=0):
     x = _dev(x, torch.float32, "x")
-    w_packed = _dev(w_packed, torch.float32, "w")
+    split = w_packed.dtype == torch.bfloat16          # [3, Cout, taps, Cin] from split_bf16x3
+    if split:
+        w_packed = _dev(w_packed, torch.bfloat16, "w")
+        wshape = w_packed.shape[1:]
+    else:
+        w_packed = _dev(w_packed, torch.float32, "w")
+        wshape = w_packed.shape
     B, H, W, Cin = x.shape
-    Cout = w_packed.shape[0]
-    assert w_packed.shape[1] == ksize * ksize and w_packed.shape[2] == Cin
+    Cout = wshape[0]
+    assert wshape[1] == ksize * ksize and wshape[2] == Cin
     OH = (H + 2 * pad - ksize) // stride + 1
     OW = (W + 2 * pad - ksize) // stride + 1
     if out is None:
         out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, OH, OW) and out.is_contiguous()
-    lib.call("al3d_conv2d_nhwc_f32", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
+    lib.call("al3d_conv2d_nhwc_bf16x6" if split else "al3d_conv2d_nhwc_f32", _ptr(x), _ptr(w_packed),
+             _ptr(scale), _ptr(shift), _ptr(out),
              B, H, W, Cin, Cout, ksize, stride, pad, out.shape[3], coff, 1 if relu else 0, _stream())
     return out
 
@@ -54,11 +75,12 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
 def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0):
     x = _dev(x, torch.float32, "x")
     B, H, W, Cin = x.shape
-    Cout = w_packed.shape[0]
+    split = w_packed.dtype == torch.bfloat16
+    Cout = w_packed.shape[1] if split else w_packed.shape[0]
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, 2 * H, 2 * W) and out.is_contiguous()
-    lib.call("al3d_deconv2x2_nhwc_f32", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
+    lib.call("al3d_deconv2x2_nhwc_bf16x6" if split else "al3d_deconv2x2_nhwc_f32", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
              B, H, W, Cin, Cout, out.shape[3], coff, 1 if relu else 0, _stream())
     return out
 

@@ -193,8 +193,10 @@ class _SparseEncoderBase(nn.Module):
                 ocoords = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
                 counter = torch.zeros(1, dtype=torch.int32, device=dev)
                 ks, ss, ps = _i3(m.kernel_size), _i3(m.stride), _i3(m.padding)
-                lib.call("al3d_sp_down_claim", _ptr(coords), n, ks, ss, ps, batch_size, olv.D, olv.H,
-                         olv.W, _ptr(olv.grid), _ptr(ocoords), _ptr(counter), cap, st)
+                ws = torch.empty(lib.load().al3d_sp_down_sites_workspace_bytes(batch_size, olv.D, olv.H, olv.W),
+                                 dtype=torch.uint8, device=dev)
+                lib.call("al3d_sp_down_sites", _ptr(coords), n, ks, ss, ps, batch_size, olv.D, olv.H,
+                         olv.W, _ptr(olv.grid), _ptr(ocoords), _ptr(counter), cap, _ptr(ws), st)
                 n_out = int(counter.item())      # one small D2H per stage
                 ocoords = ocoords[:n_out]
                 used.append((olv, ocoords, n_out))

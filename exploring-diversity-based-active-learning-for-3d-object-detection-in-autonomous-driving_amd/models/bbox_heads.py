@@ -104,7 +104,7 @@ class MultiGroupHead(nn.Module):
 
     # ------------------------------------------------------------ fused 1x1 convs
     def _prepare(self, device):
-        if getattr(self, "_packed_dev", None) == device:
+        if getattr(self, "_packed_dev", None) == (device, D.MATH):
             return
         ws, bs, self._box_off, self._cls_off = [], [], [], []
         off = 0
@@ -119,8 +119,10 @@ class MultiGroupHead(nn.Module):
             off += t.conv_cls.out_channels
         self._ch = off
         self._w = D.pack_conv_weight(torch.cat([w.detach() for w in ws], dim=0)).to(device)
+        if D.MATH == "bf16x6":
+            self._w = D.split_bf16x3(self._w)
         self._b = torch.cat([b.detach() for b in bs]).float().contiguous().to(device)
-        self._packed_dev = device
+        self._packed_dev = (device, D.MATH)
 
     def forward(self, x, finetune=False):
         """x NHWC [B,H,W,512] -> list of per-task dicts with NHWC views

@@ -69,8 +69,12 @@ class RPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.xavier_uniform_(m.weight)
 
+    @staticmethod
+    def _w(w):
+        return D.split_bf16x3(w) if D.MATH == "bf16x6" else w
+
     def _prepare(self, device):
-        if getattr(self, "_packed_dev", None) == device:
+        if getattr(self, "_packed_dev", None) == (device, D.MATH):
             return
         self._blocks_p, self._deblocks_p = [], []
         for blk in self.blocks:
@@ -80,7 +84,7 @@ class RPN(nn.Module):
                 if isinstance(m, nn.Conv2d):
                     scale, shift = D.fold_bn(mods[j + 1])
                     pad = 1 if (j > 0 and isinstance(mods[j - 1], nn.ZeroPad2d)) else m.padding[0]
-                    convs.append(dict(w=D.pack_conv_weight(m.weight).to(device), scale=scale.to(device),
+                    convs.append(dict(w=self._w(D.pack_conv_weight(m.weight).to(device)), scale=scale.to(device),
                                       shift=shift.to(device), k=m.kernel_size[0], s=m.stride[0], p=pad))
             self._blocks_p.append(convs)
         for de in self.deblocks:
@@ -88,13 +92,13 @@ class RPN(nn.Module):
             scale, shift = D.fold_bn(bn)
             if isinstance(up, nn.ConvTranspose2d):
                 assert up.kernel_size == (2, 2) and up.stride == (2, 2), "only 2x2/s2 deconv is built"
-                self._deblocks_p.append(dict(deconv=True, w=D.pack_deconv_weight(up.weight).to(device),
+                self._deblocks_p.append(dict(deconv=True, w=self._w(D.pack_deconv_weight(up.weight).to(device)),
                                              scale=scale.to(device), shift=shift.to(device)))
             else:
-                self._deblocks_p.append(dict(deconv=False, w=D.pack_conv_weight(up.weight).to(device),
+                self._deblocks_p.append(dict(deconv=False, w=self._w(D.pack_conv_weight(up.weight).to(device)),
                                              scale=scale.to(device), shift=shift.to(device),
                                              k=up.kernel_size[0], s=up.stride[0]))
-        self._packed_dev = device
+        self._packed_dev = (device, D.MATH)
 
     def forward(self, x):
         """x NHWC [B,H,W,Cin] -> NHWC [B,H',W',sum(us_num_filters)]."""
@@ -121,5 +125,5 @@ class RPN(nn.Module):
                         out = torch.empty((B, oh, ow, ctot), dtype=torch.float32, device=x.device)
                     D.conv2d_nhwc(x, d["w"], d["scale"], d["shift"], d["k"], d["s"], 0, True, out=out,
                                   coff=coff)
-                coff += d["w"].shape[0]
+                coff += d["scale"].shape[0]
         return out if out is not None else x

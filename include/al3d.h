@@ -178,8 +178,9 @@ int al3d_box_decode_f32(const float* enc, const float* anchors, int64_t n, float
  * (det3d/models/backbones/scn.py:28-97,316-392: SubMConv3d / SparseConv3d /
  * SparseConvTensor.dense()).  coords are [n,4] i32 (batch, z, y, x); `grid` is a dense
  * per-level index grid [B,D,H,W] i32 holding the row id of every active site (-1 = empty)
- * that the caller keeps in HBM across calls.  The rulebook is output-major:
- * nbr[o][k] = input row feeding output o through kernel offset k = (kz*kh+ky)*kw+kx, or -1. */
+ * that the caller keeps in HBM across calls.  The rulebook is stored tap-major:
+ * nbr[k * n_out + o] = input row feeding output o through kernel offset k = (kz*kh+ky)*kw+kx,
+ * or -1 (one entry per (offset, output) pair; no scatter, no atomics in the conv). */
 int al3d_sp_fill_i32(int* buf, int64_t count, int value, void* stream);          /* 0 or -1 */
 int al3d_sp_scatter_index(const int* coords, int n, int B, int D, int H, int W, int* grid,
                           int mode /* 1: grid=row id, 0: grid=-1 */, void* stream);
@@ -190,6 +191,13 @@ int al3d_sp_subm_table(const int* coords, int n, int B, int D, int H, int W, con
 int al3d_sp_down_claim(const int* coords_in, int n_in, const int* ksize, const int* stride,
                        const int* pad, int B, int OD, int OH, int OW, int* grid_out,
                        int* coords_out, int* counter, int cap, void* stream);
+/* Deterministic variant used by the encoder: mark the fed output cells, scan the grid, number
+ * the sites in raster (b,z,y,x) order.  Same outputs as al3d_sp_down_claim but with a fixed
+ * row order; workspace >= al3d_sp_down_sites_workspace_bytes(). */
+int64_t al3d_sp_down_sites_workspace_bytes(int B, int OD, int OH, int OW);
+int al3d_sp_down_sites(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                       const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                       int* coords_out, int* counter, int cap, void* workspace, void* stream);
 /* ... then its rulebook from the input level's grid */
 int al3d_sp_down_table(const int* coords_out, int n_out, const int* ksize, const int* stride,
                        const int* pad, int B, int ID, int IH, int IW, const int* grid_in, int* nbr,
@@ -229,6 +237,19 @@ int al3d_conv2d_nhwc_f32(const float* in, const float* wgt, const float* scale, 
 int al3d_deconv2x2_nhwc_f32(const float* in, const float* wgt, const float* scale,
                             const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
                             int ldc, int coff, int relu, void* stream);
+
+/* fp32-faithful variants on the bf16 matrix cores ("bf16x6"): every fp32 operand is split
+ * exactly into three bf16 pieces and each product is formed from the six partial products of
+ * order <= 2 (dropped terms < 2^-25 relative), fp32 accumulation.  Same contract as the two
+ * entry points above except that the weights are pre-split with al3d_split_bf16x3()
+ * (f32 [count] -> bf16 [3][count], planes hi/mid/lo) and Cin % 16 == 0. */
+int al3d_split_bf16x3(const float* w, int64_t count, void* out_bf16x3, void* stream);
+int al3d_conv2d_nhwc_bf16x6(const float* in, const void* wgt_bf16x3, const float* scale,
+                            const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                            int ksize, int stride, int pad, int ldc, int coff, int relu, void* stream);
+int al3d_deconv2x2_nhwc_bf16x6(const float* in, const void* wgt_bf16x3, const float* scale,
+                               const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                               int ldc, int coff, int relu, void* stream);
 
 /* BEV embedding: mean over W then over H of an NHWC map, [B,H,W,C] -> [B,C].
  * Replaces `fpn_feats[-1].mean(-1).mean(-1)` (det3d/selectors/feature_selector.py:68-71). */

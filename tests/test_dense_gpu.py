@@ -74,3 +74,48 @@ def test_gap_matches_two_stage_mean():
     ref = x.mean(-1).mean(-1)
     got = D.gap_nhwc(_nhwc(x).to(DEV))
     torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- bf16x6 (fp32-faithful) kernels
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(1, 16, 16, 32, 128, 3, 1, 1), (2, 24, 40, 64, 128, 3, 1, 1),
+                                                  (1, 32, 32, 128, 256, 3, 2, 1), (2, 13, 19, 32, 40, 1, 1, 0),
+                                                  (1, 64, 64, 256, 128, 3, 1, 1)])
+def test_conv2d_bf16x6_is_fp32_faithful(B, H, W, Cin, Cout, k, s, p):
+    """The six-product bf16 split must be as close to the exact (fp64) convolution as the
+    fp32-input MFMA kernel is: compare both against an fp64 CPU reference."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(H * 7 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, H, W, generator=g))  # wide dynamic range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), stride=s, padding=p)
+    ref = _nhwc(ref)
+    wp = D.pack_conv_weight(w).to(DEV)
+    got32 = D.conv2d_nhwc(_nhwc(x).to(DEV), wp, None, None, k, s, p, False).cpu().double()
+    got6 = D.conv2d_nhwc(_nhwc(x).to(DEV), D.split_bf16x3(wp), None, None, k, s, p, False).cpu().double()
+    scale = F.conv2d(x.abs().double(), w.abs().double(), stride=s, padding=p)   # sum |a*b| per output
+    scale = _nhwc(scale)
+    e32 = ((got32 - ref).abs() / scale).max().item()
+    e6 = ((got6 - ref).abs() / scale).max().item()
+    # both are fp32-accumulation noise (K up to 2304): below 1.5e-6 of sum|a*b|; the split may not
+    # be worse than 2x the fp32-input kernel (measured: it is slightly better)
+    assert e32 < 1.5e-6 and e6 < 1.5e-6 and e6 < 2.0 * e32 + 1e-8, (e32, e6)
+
+
+def test_split_bf16x3_is_exact():
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(1)
+    w = (torch.randn(4096, generator=g) * torch.exp(torch.randn(4096, generator=g) * 3)).to(DEV)
+    s3 = D.split_bf16x3(w).float()
+    assert torch.equal(s3[0] + s3[1] + s3[2], w)          # x = x1 + x2 + x3 exactly
+    assert torch.equal(s3[0], w.bfloat16().float())       # hi piece = RNE bf16
+
+
+def test_deconv_bf16x6_matches_f32_kernel():
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    w = torch.randn(64, 96, 2, 2, generator=g) / 8.0
+    wp = D.pack_deconv_weight(w).to(DEV)
+    a = D.deconv2x2_nhwc(_nhwc(x).to(DEV), wp, None, None, False)
+    b = D.deconv2x2_nhwc(_nhwc(x).to(DEV), D.split_bf16x3(wp), None, None, False)
+    torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-6)

@@ -6,12 +6,15 @@ from al3d import detector_ops as D
 
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+MODE = sys.argv[2] if len(sys.argv) > 2 else 'f32'
 shapes = [  # H, Cin, Cout, k, s, p
     (128, 256, 128, 3, 1, 1), (128, 128, 128, 3, 1, 1), (128, 128, 256, 1, 1, 0),
     (128, 128, 256, 3, 2, 1), (64, 256, 256, 3, 1, 1), (128, 512, 236, 1, 1, 0)]
 for (H, Cin, Cout, k, s, p) in shapes:
     x = torch.randn(B, H, H, Cin, device=dev)
     w = torch.randn(Cout, k * k, Cin, device=dev) * 0.05
+    if MODE == 'bf16x6':
+        w = D.split_bf16x3(w)
     sc = torch.ones(Cout, device=dev); sh = torch.zeros(Cout, device=dev)
     OH = (H + 2 * p - k) // s + 1
     out = torch.empty(B, OH, OH, Cout, device=dev)
@@ -26,4 +29,4 @@ for (H, Cin, Cout, k, s, p) in shapes:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * OH * OH * Cout * Cin * k * k
-    print(f"B={B} H={H} Cin={Cin} Cout={Cout} k={k} s={s}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
+    print(f"{MODE} B={B} H={H} Cin={Cin} Cout={Cout} k={k} s={s}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
