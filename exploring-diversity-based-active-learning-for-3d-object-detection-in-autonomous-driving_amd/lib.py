@@ -36,6 +36,11 @@ SIGNATURES = {
                                         c_dbl, c_int, c_p, c_i64, c_p, c_p, c_p]),
     "al3d_greedy_kcenter_f32": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_dbl, c_dbl,
                                         c_dbl, c_int, c_p, c_i64, c_p, c_p, c_p]),
+    "al3d_frame_entropy_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_scale_rows_f32": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p, c_p]),
+    "al3d_minmax_norm_f32": (c_int, [c_p, c_i64, c_p, c_p]),
+    "al3d_argsort_workspace_bytes": (c_i64, [c_i64]),
+    "al3d_argsort_desc_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p]),
     "al3d_knn_2d_f64": (c_int, [c_p, c_i64, c_int, c_p, c_p, c_p]),
     "al3d_apsp_workspace_bytes": (c_i64, [c_i64, c_int]),
     "al3d_apsp_knn_f64": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p]),

@@ -42,6 +42,14 @@ class LazyDetections:
             self._list = out
         return self._list
 
+    def frame_entropy(self):
+        """[B] mean binary entropy of each frame's kept scores (device tensor; empty frame ->
+        NaN), computed from the raw NMS buffers without materialising the detection dicts."""
+        from .. import selector_ops as ops
+        boxes, scores, labels, counts, done, meta = self._raw
+        torch.cuda.current_stream(boxes.device).wait_event(done)
+        return ops.frame_entropy(scores, counts)
+
     def __len__(self):
         return self._raw[3].shape[0]
 

@@ -115,6 +115,43 @@ def spatial_map(xy, k=8):
     return full[:n]
 
 
+def frame_entropy(scores, counts):
+    """scores [B,nt,post] f32, counts [B,nt] i32 -> [B] mean binary entropy per frame."""
+    scores = _dev(scores, torch.float32, "scores")
+    counts = _dev(counts, torch.int32, "counts")
+    B, nt, post = scores.shape
+    out = torch.empty((B,), dtype=torch.float32, device=scores.device)
+    lib.call("al3d_frame_entropy_f32", _ptr(scores), _ptr(counts), B, nt, post, _ptr(out), _stream())
+    return out
+
+
+def scale_rows(feats, w, widx=None):
+    feats = _dev(feats, torch.float32, "feats")
+    w = _dev(w, torch.float32, "w")
+    widx = _dev(widx, torch.int64, "widx")
+    n, c = feats.shape
+    out = torch.empty_like(feats)
+    lib.call("al3d_scale_rows_f32", _ptr(feats), _ptr(w), _ptr(widx), n, c, _ptr(out), _stream())
+    return out
+
+
+def minmax_norm(x):
+    x = _dev(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    lib.call("al3d_minmax_norm_f32", _ptr(x), x.numel(), _ptr(out), _stream())
+    return out
+
+
+def argsort_desc(x):
+    """torch.argsort(-x) semantics: descending, NaN last, ties by ascending index."""
+    x = _dev(x, torch.float32, "x")
+    n = x.numel()
+    out = torch.empty((n,), dtype=torch.int64, device=x.device)
+    ws = torch.empty(max(8, lib.load().al3d_argsort_workspace_bytes(n)), dtype=torch.uint8, device=x.device)
+    lib.call("al3d_argsort_desc_f32", _ptr(x), n, _ptr(out), _ptr(ws), _stream())
+    return out
+
+
 def greedy_kcenter(D, seeded, first, box_cost, cost_f, start_cost, budget_int, seed_map=None,
                    check_seeded=False, cap=None):
     """Run the whole pick loop on device.  Returns (status, picks[list[int]])."""

@@ -9,7 +9,9 @@ from .map_selectors import (SpatialSelector, TemporalSelector, EuSpatialSelector
 from .feature_selectors import (FeatureSelector, SpatialFeatureSelector,
                                 SpatialTemporalFeatureSelector)
 
-__all__ = ["BaseSelector", "RandomSelector", "SpatialSelector", "EuSpatialSelector",
+from .uncertainty_selectors import EntropySelector, BadgeSelector, UWESelector
+
+__all__ = ["EntropySelector", "BadgeSelector", "UWESelector","BaseSelector", "RandomSelector", "SpatialSelector", "EuSpatialSelector",
            "TemporalSelector", "SpatialTemporalSelector", "FeatureSelector",
            "SpatialFeatureSelector", "SpatialTemporalFeatureSelector",
            "SELECTORS", "build_selector"]

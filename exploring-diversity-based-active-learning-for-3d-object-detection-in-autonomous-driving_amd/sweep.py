@@ -62,10 +62,16 @@ def gather_in_dataset_order(local_feats, local_index, num_frames):
     return out
 
 
-def sweep_embeddings(detector, dataloader, device, num_frames=None):
+def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy=False,
+                     batch_local_weights=None):
     """Run ``detector(example, return_loss=False, estimate=True)`` over the loader and
-    return the ``[N,512]`` embeddings in dataset order (on ``device``)."""
-    feats, index = [], []
+    return the ``[N,512]`` embeddings in dataset order (on ``device``).
+
+    ``with_entropy``: also return the ``[N]`` per-frame mean box entropy
+    (entropy_selector.py:72-75).  ``batch_local_weights``: UWE's second pass -- a ``[>=B]``
+    tensor indexed by the position *inside the batch* that scales each embedding
+    (uwe_selector.py:96-99, quirk A.1 #8)."""
+    feats, index, ents = [], [], []
     seen = 0
     sampler_idx = None
     sampler = getattr(dataloader, "sampler", None)
@@ -75,8 +81,14 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None):
     with torch.no_grad():
         for data_batch in dataloader:
             example = example_to_device(data_batch, device, non_blocking=False)
-            _, middle = detector(example, return_loss=False, estimate=True)
+            preds, middle = detector(example, return_loss=False, estimate=True)
             emb = gap_embedding(middle[-1])
+            if batch_local_weights is not None:
+                from . import selector_ops as ops
+                emb = ops.scale_rows(emb.contiguous(), batch_local_weights[: emb.shape[0]].contiguous())
+            if with_entropy:
+                ents.append(preds.frame_entropy() if hasattr(preds, "frame_entropy")
+                            else torch.stack([_entropy_of(p["scores"]) for p in preds]))
             feats.append(emb)
             b = emb.shape[0]
             if sampler_idx is not None:
@@ -87,4 +99,18 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None):
     local = torch.cat(feats, dim=0)
     idx = torch.as_tensor(index, dtype=torch.int64, device=local.device)
     n = num_frames if num_frames is not None else int(idx.max().item()) + 1
-    return gather_in_dataset_order(local, idx, n)
+    out = gather_in_dataset_order(local, idx, n)
+    if with_entropy:
+        e = gather_in_dataset_order(torch.cat(ents).unsqueeze(1), idx, n).squeeze(1)
+        return out, e
+    return out
+
+
+def _entropy_of(scores):
+    """Fallback for detectors that return plain dict lists (not this build's head)."""
+    from . import selector_ops as ops
+    s = scores.float().contiguous().view(1, 1, -1)
+    cnt = torch.tensor([[s.shape[2]]], dtype=torch.int32, device=s.device)
+    if s.shape[2] == 0:
+        return torch.full((), float("nan"), device=s.device)
+    return ops.frame_entropy(s, cnt)[0]

@@ -99,6 +99,21 @@ int al3d_greedy_kcenter_f32(const float* D, const float* seed_map, int64_t n,
                             int64_t* out_idx, int64_t cap, int64_t* out_meta,
                             void* workspace, void* stream);
 
+/* Uncertainty-selector epilogues.
+ * frame entropy: mean over a frame's kept boxes of -s log s - (1-s) log(1-s), read from the
+ * al3d_head_decode_nms outputs (scores [B,nt,post], counts [B,nt]); empty frame -> NaN.
+ * Replaces det3d/selectors/entropy_selector.py:72-75 (same lines in badge/uwe selectors). */
+int al3d_frame_entropy_f32(const float* scores, const int* counts, int B, int nt, int post,
+                           float* out, void* stream);
+/* out[i,:] = feats[i,:] * w[widx ? widx[i] : i]  (badge_selector.py:75-78, uwe_selector.py:96-99) */
+int al3d_scale_rows_f32(const float* feats, const float* w, const int64_t* widx, int64_t n, int c,
+                        float* out, void* stream);
+/* (x - min) / (max - min), NaN-propagating like torch (uwe_selector.py:78) */
+int al3d_minmax_norm_f32(const float* x, int64_t n, float* out, void* stream);
+/* torch.argsort(-x): descending, NaN last, ties by ascending index (entropy_selector.py:121) */
+int64_t al3d_argsort_workspace_bytes(int64_t n);
+int al3d_argsort_desc_f32(const float* x, int64_t n, int64_t* out_idx, void* workspace, void* stream);
+
 /* Exact k-nearest neighbours (self included) of 2-D points, ascending
  * (distance, index).  Replaces scipy cKDTree(locations).query(locations, k+1)
  * (spatial_temporal_selector.py:97-98).  xy [n,2] f64 -> knn_d [n,kq] f64,

@@ -60,12 +60,16 @@ def _capture_locals(func, names):
 
 
 def run_case(name, cls_name, module, infos, logs, buffer, budget, kwargs=None,
-             feats_seed=None, feats_scale=0.01, capture=False, expect_assert=False):
+             feats_seed=None, feats_scale=0.01, capture=False, expect_assert=False,
+             entropy=None, modname=None):
     kwargs = dict(kwargs or {})
     feats = None
     if feats_seed is not None:
         feats = synthetic.make_embeddings(len(infos), seed=feats_seed, scale=feats_scale)
     mods = ref_import.import_selectors()
+    if module not in mods:
+        import importlib
+        mods[module] = importlib.import_module("det3d.selectors." + module)
     cls = getattr(mods[module], cls_name)
     with tempfile.TemporaryDirectory() as td:
         infos_p = os.path.join(td, "infos.pkl")
@@ -83,9 +87,18 @@ def run_case(name, cls_name, module, infos, logs, buffer, budget, kwargs=None,
             fp = os.path.join(td, "feats.pt")
             torch.save(torch.from_numpy(feats), fp)
             ctor["buffer_path"] = fp
-        if cls_name not in ("FeatureSelector", "TemporalSelector", "RandomSelector"):
+        if cls_name in ("BadgeSelector", "UWESelector"):
+            fp = os.path.join(td, "wfeats.pt")
+            torch.save(torch.from_numpy(feats), fp)
+            ctor["weighted_feat_path"] = fp
+        if cls_name == "EntropySelector":
+            fp = os.path.join(td, "entropy.pt")
+            torch.save(torch.from_numpy(entropy), fp)
+            ctor["buffer_path"] = fp
+        if cls_name not in ("FeatureSelector", "TemporalSelector", "RandomSelector", "EntropySelector",
+                            "BadgeSelector", "UWESelector"):
             ctor["logs_file"] = logs_p
-        if cls_name not in ("TemporalSelector", "RandomSelector"):
+        if cls_name not in ("TemporalSelector", "RandomSelector", "EntropySelector"):
             ctor["distance_store_file"] = os.path.join(td, "dist.npy")
         ctor.update(kwargs)
         torch.manual_seed(SEED)
@@ -125,6 +138,8 @@ def run_case(name, cls_name, module, infos, logs, buffer, budget, kwargs=None,
         current_budget=np.array(key), selected=selected, error=np.array(err),
         logs_json=np.array(json.dumps(logs)),
     )
+    if entropy is not None:
+        out["entropy"] = entropy
     if feats is not None:
         # embeddings are regenerated from the seed by the tests
         # (al3d.synthetic.make_embeddings); the digest guards the generator.
@@ -195,6 +210,25 @@ def main():
              kwargs=dict(lambda_f=2.0, lambda_t=0.5, p=1), feats_seed=5, capture=True)
     run_case("stf_pool64_b600", *STF, pool64, logs64, empty, 600,
              kwargs=dict(lambda_f=1.0, lambda_t=1.0), feats_seed=6)
+    # uncertainty family (pred=False: the swept quantities are loaded from .pt files)
+    import importlib
+    for mod in ("uwe_selector", "badge_selector"):
+        ref_import.import_selectors()[mod] = importlib.import_module("det3d.selectors." + mod)
+    rng = np.random.default_rng(9)
+    ent = rng.uniform(0.05, 0.69, size=len(small)).astype(np.float32)
+    # no exact ties: torch.argsort is not stable, the reference's tie order is unspecified
+    run_case("entropy_seeded", "EntropySelector", "entropy_selector", small, small_logs, seeded, 30,
+             entropy=ent)
+    ent_nan = ent.copy()
+    ent_nan[[10, 11, 100]] = np.nan                 # frames without detections
+    run_case("entropy_empty_nan", "EntropySelector", "entropy_selector", small, small_logs, empty, 40,
+             entropy=ent_nan)
+    run_case("entropy_random_sample", "EntropySelector", "entropy_selector", small, small_logs, seeded, 30,
+             kwargs=dict(random_sample=True, sample_num=100), entropy=ent)
+    run_case("badge_seeded", "BadgeSelector", "badge_selector", small, small_logs, seeded, 30,
+             kwargs=dict(p=2), feats_seed=5)
+    run_case("uwe_seeded", "UWESelector", "uwe_selector", small, small_logs, seeded, 30,
+             kwargs=dict(p=1), feats_seed=7)
     SF = ("SpatialFeatureSelector", "spatial_feature_selector")
     run_case("sf_seeded", *SF, small, small_logs, seeded, 30, feats_seed=5, capture=True)
 

@@ -250,3 +250,18 @@ def head_predict(hout, anchors, na, nc, box_off, cls_off, score_thresh, iou_thre
 def set_threads(n):
     """OpenMP thread count of the oracle (cpu_baseline reports it as `cores`)."""
     lib().al3d_oracle_set_threads(c_int(int(n)))
+
+
+def argsort_desc(x):
+    """torch.argsort(-x) restated: descending, NaN last, ties by ascending index (stable)."""
+    x = np.asarray(x, dtype=np.float32)
+    return np.argsort(-x, kind="stable")
+
+
+def frame_entropy(scores):
+    """Mean binary entropy of one frame's kept scores (entropy_selector.py:72-75); NaN if empty."""
+    s = np.asarray(scores, dtype=np.float32)
+    if s.size == 0:
+        return np.float32(np.nan)
+    h = -s * np.log(s) - (np.float32(1.0) - s) * np.log(np.float32(1.0) - s)
+    return h.astype(np.float32).mean(dtype=np.float32)

@@ -62,3 +62,7 @@ def greedy(D, seeded, first, box_cost, cost_f, start_cost, budget_int, seed_map=
                                    cost_f, start_cost, budget_int, seed_map=st,
                                    check_seeded=check_seeded, cap=cap)
     return rc, np.asarray(picks, dtype=np.int64)
+
+
+def argsort_desc(x):
+    return ops.argsort_desc(_t(x, np.float32)).cpu().numpy()

@@ -92,7 +92,30 @@ def run_case(fx, backend, feats=None, maps_out=None):
         check_seeded = True
         if maps_out is not None:
             maps_out.update(distance_map=D)
-    elif cls == "FeatureSelector":
+    elif cls == "EntropySelector":
+        # entropy_selector.py:88-147: argsort(-entropy) over the unlabeled frames, taken in
+        # order under the budget; first pick charged at infos_origin[sorted position] (quirk 7)
+        left = [i for i in range(n) if i not in sampled]
+        if kw.get("random_sample", False):
+            left = random.sample(left, kw["sample_num"])
+        ent = np.asarray(fx["entropy"], dtype=np.float32)[left]
+        srt = [int(v) for v in backend.argsort_desc(ent)]
+        picks = [left[srt[0]]]
+        cost = start_cost
+        cost += cost_f
+        cost += int(fx["n_boxes"][srt[0]]) * cost_b
+        sid = 1
+        while True:
+            idx = left[srt[sid]]
+            sid += 1
+            assert idx not in picks
+            cost += cost_f
+            cost += int(fx["n_boxes"][idx]) * cost_b
+            if cost > budget_int:
+                break
+            picks.append(idx)
+        return 0, picks + sampled
+    elif cls in ("FeatureSelector", "BadgeSelector", "UWESelector"):
         D = backend.l1_map_f32(feats, kw.get("p", 2))
         order = "selected+sampled"
         if maps_out is not None:

@@ -259,3 +259,54 @@ def test_detector_batch_invariance_and_determinism():
         assert p["box3d_lidar"].shape == (k, 9) and p["scores"].shape == (k,) and k <= 6 * 83
         assert p["label_preds"].dtype == torch.int64 and int(p["label_preds"].max()) <= 9
         assert p["metadata"]["token"].startswith("frame")
+
+
+def test_uncertainty_sweeps_compose(oracle, tmp_path):
+    """pred=True paths of Entropy / Badge / UWE: the swept quantities must equal what the
+    reference expressions give on the detector's own outputs (entropy from the post-NMS scores,
+    embeddings times entropy, UWE's batch-local weighting)."""
+    import json
+    import pickle
+    from al3d import synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.selectors import build_selector
+    from al3d.sweep import sweep_embeddings
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    infos, _ = synthetic.make_pool(1, seed=4, frames_per_scene=4)
+    pool = PoolFrames.from_numpy([synthetic.make_point_cloud(60 + i, nsweeps=2) for i in range(4)], DEV)
+
+    def loader():
+        return DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 2, device=DEV)
+
+    feats, ent = sweep_embeddings(model, loader(), DEV, 4, with_entropy=True)
+    # reference expression on the materialised detections
+    ref_ent = []
+    with torch.no_grad():
+        for ex in loader():
+            preds, _ = model(ex, return_loss=False, estimate=True)
+            for p in preds:
+                s = p["scores"]
+                ref_ent.append((-s * torch.log(s) - (1.0 - s) * torch.log(1 - s)).mean())
+    torch.testing.assert_close(ent, torch.stack(ref_ent), rtol=1e-5, atol=1e-6)
+    ip, bp = str(tmp_path / "infos.pkl"), str(tmp_path / "buf.json")
+    pickle.dump(infos, open(ip, "wb"))
+    json.dump({"0": [], "1": [2]}, open(bp, "w"))
+    common = dict(budget=1, buffer_file=bp, infos_origin=ip, pred=True, detector=model)
+    badge = build_selector(dict(type="BadgeSelector", dataloader=loader(), weighted_feat_path="",
+                                distance_store_file=None, **common))
+    torch.testing.assert_close(badge.buffer_pred(local_rank=0), feats * ent[:, None], rtol=1e-6, atol=0)
+    uwe = build_selector(dict(type="UWESelector", dataloader=loader(), weighted_feat_path="",
+                              distance_store_file=None, **common))
+    norm = (ent - ent.min()) / (ent.max() - ent.min())
+    want = feats * norm[torch.tensor([0, 1, 0, 1], device=DEV)][:, None]      # batch-local index (quirk 8)
+    torch.testing.assert_close(uwe.buffer_pred(local_rank=0), want, rtol=1e-5, atol=1e-7)
+    es = build_selector(dict(type="EntropySelector", dataloader=loader(), buffer_path="", **common))
+    es.select_samples(local_rank=0)
+    assert es.selected_index["2"][-1] == 2 and len(es.selected_index["2"]) >= 2

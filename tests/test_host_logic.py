@@ -38,7 +38,8 @@ def test_selector_and_model_registries_carry_reference_names():
     from al3d.selectors import SELECTORS
     for name in ("BaseSelector", "RandomSelector", "SpatialSelector", "TemporalSelector",
                  "EuSpatialSelector", "SpatialTemporalSelector", "FeatureSelector",
-                 "SpatialFeatureSelector", "SpatialTemporalFeatureSelector"):
+                 "SpatialFeatureSelector", "SpatialTemporalFeatureSelector", "EntropySelector",
+                 "BadgeSelector", "UWESelector"):
         assert SELECTORS.get(name) is not None, name
     assert DETECTORS.get("FPNVoxelNet") and DETECTORS.get("VoxelNet")
     assert READERS.get("VoxelFeatureExtractorV3") and BACKBONES.get("FPNSpMiddleResNetFHD")

@@ -190,9 +190,18 @@ def test_build_selector_end_to_end(path, tmp_path):
         fp = os.path.join(tmp, "feats.pt")
         torch.save(torch.from_numpy(_feats(fx)), fp)
         cfg["buffer_path"] = fp
-    if cls not in ("FeatureSelector", "TemporalSelector", "RandomSelector"):
+    if cls in ("BadgeSelector", "UWESelector"):
+        fp = os.path.join(tmp, "wfeats.pt")
+        torch.save(torch.from_numpy(_feats(fx)), fp)
+        cfg["weighted_feat_path"] = fp
+    if cls == "EntropySelector":
+        fp = os.path.join(tmp, "entropy.pt")
+        torch.save(torch.from_numpy(fx["entropy"]), fp)
+        cfg["buffer_path"] = fp
+    if cls not in ("FeatureSelector", "TemporalSelector", "RandomSelector", "EntropySelector",
+                   "BadgeSelector", "UWESelector"):
         cfg["logs_file"] = lp
-    if cls not in ("TemporalSelector", "RandomSelector"):
+    if cls not in ("TemporalSelector", "RandomSelector", "EntropySelector"):
         cfg["distance_store_file"] = os.path.join(tmp, "dist.npy")
     cfg.update(fx["kwargs"])
     random.seed(L.SEED)
@@ -244,3 +253,39 @@ def test_full_size_pool_properties(hip, oracle):
     # unconditional initial pick (the reference appends it before any budget test)
     rc2, more = hip.greedy(D, picks.tolist(), -1, box, 0.12, cost, 600.0)
     assert rc2 == 0 and len(more) == 1 and more[0] not in set(picks.tolist())
+
+
+# ---------------------------------------------------------------- uncertainty epilogues
+def test_argsort_minmax_scale_entropy_primitives(oracle):
+    from al3d import selector_ops as ops
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=5000).astype(np.float32)
+    x[[5, 77, 78, 4000]] = x[9]                      # ties
+    x[[100, 2000]] = np.nan
+    x[[7, 8]] = [np.inf, -np.inf]
+    got = ops.argsort_desc(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+    assert np.array_equal(got, oracle.argsort_desc(x))
+    assert np.array_equal(got, torch.argsort(-torch.from_numpy(x), stable=True).numpy())
+    y = rng.uniform(0.1, 0.6, size=333).astype(np.float32)
+    n = ops.minmax_norm(torch.from_numpy(y).to("cuda:0")).cpu().numpy()
+    ty = torch.from_numpy(y)
+    np.testing.assert_allclose(n, ((ty - ty.min()) / (ty.max() - ty.min())).numpy(), rtol=1e-6, atol=0)
+    y[5] = np.nan
+    assert np.isnan(ops.minmax_norm(torch.from_numpy(y).to("cuda:0")).cpu().numpy()).all()
+    f = rng.normal(size=(40, 512)).astype(np.float32)
+    w = rng.uniform(size=40).astype(np.float32)
+    got = ops.scale_rows(torch.from_numpy(f).to("cuda:0"), torch.from_numpy(w).to("cuda:0")).cpu().numpy()
+    assert np.array_equal(got, f * w[:, None])
+    scores = rng.uniform(0.1, 0.99, size=(3, 6, 83)).astype(np.float32)
+    counts = rng.integers(0, 84, size=(3, 6)).astype(np.int32)
+    counts[1] = 0                                    # a frame without detections -> NaN
+    e = ops.frame_entropy(torch.from_numpy(scores).to("cuda:0"), torch.from_numpy(counts).to("cuda:0")).cpu().numpy()
+    for b in range(3):
+        kept = np.concatenate([scores[b, t, :counts[b, t]] for t in range(6)])
+        ref = oracle.frame_entropy(kept)
+        if b == 1:
+            assert np.isnan(e[b]) and np.isnan(ref)
+        else:
+            np.testing.assert_allclose(e[b], ref, rtol=2e-6)
+            t = torch.from_numpy(kept)
+            np.testing.assert_allclose(e[b], (-t * torch.log(t) - (1.0 - t) * torch.log(1 - t)).mean().item(), rtol=2e-6)
