@@ -35,6 +35,7 @@ FRAMES_PER_SCENE = 40
 BUDGET = 600
 DENSE_GFLOP_PER_FRAME = 67.6      # neck 63.7 + heads 3.96 (2*MAC, fp32)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
 def parse():
@@ -89,14 +90,35 @@ class ConvTimer:
     def result(self):
         if not self.pairs:
             return None
+        from al3d import detector_ops as D
         ms = sum(a.elapsed_time(b) for a, b in self.pairs)
         flops = self.frames * DENSE_GFLOP_PER_FRAME * 1e9
         tf = flops / (ms * 1e-3) / 1e12
-        return dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
-                    kernel="conv2d_mfma_kernel", launches=self.launches,
-                    avg_launch_us=round(ms * 1e3 / max(self.launches, 1), 2),
-                    gflop_per_frame=DENSE_GFLOP_PER_FRAME)
+        out = dict(bound="mfma", achieved=round(tf, 2), unit="TFLOP/s", traffic=None,
+                   launches=self.launches, avg_launch_us=round(ms * 1e3 / max(self.launches, 1), 2),
+                   gflop_per_frame=DENSE_GFLOP_PER_FRAME)
+        if D.MATH == "bf16x6":
+            # fp32-faithful arithmetic on the bf16 matrix cores: every algorithmic MAC executes as
+            # six bf16 MFMA products, so the bf16 peak bounds the *executed* rate.
+            out.update(kernel="conv2d_bf16x6_kernel", peak=MFMA_BF16_PEAK_TFLOPS,
+                       frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), mfma_products_per_mac=6,
+                       executed_tflops=round(6 * tf, 1),
+                       frac_executed=round(6 * tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                       fp32_mfma_peak=MFMA_F32_PEAK_TFLOPS,
+                       vs_fp32_mfma_peak=round(tf / MFMA_F32_PEAK_TFLOPS, 3))
+        else:
+            out.update(kernel="conv2d_mfma_kernel", peak=MFMA_F32_PEAK_TFLOPS,
+                       frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc):      # PMC passes are separate runs (rocprofv3 --pmc); see DESIGN.md
+            try:
+                rec = json.load(open(pmc)).get(out["kernel"])
+                if rec:
+                    out["traffic"] = round(rec["hbm_mb_corrected"] * 1e6)
+                    out["traffic_note"] = rec.get("note", "")
+            except Exception:
+                pass
+        return out
 
 
 def write_pool_files(tmp, infos, logs):
@@ -224,7 +246,9 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "scenes_per_s": round(value / FRAMES_PER_SCENE, 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if _math() == "f32" else "f32 (exact 3-way bf16 split, 6 MFMA products per MAC, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"{args.scenes * world}-scene nuScenes-shaped pool ({n_total} frames, "
                                    f"10-sweep ~250k-point clouds resident in HBM), FPNVoxelNet sweep + "
                                    f"SpatialTemporalFeatureSelector budget {BUDGET} (BASELINE configs[1] per GPU)",
@@ -248,6 +272,11 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _math():
+    from al3d import detector_ops as D
+    return D.MATH
 
 
 def verify_selection(infos, feats, selected):

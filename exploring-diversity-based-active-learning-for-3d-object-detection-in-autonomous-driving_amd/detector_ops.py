@@ -198,8 +198,12 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
                  _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     if mfma is None:
-        mfma = (cin, cout) in MFMA_PAIRS
-    if mfma:
+        mfma = (cin, cout) in MFMA_PAIRS and (MATH if MATH == "bf16x6" else True)
+    if mfma == "bf16x6":
+        w6 = split_bf16x3(w.permute(2, 0, 1).contiguous())
+        lib.call("al3d_sp_conv_bf16x6", _ptr(feats), _ptr(nbr), K, _ptr(w6), cin, cout, _ptr(scale),
+                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+    elif mfma:
         w_ock = w.permute(2, 0, 1).contiguous()          # [Cout, K, Cin]
         lib.call("al3d_sp_conv_mfma_f32", _ptr(feats), _ptr(nbr), K, _ptr(w_ock), cin, cout, _ptr(scale),
                  _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)

@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from .. import lib
+from .. import detector_ops as D
 from ..detector_ops import MFMA_PAIRS, fold_bn
 from ..selector_ops import _ptr, _stream
 from .registry import BACKBONES
@@ -91,7 +92,7 @@ class _SparseEncoderBase(nn.Module):
 
     def _prepare(self, device):
         """Pack weights / fold BN once per device (eval only)."""
-        if getattr(self, "_packed_dev", None) == device:
+        if getattr(self, "_packed_dev", None) == (device, D.MATH):
             return
         plan = []
         for seq in self._stages():
@@ -121,7 +122,7 @@ class _SparseEncoderBase(nn.Module):
                     i += 1
             plan.append(dict(kind="stage_end"))
         self._plan = plan
-        self._packed_dev = device
+        self._packed_dev = (device, D.MATH)
         self._levels = {}
 
     @staticmethod
@@ -129,12 +130,16 @@ class _SparseEncoderBase(nn.Module):
         """[kz,ky,kx,Cin,Cout] -> [K,Cin,Cout] (VALU kernel) or [Cout,K,Cin] (MFMA kernel)."""
         w = m.weight.detach().reshape(-1, m.in_channels, m.out_channels).float()
         if (m.in_channels, m.out_channels) in MFMA_PAIRS:
-            w = w.permute(2, 0, 1)
+            w = w.permute(2, 0, 1).contiguous().to(device)
+            return D.split_bf16x3(w) if D.MATH == "bf16x6" else w
         return w.contiguous().to(device)
 
     @staticmethod
     def _conv(m, feats, nbr, K, step, residual, out, n, st):
-        fn = "al3d_sp_conv_mfma_f32" if (m.in_channels, m.out_channels) in MFMA_PAIRS else "al3d_sp_conv_f32"
+        if (m.in_channels, m.out_channels) in MFMA_PAIRS:
+            fn = "al3d_sp_conv_bf16x6" if step["w"].dtype == torch.bfloat16 else "al3d_sp_conv_mfma_f32"
+        else:
+            fn = "al3d_sp_conv_f32"
         lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
                  _ptr(step["scale"]), _ptr(step["shift"]), residual, 1, _ptr(out), n, st)
 

@@ -229,6 +229,11 @@ int al3d_sp_conv_f32(const float* fin, const int* nbr, int K, const float* wgt, 
 int al3d_sp_conv_mfma_f32(const float* fin, const int* nbr, int K, const float* wgt_ock, int cin,
                           int cout, const float* scale, const float* shift, const float* residual,
                           int relu, float* fout, int n_out, void* stream);
+/* fp32-faithful bf16x6 variant (see al3d_conv2d_nhwc_bf16x6): weights = al3d_split_bf16x3 of
+ * the [Cout, K, Cin] packing; same channel pairs as the fp32-MFMA entry point plus 16->16. */
+int al3d_sp_conv_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
+                        int cout, const float* scale, const float* shift, const float* residual,
+                        int relu, float* fout, int n_out, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
  * out must be zero-filled. */
 int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D, int H,
