@@ -100,7 +100,9 @@ class ConvTimer:
         if D.MATH == "bf16x6":
             # fp32-faithful arithmetic on the bf16 matrix cores: every algorithmic MAC executes as
             # six bf16 MFMA products, so the bf16 peak bounds the *executed* rate.
-            out.update(kernel="conv2d_bf16x6_kernel", peak=MFMA_BF16_PEAK_TFLOPS,
+            out.update(kernel="conv3x3_bf16x6_halo_kernel", peak=MFMA_BF16_PEAK_TFLOPS,
+                       kernel_family="conv3x3_bf16x6_halo_kernel (11 of 15 launches) + conv2d_bf16x6_kernel "
+                                     "(stride-2, 1x1, deconv, fused head)",
                        frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), mfma_products_per_mac=6,
                        executed_tflops=round(6 * tf, 1),
                        frac_executed=round(6 * tf / MFMA_BF16_PEAK_TFLOPS, 4),
