@@ -1,0 +1,57 @@
+"""GPU suite: the N>1 selection path with two ranks sharing cuda:0 (gloo transport, device
+tensors): sharded all-pairs geodesics + all-gather must reproduce the single-process map bit for
+bit, and the gathered embeddings must come back in dataset order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from al3d import selector_ops as ops, synthetic
+        from al3d.sweep import gather_in_dataset_order
+        dev = torch.device("cuda:0")
+        infos, _ = synthetic.make_pool(110, seed=3)            # N = 4400 >= the sharding threshold
+        cfgm, _, _ = synthetic.pool_arrays(infos)
+        xy = torch.from_numpy(np.stack([(-(c[:3, 3].T @ c[:3, :3]))[:2] for c in cfgm])).to(dev)
+        S = ops.spatial_map(xy, 8)                              # sharded over the two ranks
+        d, i = ops.knn_2d(xy, 9)
+        S1 = ops.apsp_knn(d, i)                                 # single-process reference
+        ok_map = bool(torch.equal(S.view(torch.int64), S1.view(torch.int64)))
+        n = 37
+        full = torch.arange(n * 4, dtype=torch.float32, device=dev).view(n, 4)
+        per = (n + world - 1) // world
+        idx = torch.arange(rank * per, min(n, (rank + 1) * per), device=dev)
+        ok_gather = bool(torch.equal(gather_in_dataset_order(full[idx], idx, n), full))
+        q.put((rank, ok_map, ok_gather))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert results == [(0, True, True), (1, True, True)]
