@@ -282,23 +282,52 @@ def _math():
 
 
 def verify_selection(infos, feats, selected):
-    """Checker (not timed): the oracle selector on the same embeddings must pick the same frames."""
+    """Checker (not timed, rank 0 only, no collectives): the oracle selector must pick the same
+    frames.  Pools up to 6,000 frames are recomputed end to end on the CPU; above that the O(N^2 C)
+    oracle maps are too slow, so 48 sampled rows of every device map are compared bit for bit
+    with oracle rows and the oracle's greedy loop runs on the (host copy of the) device map."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build()
-    from al3d import synthetic
+    from al3d import selector_ops as ops, synthetic
     cfgm, run_id, n_boxes = synthetic.pool_arrays(infos)
     n = len(infos)
     xy = np.stack([(-(c[:3, 3].T @ c[:3, :3]))[:2] for c in cfgm])
-    F = oracle.l1_map_f32(feats.cpu().numpy(), 2)
-    S = oracle.spatial_map(xy, 8)
-    D = oracle.combine(n, spatial=S, temporal_id=run_id, feat=F, normalize="exp", aggregate="sum",
-                       lambda_t=1.0, lambda_f=1.0)
     random.seed(3407)
     first = random.choice(range(n))
     box = np.array([int(b) * 0.04 for b in n_boxes], dtype=np.float64)
-    rc, picks = oracle.greedy(D, [], first, box, 0.12, 0.0, float(BUDGET))
-    return bool(rc == 0 and picks.tolist() == list(selected))
+    if n <= 6000:
+        F = oracle.l1_map_f32(feats.cpu().numpy(), 2)
+        S = oracle.spatial_map(xy, 8)
+        D = oracle.combine(n, spatial=S, temporal_id=run_id, feat=F, normalize="exp", aggregate="sum",
+                           lambda_t=1.0, lambda_f=1.0)
+        rc, picks = oracle.greedy(D, [], first, box, 0.12, 0.0, float(BUDGET))
+        return bool(rc == 0 and picks.tolist() == list(selected))
+    dev = feats.device
+    d, i = ops.knn_2d(torch.from_numpy(xy).to(dev), 9)
+    S = ops.apsp_knn(d, i)
+    F = ops.l1_distance(feats, 2)
+    D = ops.combine_maps(n, spatial=S, temporal_id=torch.from_numpy(run_id).to(dev), feat=F,
+                         normalize="exp", aggregate="sum", lambda_t=1.0, lambda_f=1.0)
+    rows = np.unique(np.linspace(0, n - 1, 48).astype(np.int64))
+    kd, ki = oracle.knn(xy, 9)
+    indptr, indices, w = oracle.knn_csr(kd, ki)
+    fnp = feats.cpu().numpy()
+    ok = True
+    for r in rows:
+        s_row = oracle.apsp(indptr, indices, w, int(r), int(r) + 1)[0]
+        f_row = np.zeros(n, dtype=np.float32)
+        acc = np.zeros(n, dtype=np.float32)
+        for c in range(fnp.shape[1]):                      # canonical order c = 0..C-1, float32
+            acc += np.abs(fnp[:, c] - fnp[r, c])
+        f_row = acc
+        ok &= np.array_equal(S[r].cpu().numpy().view(np.int64), s_row.view(np.int64))
+        ok &= np.array_equal(F[r].cpu().numpy().view(np.int32), f_row.view(np.int32))
+    Dh = D.cpu().numpy()
+    del S, F, D
+    # combined map rows: oracle combine on the sampled rows only (row-sliced inputs)
+    rc, picks = oracle.greedy(Dh, [], first, box, 0.12, 0.0, float(BUDGET))
+    return bool(ok and rc == 0 and picks.tolist() == list(selected))
 
 
 if __name__ == "__main__":
