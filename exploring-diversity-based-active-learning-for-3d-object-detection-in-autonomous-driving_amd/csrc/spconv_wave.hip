@@ -1,0 +1,202 @@
+// Sparse convolution, wave-autonomous gather + bf16x6 MFMA (gfx950).
+//
+// sp_conv_bf16x6_kernel stages the gathered input rows through LDS like a dense GEMM tile; for
+// the sparse layers that costs an LDS write + barrier per (offset, 16-channel) step whose MFMA
+// work is tiny at 16..64 channels.  Here each wave owns 32 output rows and ALL output channels:
+// its A operand never touches LDS -- every lane loads the 8 consecutive channels its MFMA
+// fragment needs straight from the gathered feature row, splits them into the three bf16 pieces
+// in registers and issues the six partial-product MFMAs per output tile.  Only the (pre-split)
+// weights go through LDS, in slabs of several (offset, channel-group) units shared by the four
+// waves of the workgroup, double-buffered, one barrier per slab.  Waves skip the offsets that
+// are empty for their own 32 rows and otherwise run unsynchronised, so gather latency is hidden
+// by the other waves on the SIMD instead of by a software pipeline.
+#include "al3d_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define SW_ROWS 128                 // rows per workgroup (4 waves x 32)
+#define SW_PITCH 48                 // bytes per LDS weight row: 16 bf16 + 16 B pad
+
+__device__ __forceinline__ void sw_split8(const float4& lo, const float4& hi, bf16x8& p0, bf16x8& p1, bf16x8& p2)
+{
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 a = (__bf16)v[e];
+        const float r1 = v[e] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const float r2 = r1 - (float)b;
+        p0[e] = a; p1[e] = b; p2[e] = (__bf16)r2;
+    }
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restrict__ fin,
+                                                           const int* __restrict__ nbr, int K,
+                                                           const __bf16* __restrict__ wgt,   // [3][COUT][K][CIN]
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ residual, int relu,
+                                                           float* __restrict__ fout, int n_out)
+{
+    constexpr int KG = CIN / 16;                         // 16-channel groups per offset
+    constexpr int TN = (COUT + 31) / 32;                 // 32-wide output tiles per wave
+    constexpr int NROWS = COUT;                          // weight rows per unit
+    constexpr int UNIT_BYTES = 3 * NROWS * SW_PITCH;
+    constexpr int UPS_RAW = (14 * 1024) / UNIT_BYTES;    // units per slab (small slabs -> more workgroups per CU)
+    constexpr int UPS = UPS_RAW < 1 ? 1 : (UPS_RAW > 16 ? 16 : UPS_RAW);
+    constexpr int SLAB_PIECES = UPS * 3 * NROWS * 2;     // 16-byte pieces per slab
+    constexpr int PASSES = (SLAB_PIECES + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char Ws[2][UPS * UNIT_BYTES + 64];
+    __shared__ __attribute__((aligned(16))) unsigned char zrow[64];   // zero fragment for n >= COUT
+    __shared__ unsigned s_mask;
+    __shared__ int s_taps[32];
+    __shared__ int s_ntaps;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int row0 = blockIdx.x * SW_ROWS;
+    const int my_row = row0 + wave * 32 + fr;
+    const int64_t plane = (int64_t)COUT * K * CIN;
+
+    if (tid < 16) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
+    if (tid == 0) s_mask = 0u;
+    __syncthreads();
+    // offsets with a neighbour in this wave's rows (wmask) / anywhere in the workgroup (s_mask)
+    unsigned wmask = 0u;
+    for (int k0 = 0; k0 < K; k0 += 2) {
+        const int k = k0 + fh;
+        const bool v = k < K && my_row < n_out && nbr[(int64_t)k * n_out + my_row] >= 0;
+        const unsigned long long bal = __ballot(v);
+        if (bal & 0xffffffffull) wmask |= 1u << k0;
+        if (bal >> 32) wmask |= 1u << (k0 + 1);
+    }
+    wmask = __builtin_amdgcn_readfirstlane(wmask);
+    if (lane == 0 && wmask) atomicOr(&s_mask, wmask);
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        const unsigned m = s_mask;
+        for (int k = 0; k < K; ++k) if (m >> k & 1u) s_taps[c++] = k;
+        s_ntaps = c;
+    }
+    __syncthreads();
+    const int nunits = s_ntaps * KG;
+    const int nslabs = (nunits + UPS - 1) / UPS;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- weight slab staging (all 256 threads): piece -> (unit, plane, n, half)
+    uint4 rw[PASSES];
+    auto load_slab = [&](int slab) {
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const int piece = tid + 256 * q;
+            const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
+            const int uu = (piece >> 1) / (NROWS * 3);
+            const int unit = slab * UPS + uu;
+            if (piece < SLAB_PIECES && unit < nunits) {
+                const int tap = s_taps[unit / KG], g = unit % KG;
+                rw[q] = *reinterpret_cast<const uint4*>(wgt + pl * plane + ((int64_t)n * K + tap) * CIN + 16 * g + 8 * half);
+            } else rw[q] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const int piece = tid + 256 * q;
+            if (piece >= SLAB_PIECES) continue;
+            const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
+            const int uu = (piece >> 1) / (NROWS * 3);
+            *reinterpret_cast<uint4*>(&Ws[buf][uu * UNIT_BYTES + (pl * NROWS + n) * SW_PITCH + 16 * half]) = rw[q];
+        }
+    };
+
+    if (nslabs > 0) { load_slab(0); store_slab(0); }
+    __syncthreads();
+    for (int slab = 0; slab < nslabs; ++slab) {
+        const int buf = slab & 1;
+        if (slab + 1 < nslabs) load_slab(slab + 1);
+        // ---- this wave walks the units of the slab on its own
+        const int u0 = slab * UPS, u1 = (u0 + UPS < nunits) ? u0 + UPS : nunits;
+        int cur_tap = -1, src = -1;
+        for (int unit = u0; unit < u1; ++unit) {
+            const int tap = s_taps[unit / KG], g = unit % KG;
+            if (!(wmask >> tap & 1u)) continue;                       // wave-uniform
+            if (tap != cur_tap) {
+                cur_tap = tap;
+                src = my_row < n_out ? nbr[(int64_t)tap * n_out + my_row] : -1;
+            }
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (src >= 0) {
+                const float* rp = fin + (int64_t)src * CIN + 16 * g + 8 * fh;
+                lo = *reinterpret_cast<const float4*>(rp);
+                hi = *reinterpret_cast<const float4*>(rp + 4);
+            }
+            bf16x8 a0, a1, a2;
+            sw_split8(lo, hi, a0, a1, a2);
+            const unsigned char* ub = &Ws[buf][(unit - u0) * UNIT_BYTES];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = j * 32 + fr;
+                const bool live = n < COUT;
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(live ? ub + (0 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(live ? ub + (1 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(live ? ub + (2 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+            }
+        }
+        if (slab + 1 < nslabs) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = j * 32 + fr;
+        if (n >= COUT) continue;
+        const float sc = scale ? scale[n] : 1.0f;
+        const float sh = shift ? shift[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (row >= n_out) continue;
+            float v = acc[j][r] * sc + sh;
+            if (residual) v += residual[(int64_t)row * COUT + n];
+            if (relu) v = v > 0.f ? v : 0.f;
+            fout[(int64_t)row * COUT + n] = v;
+        }
+    }
+}
+
+#define SW_DISPATCH(CI, CO)                                                                           \
+    if (cin == CI && cout == CO) {                                                                    \
+        hipLaunchKernelGGL((sp_conv_wave_kernel<CI, CO>), dim3((unsigned)al3d_cdiv(n_out, SW_ROWS)),   \
+                           dim3(256), 0, s, fin, nbr, K, (const __bf16*)wgt_bf16x3, scale, shift,     \
+                           residual, relu, fout, n_out);                                              \
+        AL3D_CHECK_LAUNCH("sp_conv_wave_kernel");                                                     \
+        return AL3D_OK;                                                                               \
+    }
+
+extern "C" int al3d_sp_conv_wave_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3,
+                                        int cin, int cout, const float* scale, const float* shift,
+                                        const float* residual, int relu, float* fout, int n_out,
+                                        void* stream)
+{
+    AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_wave_bf16x6: bad sizes");
+    if (n_out == 0) return AL3D_OK;
+    AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave_bf16x6: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    SW_DISPATCH(16, 16) SW_DISPATCH(16, 32) SW_DISPATCH(32, 32) SW_DISPATCH(32, 64) SW_DISPATCH(64, 64)
+    SW_DISPATCH(64, 128) SW_DISPATCH(128, 128)
+    return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave_bf16x6: unsupported channel pair %d -> %d", cin, cout);
+}

@@ -46,6 +46,9 @@ def split_bf16x3(w_packed):
 # matrix cores (default), "f32" = fp32-input MFMA (bitwise an fp32 FMA chain).
 import os as _os
 MATH = _os.environ.get("AL3D_MATH", "bf16x6")
+# sparse-conv structure for the bf16x6 arithmetic: "wave" (A operand in registers, wave-autonomous)
+# or "tile" (LDS-staged 128-row tile); "auto" picks per layer
+SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
 
 
 # ------------------------------------------------------------------ kernels
@@ -199,9 +202,9 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     if mfma is None:
         mfma = (cin, cout) in MFMA_PAIRS and (MATH if MATH == "bf16x6" else True)
-    if mfma == "bf16x6":
+    if mfma in ("bf16x6", "wave"):
         w6 = split_bf16x3(w.permute(2, 0, 1).contiguous())
-        lib.call("al3d_sp_conv_bf16x6", _ptr(feats), _ptr(nbr), K, _ptr(w6), cin, cout, _ptr(scale),
+        lib.call("al3d_sp_conv_wave_bf16x6" if mfma == "wave" else "al3d_sp_conv_bf16x6", _ptr(feats), _ptr(nbr), K, _ptr(w6), cin, cout, _ptr(scale),
                  _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
     elif mfma:
         w_ock = w.permute(2, 0, 1).contiguous()          # [Cout, K, Cin]

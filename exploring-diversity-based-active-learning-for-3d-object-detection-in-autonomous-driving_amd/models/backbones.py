@@ -137,7 +137,13 @@ class _SparseEncoderBase(nn.Module):
     @staticmethod
     def _conv(m, feats, nbr, K, step, residual, out, n, st):
         if (m.in_channels, m.out_channels) in MFMA_PAIRS:
-            fn = "al3d_sp_conv_bf16x6" if step["w"].dtype == torch.bfloat16 else "al3d_sp_conv_mfma_f32"
+            if step["w"].dtype == torch.bfloat16:
+                # measured per channel pair (profiles/): the wave-autonomous kernel wins up to 64
+                # output channels, the LDS-staged tile kernel at 128
+                wave = D.SPCONV == "wave" or (D.SPCONV == "auto" and m.out_channels <= 64)
+                fn = "al3d_sp_conv_wave_bf16x6" if wave else "al3d_sp_conv_bf16x6"
+            else:
+                fn = "al3d_sp_conv_mfma_f32"
         else:
             fn = "al3d_sp_conv_f32"
         lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,

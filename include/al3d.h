@@ -234,6 +234,13 @@ int al3d_sp_conv_mfma_f32(const float* fin, const int* nbr, int K, const float* 
 int al3d_sp_conv_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                         int cout, const float* scale, const float* shift, const float* residual,
                         int relu, float* fout, int n_out, void* stream);
+/* Same arithmetic and weight packing as al3d_sp_conv_bf16x6, different structure: each wave owns
+ * 32 output rows and all output channels, the gathered rows go straight into its MFMA fragments
+ * (no LDS staging of activations), only weight slabs are shared through LDS.  The encoder's
+ * default for the bf16x6 arithmetic. */
+int al3d_sp_conv_wave_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
+                             int cout, const float* scale, const float* shift, const float* residual,
+                             int relu, float* fout, int n_out, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
  * out must be zero-filled. */
 int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D, int H,
