@@ -354,6 +354,25 @@ extern "C" int al3d_split_bf16x3(const float* w, int64_t count, void* out_bf16x3
     return AL3D_OK;
 }
 
+// inverse of the split: f32 = (x1 + x2) + x3, exact
+__global__ void merge_planes_kernel(const __bf16* __restrict__ pl, int64_t count, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    out[i] = ((float)pl[i] + (float)pl[count + i]) + (float)pl[2 * count + i];
+}
+
+extern "C" int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void* stream)
+{
+    AL3D_REQUIRE(count >= 0, "al3d_merge_bf16x3: bad count");
+    if (count == 0) return AL3D_OK;
+    AL3D_REQUIRE(planes_bf16x3 && out, "al3d_merge_bf16x3: null pointer");
+    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)planes_bf16x3, count, out);
+    AL3D_CHECK_LAUNCH("merge_planes_kernel");
+    return AL3D_OK;
+}
+
 static int conv6_check(const Conv6Params& p, const char* name)
 {
     AL3D_REQUIRE(p.in && p.wgt && p.out, "%s: null pointer", name);

@@ -49,6 +49,7 @@ MATH = _os.environ.get("AL3D_MATH", "bf16x6")
 # sparse-conv structure for the bf16x6 arithmetic: "wave" (A operand in registers, wave-autonomous)
 # or "tile" (LDS-staged 128-row tile); "auto" picks per layer
 SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
+SP_PLANES = _os.environ.get("AL3D_SP_PLANES", "0") == "1"
 
 
 # ------------------------------------------------------------------ kernels
@@ -205,7 +206,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
     if mfma in ("bf16x6", "wave"):
         w6 = split_bf16x3(w.permute(2, 0, 1).contiguous())
         lib.call("al3d_sp_conv_wave_bf16x6" if mfma == "wave" else "al3d_sp_conv_bf16x6", _ptr(feats), _ptr(nbr), K, _ptr(w6), cin, cout, _ptr(scale),
-                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, n, 0, st)
     elif mfma:
         w_ock = w.permute(2, 0, 1).contiguous()          # [Cout, K, Cin]
         lib.call("al3d_sp_conv_mfma_f32", _ptr(feats), _ptr(nbr), K, _ptr(w_ock), cin, cout, _ptr(scale),

@@ -61,11 +61,27 @@ class SparseBasicBlock(nn.Module):
 
 
 class SparseTensor:
-    """Minimal stand-in for spconv.SparseConvTensor: features [N,C], indices [N,4] i32."""
+    """Minimal stand-in for spconv.SparseConvTensor: features [N,C] f32, indices [N,4] i32.
+    Inside the encoder features may be held pre-split (bf16 planes [3,N,C]); ``features``
+    merges them back (exactly) on first access."""
 
     def __init__(self, features, indices, spatial_shape, batch_size):
-        self.features, self.indices = features, indices
+        self._f = features
+        self.indices = indices
         self.spatial_shape, self.batch_size = list(spatial_shape), batch_size
+
+    @property
+    def features(self):
+        if self._f.dtype == torch.bfloat16:
+            pl = self._f.contiguous()
+            out = torch.empty(pl.shape[1:], dtype=torch.float32, device=pl.device)
+            lib.call("al3d_merge_bf16x3", _ptr(pl), out.numel(), _ptr(out), _stream())
+            self._f = out
+        return self._f
+
+    @features.setter
+    def features(self, v):
+        self._f = v
 
 
 def _bn(c):
@@ -136,6 +152,29 @@ class _SparseEncoderBase(nn.Module):
 
     @staticmethod
     def _conv(m, feats, nbr, K, step, residual, out, n, st):
+        """One fused sparse layer.  Tensors of dtype bfloat16 are pre-split planes [3,n,C]."""
+        fmt = 0
+        n_in = feats.shape[-2]
+        if feats.dtype == torch.bfloat16:
+            fmt |= 1
+        if out.dtype == torch.bfloat16:
+            fmt |= 2
+        if residual is not None and residual.dtype == torch.bfloat16:
+            fmt |= 4
+        res_ptr = None if residual is None else _ptr(residual)
+        if fmt:
+            wave = D.SPCONV == "wave" or (D.SPCONV == "auto" and m.out_channels <= 64)
+            fn = "al3d_sp_conv_wave_bf16x6" if wave else "al3d_sp_conv_bf16x6"
+            lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
+                     _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, n_in, fmt, st)
+            return
+        if (m.in_channels, m.out_channels) in MFMA_PAIRS and step["w"].dtype == torch.bfloat16:
+            wave = D.SPCONV == "wave" or (D.SPCONV == "auto" and m.out_channels <= 64)
+            fn = "al3d_sp_conv_wave_bf16x6" if wave else "al3d_sp_conv_bf16x6"
+            lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
+                     _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, n_in, 0, st)
+            return
+        residual = res_ptr
         if (m.in_channels, m.out_channels) in MFMA_PAIRS:
             if step["w"].dtype == torch.bfloat16:
                 # measured per channel pair (profiles/): the wave-autonomous kernel wins up to 64
@@ -179,6 +218,26 @@ class _SparseEncoderBase(nn.Module):
         nbr, nbr_key = None, None
         middle = []
         identity = None
+        # Optional: keep activations pre-split (bf16 planes) between sparse layers so the split
+        # happens once per element instead of once per gather.  Measured SLOWER on MI355X (2-byte
+        # plane stores in the epilogue + 1.5x gather bytes: 764 vs 848 frames/s), so it is off
+        # unless AL3D_SP_PLANES=1; the last layer always writes f32 for dense().
+        planes = D.MATH == "bf16x6" and D.SP_PLANES
+        convs = [s_ for s_ in self._plan if s_["kind"] != "stage_end"]
+        last = convs[-1]
+
+        def new_out(rows, m, step):
+            ok = planes and step is not last and (m.in_channels, m.out_channels) in MFMA_PAIRS
+            if ok:
+                return torch.empty((3, rows, m.out_channels), dtype=torch.bfloat16, device=dev)
+            return torch.empty((rows, m.out_channels), dtype=torch.float32, device=dev)
+
+        def as_input(t, m):
+            """f32 rows feeding an MFMA layer in planes mode are split once here (first layer)."""
+            if planes and t.dtype != torch.bfloat16 and (m.in_channels, m.out_channels) in MFMA_PAIRS:
+                return D.split_bf16x3(t)
+            return t
+
         for step in self._plan:
             if step["kind"] == "stage_end":
                 middle.append(SparseTensor(feats, coords, shape, batch_size))
@@ -192,10 +251,11 @@ class _SparseEncoderBase(nn.Module):
                     lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
                              _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
                     nbr_key = key
+                feats = as_input(feats, m)
                 if step.get("block_start"):
                     identity = feats
-                out = torch.empty((n, m.out_channels), dtype=torch.float32, device=dev)
-                self._conv(m, feats, nbr, K, step, _ptr(identity) if step["residual"] else None, out, n, st)
+                out = new_out(n, m, step)
+                self._conv(m, feats, nbr, K, step, identity if step["residual"] else None, out, n, st)
                 feats = out
             else:
                 oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
@@ -214,7 +274,8 @@ class _SparseEncoderBase(nn.Module):
                 dnbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
                 lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
                          lv.W, _ptr(lv.grid), _ptr(dnbr), st)
-                out = torch.empty((n_out, m.out_channels), dtype=torch.float32, device=dev)
+                feats = as_input(feats, m)
+                out = new_out(n_out, m, step)
                 self._conv(m, feats, dnbr, K, step, None, out, n_out, st)
                 feats, coords, n, shape, lv = out, ocoords, n_out, oshape, olv
                 nbr_key = None

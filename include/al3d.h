@@ -230,17 +230,27 @@ int al3d_sp_conv_mfma_f32(const float* fin, const int* nbr, int K, const float* 
                           int cout, const float* scale, const float* shift, const float* residual,
                           int relu, float* fout, int n_out, void* stream);
 /* fp32-faithful bf16x6 variant (see al3d_conv2d_nhwc_bf16x6): weights = al3d_split_bf16x3 of
- * the [Cout, K, Cin] packing; same channel pairs as the fp32-MFMA entry point plus 16->16. */
+ * the [Cout, K, Cin] packing; same channel pairs as the fp32-MFMA entry point plus 16->16.
+ * Feature formats (`fmt` bits): activations may stay pre-split between sparse layers -- bf16
+ * planes [3][n][C] (hi, mid, lo; x = (x1+x2)+x3 exactly) instead of f32 [n][C] -- so the split is
+ * done once by the producing layer's epilogue instead of once per (row, offset) gather.
+ * bit0: fin is planes [3][n_in][cin]; bit1: fout is planes [3][n_out][cout]; bit2: residual is
+ * planes [3][n_out][cout].  fmt = 0 is plain f32 everywhere. */
+#define AL3D_FMT_IN_PLANES 1
+#define AL3D_FMT_OUT_PLANES 2
+#define AL3D_FMT_RES_PLANES 4
 int al3d_sp_conv_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                         int cout, const float* scale, const float* shift, const float* residual,
-                        int relu, float* fout, int n_out, void* stream);
+                        int relu, float* fout, int n_out, int n_in, int fmt, void* stream);
+/* planes [3][count] bf16 -> f32 [count], exact (inverse of al3d_split_bf16x3) */
+int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void* stream);
 /* Same arithmetic and weight packing as al3d_sp_conv_bf16x6, different structure: each wave owns
  * 32 output rows and all output channels, the gathered rows go straight into its MFMA fragments
  * (no LDS staging of activations), only weight slabs are shared through LDS.  The encoder's
  * default for the bf16x6 arithmetic. */
 int al3d_sp_conv_wave_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                              int cout, const float* scale, const float* shift, const float* residual,
-                             int relu, float* fout, int n_out, void* stream);
+                             int relu, float* fout, int n_out, int n_in, int fmt, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
  * out must be zero-filled. */
 int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D, int H,
