@@ -149,3 +149,62 @@ extern "C" int al3d_argsort_desc_f32(const float* x, int64_t n, int64_t* out_idx
     AL3D_CHECK_LAUNCH("argsort_desc_kernel");
     return AL3D_OK;
 }
+
+// PPAL (det3d/selectors/ppal_selector.py:99-109): class-weighted entropy SUM per frame,
+// weight looked up by the merged label id.  Empty frame -> 0 (sum of an empty tensor).
+__global__ __launch_bounds__(64) void frame_weighted_entropy_kernel(const float* __restrict__ scores,
+                                                                    const int* __restrict__ labels,
+                                                                    const int* __restrict__ counts, int nt,
+                                                                    int post, const float* __restrict__ cw,
+                                                                    int ncls, float* __restrict__ out)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float sum = 0.f;
+    for (int t = 0; t < nt; ++t) {
+        const int c = counts[b * nt + t];
+        for (int i = lane; i < c; i += 64) {
+            const int64_t o = ((int64_t)b * nt + t) * post + i;
+            const float s = scores[o];
+            const int l = labels[o];
+            const float w = (l >= 0 && l < ncls) ? cw[l] : 0.f;
+            sum += (-s * logf(s) - (1.0f - s) * logf(1.0f - s)) * w;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) out[b] = sum;
+}
+
+extern "C" int al3d_frame_weighted_entropy_f32(const float* scores, const int* labels, const int* counts,
+                                               int B, int nt, int post, const float* class_weight,
+                                               int ncls, float* out, void* stream)
+{
+    AL3D_REQUIRE(B >= 0 && nt >= 1 && post >= 1 && ncls >= 1, "al3d_frame_weighted_entropy_f32: bad sizes");
+    if (B == 0) return AL3D_OK;
+    AL3D_REQUIRE(scores && labels && counts && class_weight && out, "al3d_frame_weighted_entropy_f32: null pointer");
+    hipLaunchKernelGGL(frame_weighted_entropy_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, scores,
+                       labels, counts, nt, post, class_weight, ncls, out);
+    AL3D_CHECK_LAUNCH("frame_weighted_entropy_kernel");
+    return AL3D_OK;
+}
+
+// PPAL pool restriction (ppal_selector.py:194-196): rows and columns of frames outside the
+// candidate pool become -inf so the greedy can never reach them.
+__global__ void mask_map_kernel(float* __restrict__ D, int64_t n, const unsigned char* __restrict__ keep)
+{
+    const int64_t i = blockIdx.y;
+    const bool ki = keep[i] != 0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        if (!ki || !keep[j]) D[i * n + j] = -__builtin_inff();
+}
+
+extern "C" int al3d_mask_map_f32(float* D, int64_t n, const unsigned char* keep, void* stream)
+{
+    AL3D_REQUIRE(n >= 0 && n < (1LL << 31), "al3d_mask_map_f32: bad n");
+    if (n == 0) return AL3D_OK;
+    AL3D_REQUIRE(D && keep, "al3d_mask_map_f32: null pointer");
+    unsigned gx = (unsigned)al3d_cdiv(n, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(mask_map_kernel, dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, D, n, keep);
+    AL3D_CHECK_LAUNCH("mask_map_kernel");
+    return AL3D_OK;
+}

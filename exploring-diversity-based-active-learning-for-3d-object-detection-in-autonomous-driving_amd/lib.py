@@ -37,6 +37,8 @@ SIGNATURES = {
     "al3d_greedy_kcenter_f32": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_dbl, c_dbl,
                                         c_dbl, c_int, c_p, c_i64, c_p, c_p, c_p]),
     "al3d_frame_entropy_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_frame_weighted_entropy_f32": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_int, c_p, c_p]),
+    "al3d_mask_map_f32": (c_int, [c_p, c_i64, c_p, c_p]),
     "al3d_scale_rows_f32": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p, c_p]),
     "al3d_minmax_norm_f32": (c_int, [c_p, c_i64, c_p, c_p]),
     "al3d_argsort_workspace_bytes": (c_i64, [c_i64]),

@@ -50,6 +50,13 @@ class LazyDetections:
         torch.cuda.current_stream(boxes.device).wait_event(done)
         return ops.frame_entropy(scores, counts)
 
+    def frame_weighted_entropy(self, class_weight):
+        """[B] sum over kept boxes of entropy * class_weight[label] (PPAL, ppal_selector.py:99-109)."""
+        from .. import selector_ops as ops
+        boxes, scores, labels, counts, done, meta = self._raw
+        torch.cuda.current_stream(boxes.device).wait_event(done)
+        return ops.frame_weighted_entropy(scores, labels, counts, class_weight)
+
     def __len__(self):
         return self._raw[3].shape[0]
 

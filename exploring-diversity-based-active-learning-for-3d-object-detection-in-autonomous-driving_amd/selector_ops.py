@@ -125,6 +125,26 @@ def frame_entropy(scores, counts):
     return out
 
 
+def frame_weighted_entropy(scores, labels, counts, class_weight):
+    scores = _dev(scores, torch.float32, "scores")
+    labels = _dev(labels, torch.int32, "labels")
+    counts = _dev(counts, torch.int32, "counts")
+    cw = _dev(class_weight, torch.float32, "class_weight")
+    B, nt, post = scores.shape
+    out = torch.empty((B,), dtype=torch.float32, device=scores.device)
+    lib.call("al3d_frame_weighted_entropy_f32", _ptr(scores), _ptr(labels), _ptr(counts), B, nt, post,
+             _ptr(cw), cw.numel(), _ptr(out), _stream())
+    return out
+
+
+def mask_map_(D, keep):
+    """In place: D[i,j] = -inf unless keep[i] and keep[j] (keep: uint8 [n])."""
+    D = _dev(D, torch.float32, "D")
+    keep = _dev(keep, torch.uint8, "keep")
+    lib.call("al3d_mask_map_f32", _ptr(D), D.shape[0], _ptr(keep), _stream())
+    return D
+
+
 def scale_rows(feats, w, widx=None):
     feats = _dev(feats, torch.float32, "feats")
     w = _dev(w, torch.float32, "w")

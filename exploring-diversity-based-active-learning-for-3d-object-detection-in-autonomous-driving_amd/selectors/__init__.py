@@ -9,9 +9,9 @@ from .map_selectors import (SpatialSelector, TemporalSelector, EuSpatialSelector
 from .feature_selectors import (FeatureSelector, SpatialFeatureSelector,
                                 SpatialTemporalFeatureSelector)
 
-from .uncertainty_selectors import EntropySelector, BadgeSelector, UWESelector
+from .uncertainty_selectors import EntropySelector, BadgeSelector, UWESelector, PPALSelector
 
-__all__ = ["EntropySelector", "BadgeSelector", "UWESelector","BaseSelector", "RandomSelector", "SpatialSelector", "EuSpatialSelector",
+__all__ = ["EntropySelector", "BadgeSelector", "UWESelector", "PPALSelector","BaseSelector", "RandomSelector", "SpatialSelector", "EuSpatialSelector",
            "TemporalSelector", "SpatialTemporalSelector", "FeatureSelector",
            "SpatialFeatureSelector", "SpatialTemporalFeatureSelector",
            "SELECTORS", "build_selector"]

@@ -199,3 +199,109 @@ class UWESelector(_WeightedFeatureSelector):
             torch.save(prediction.cpu(), self.weighted_feat_path)
         self.detector = None
         return prediction
+
+
+@SELECTORS.register_module
+class PPALSelector(_WeightedFeatureSelector):
+    """Two-stage PPAL (ppal_selector.py:18-239): a class-weighted-entropy ranking picks a
+    candidate pool worth ``delta`` times the budget, then the greedy k-center runs on the L1
+    embedding map restricted to (pool + labelled) frames."""
+
+    def __init__(
+            self,
+            budget: int,
+            buffer_file: str,
+            dump_file_name: Optional[str] = None,
+            infos_origin: List[Dict] = [],
+            ent_path: str = "/home/st2000/data/buffers/ppal_ent.pt",
+            feat_path: str = "/home/st2000/data/buffers/ppal_feat.pt",
+            distance_store_file: str = "/home/st2000/data/buffers/ppal_distance_map.npy",
+            class_weight_file: str = "tools/diff_category_average.json",
+            p: int = 2,
+            detector: Optional[torch.nn.Module] = None,
+            dataloader=None,
+            logger: Optional[logging.Logger] = None,
+            pred: bool = True,
+            cost_b: float = 0.04,
+            cost_f: float = 0.12,
+            delta: int = 4,
+    ) -> None:
+        super().__init__(budget, buffer_file, dump_file_name, infos_origin=infos_origin,
+                         detector=detector, dataloader=dataloader, logger=logger, pred=pred,
+                         cost_b=cost_b, cost_f=cost_f)
+        self._init_common(feat_path, distance_store_file, p)
+        self.ent_path = ent_path
+        self.feat_path = feat_path
+        self.class_weight_file = class_weight_file
+        self.delta = delta
+
+    def buffer_pred(self, sampled_index_list=None, left_index_list=None, **kwargs):
+        import json
+        from ..sweep import example_to_device, gap_embedding, gather_in_dataset_order
+        device = self._device(kwargs)
+        with open(self.class_weight_file, "r") as f:
+            class_weight = json.load(f)
+        names = [c for group in self.detector.bbox_head.class_names for c in group]
+        cw = torch.tensor([class_weight[c] for c in names], dtype=torch.float32, device=device)
+        ents, feats, index, seen = [], [], [], 0
+        sampler = list(getattr(self.dataloader, "sampler", []) or [])
+        with torch.no_grad():
+            for batch in self.dataloader:
+                example = example_to_device(batch, device)
+                preds, middle = self.detector(example, return_loss=False, estimate=True)
+                emb = gap_embedding(middle[-1])
+                ents.append(preds.frame_weighted_entropy(cw))
+                feats.append(emb)
+                b = emb.shape[0]
+                index.extend(sampler[seen:seen + b] if sampler else range(seen, seen + b))
+                seen += b
+        n = len(self.infos_origin)
+        idx = torch.as_tensor(index, dtype=torch.int64, device=device)
+        feat_pred = gather_in_dataset_order(torch.cat(feats), idx, n)
+        entropy_pred = gather_in_dataset_order(torch.cat(ents).unsqueeze(1), idx, n).squeeze(1)
+        if _rank() == 0:
+            if self.feat_path:
+                torch.save(feat_pred.cpu(), self.feat_path)
+            if self.ent_path:
+                torch.save(entropy_pred.cpu(), self.ent_path)
+        self.detector = None
+        return entropy_pred, feat_pred
+
+    def select_samples(self, **kwargs) -> None:
+        from .. import selector_ops as ops
+        device = self._device(kwargs)
+        n = len(self.infos_origin)
+        sampled = list(self.buffer[self.get_max_key()])
+        left = list(range(n))
+        for x in sampled:
+            left.remove(x)
+        if self.pred:
+            ents, feats = self.buffer_pred(sampled_index_list=sampled, left_index_list=left, **kwargs)
+        else:
+            ents = torch.load(self.ent_path, weights_only=True)
+            feats = torch.load(self.feat_path, weights_only=True)
+        ents = ents.to(device=device, dtype=torch.float32)
+        feats = feats.to(device=device, dtype=torch.float32)
+        distance_map = self.get_feature_distance_map(feats).clone()
+        # stage 1: entropy-ranked candidate pool under the expanded budget (ppal_selector.py:169-189)
+        order = ops.argsort_desc(ents[torch.as_tensor(left, device=device)].contiguous()).tolist()
+        pool = [left[order[0]]]
+        cost = self.get_cost_amount()
+        cost += self.cost_f
+        cost += self.infos_origin[order[0]]["gt_names"].shape[0] * self.cost_b      # quirk A.1 #7
+        limit = int(self.current_budget) + self.budget * (self.delta - 1)
+        sort_id = 1
+        while True:
+            idx = left[order[sort_id]]
+            sort_id += 1
+            assert idx not in pool, f"id: {idx} has been selected"
+            cost += self.cost_f
+            cost += self.infos_origin[idx]["gt_names"].shape[0] * self.cost_b
+            if cost > limit:
+                break
+            pool.append(idx)
+        # stage 2: greedy k-center restricted to pool + labelled frames (:191-236)
+        keep = torch.zeros(n, dtype=torch.uint8, device=device)
+        keep[torch.as_tensor(pool + sampled, device=device)] = 1
+        ops.mask_map_(distance_map, keep)
+        self._greedy(distance_map, device, order="selected+sampled")

@@ -105,6 +105,13 @@ int al3d_greedy_kcenter_f32(const float* D, const float* seed_map, int64_t n,
  * Replaces det3d/selectors/entropy_selector.py:72-75 (same lines in badge/uwe selectors). */
 int al3d_frame_entropy_f32(const float* scores, const int* counts, int B, int nt, int post,
                            float* out, void* stream);
+/* PPAL: sum over a frame's kept boxes of entropy * class_weight[label] (labels [B,nt,post] i32,
+ * class_weight [ncls] f32); empty frame -> 0.  Replaces det3d/selectors/ppal_selector.py:99-109. */
+int al3d_frame_weighted_entropy_f32(const float* scores, const int* labels, const int* counts, int B,
+                                    int nt, int post, const float* class_weight, int ncls, float* out,
+                                    void* stream);
+/* PPAL pool restriction: D[i,j] = -inf unless keep[i] && keep[j] (ppal_selector.py:194-196) */
+int al3d_mask_map_f32(float* D, int64_t n, const unsigned char* keep, void* stream);
 /* out[i,:] = feats[i,:] * w[widx ? widx[i] : i]  (badge_selector.py:75-78, uwe_selector.py:96-99) */
 int al3d_scale_rows_f32(const float* feats, const float* w, const int64_t* widx, int64_t n, int c,
                         float* out, void* stream);

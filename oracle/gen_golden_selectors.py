@@ -91,12 +91,18 @@ def run_case(name, cls_name, module, infos, logs, buffer, budget, kwargs=None,
             fp = os.path.join(td, "wfeats.pt")
             torch.save(torch.from_numpy(feats), fp)
             ctor["weighted_feat_path"] = fp
+        if cls_name == "PPALSelector":
+            fp = os.path.join(td, "pfeats.pt")
+            torch.save(torch.from_numpy(feats), fp)
+            ep = os.path.join(td, "pent.pt")
+            torch.save(torch.from_numpy(entropy), ep)
+            ctor.update(feat_path=fp, ent_path=ep, class_weight_file=os.path.join(td, "cw.json"))
         if cls_name == "EntropySelector":
             fp = os.path.join(td, "entropy.pt")
             torch.save(torch.from_numpy(entropy), fp)
             ctor["buffer_path"] = fp
         if cls_name not in ("FeatureSelector", "TemporalSelector", "RandomSelector", "EntropySelector",
-                            "BadgeSelector", "UWESelector"):
+                            "BadgeSelector", "UWESelector", "PPALSelector"):
             ctor["logs_file"] = logs_p
         if cls_name not in ("TemporalSelector", "RandomSelector", "EntropySelector"):
             ctor["distance_store_file"] = os.path.join(td, "dist.npy")
@@ -229,6 +235,11 @@ def main():
              kwargs=dict(p=2), feats_seed=5)
     run_case("uwe_seeded", "UWESelector", "uwe_selector", small, small_logs, seeded, 30,
              kwargs=dict(p=1), feats_seed=7)
+    ent_sum = rng.uniform(0.5, 30.0, size=len(small)).astype(np.float32)     # PPAL: weighted entropy sums
+    run_case("ppal_seeded", "PPALSelector", "ppal_selector", small, small_logs, seeded, 15,
+             kwargs=dict(p=2, delta=4), feats_seed=8, entropy=ent_sum)
+    run_case("ppal_delta2", "PPALSelector", "ppal_selector", small, small_logs, seeded, 20,
+             kwargs=dict(p=1, delta=2), feats_seed=8, entropy=ent_sum)
     SF = ("SpatialFeatureSelector", "spatial_feature_selector")
     run_case("sf_seeded", *SF, small, small_logs, seeded, 30, feats_seed=5, capture=True)
 

@@ -115,6 +115,34 @@ def run_case(fx, backend, feats=None, maps_out=None):
                 break
             picks.append(idx)
         return 0, picks + sampled
+    elif cls == "PPALSelector":
+        # ppal_selector.py:146-239: entropy-ranked pool under delta x budget, then greedy on the
+        # L1 map with every row/column outside pool + labelled set to -inf
+        left = [i for i in range(n) if i not in sampled]
+        ent = np.asarray(fx["entropy"], dtype=np.float32)[left]
+        srt = [int(v) for v in backend.argsort_desc(ent)]
+        pool = [left[srt[0]]]
+        cost = start_cost
+        cost += cost_f
+        cost += int(fx["n_boxes"][srt[0]]) * cost_b
+        limit = budget_int + fx["budget"] * (kw.get("delta", 4) - 1)
+        sid = 1
+        while True:
+            idx = left[srt[sid]]
+            sid += 1
+            cost += cost_f
+            cost += int(fx["n_boxes"][idx]) * cost_b
+            if cost > limit:
+                break
+            pool.append(idx)
+        D = np.array(backend.l1_map_f32(feats, kw.get("p", 2)), dtype=np.float32, copy=True)
+        keep = np.zeros(n, dtype=bool)
+        keep[pool + sampled] = True
+        D[~keep] = -np.inf
+        D[:, ~keep] = -np.inf
+        order = "selected+sampled"
+        if maps_out is not None:
+            maps_out.update(distance_map=D)
     elif cls in ("FeatureSelector", "BadgeSelector", "UWESelector"):
         D = backend.l1_map_f32(feats, kw.get("p", 2))
         order = "selected+sampled"

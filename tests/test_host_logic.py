@@ -39,7 +39,7 @@ def test_selector_and_model_registries_carry_reference_names():
     for name in ("BaseSelector", "RandomSelector", "SpatialSelector", "TemporalSelector",
                  "EuSpatialSelector", "SpatialTemporalSelector", "FeatureSelector",
                  "SpatialFeatureSelector", "SpatialTemporalFeatureSelector", "EntropySelector",
-                 "BadgeSelector", "UWESelector"):
+                 "BadgeSelector", "UWESelector", "PPALSelector"):
         assert SELECTORS.get(name) is not None, name
     assert DETECTORS.get("FPNVoxelNet") and DETECTORS.get("VoxelNet")
     assert READERS.get("VoxelFeatureExtractorV3") and BACKBONES.get("FPNSpMiddleResNetFHD")

@@ -194,12 +194,18 @@ def test_build_selector_end_to_end(path, tmp_path):
         fp = os.path.join(tmp, "wfeats.pt")
         torch.save(torch.from_numpy(_feats(fx)), fp)
         cfg["weighted_feat_path"] = fp
+    if cls == "PPALSelector":
+        fp = os.path.join(tmp, "pfeats.pt")
+        torch.save(torch.from_numpy(_feats(fx)), fp)
+        ep = os.path.join(tmp, "pent.pt")
+        torch.save(torch.from_numpy(fx["entropy"]), ep)
+        cfg.update(feat_path=fp, ent_path=ep)
     if cls == "EntropySelector":
         fp = os.path.join(tmp, "entropy.pt")
         torch.save(torch.from_numpy(fx["entropy"]), fp)
         cfg["buffer_path"] = fp
     if cls not in ("FeatureSelector", "TemporalSelector", "RandomSelector", "EntropySelector",
-                   "BadgeSelector", "UWESelector"):
+                   "BadgeSelector", "UWESelector", "PPALSelector"):
         cfg["logs_file"] = lp
     if cls not in ("TemporalSelector", "RandomSelector", "EntropySelector"):
         cfg["distance_store_file"] = os.path.join(tmp, "dist.npy")
@@ -289,3 +295,26 @@ def test_argsort_minmax_scale_entropy_primitives(oracle):
             np.testing.assert_allclose(e[b], ref, rtol=2e-6)
             t = torch.from_numpy(kept)
             np.testing.assert_allclose(e[b], (-t * torch.log(t) - (1.0 - t) * torch.log(1 - t)).mean().item(), rtol=2e-6)
+
+
+def test_ppal_primitives(oracle):
+    from al3d import selector_ops as ops
+    rng = np.random.default_rng(3)
+    n = 300
+    Dm = rng.uniform(0, 5, size=(n, n)).astype(np.float32)
+    keep = rng.uniform(size=n) < 0.4
+    got = ops.mask_map_(torch.from_numpy(Dm.copy()).to("cuda:0"), torch.from_numpy(keep.astype(np.uint8)).to("cuda:0")).cpu().numpy()
+    ref = Dm.copy(); ref[~keep] = -np.inf; ref[:, ~keep] = -np.inf
+    assert np.array_equal(got, ref)
+    scores = rng.uniform(0.1, 0.99, size=(2, 6, 83)).astype(np.float32)
+    labels = rng.integers(0, 10, size=(2, 6, 83)).astype(np.int32)
+    counts = rng.integers(0, 84, size=(2, 6)).astype(np.int32)
+    cw = rng.uniform(0.5, 2.0, size=10).astype(np.float32)
+    e = ops.frame_weighted_entropy(*(torch.from_numpy(a).to("cuda:0") for a in (scores, labels, counts, cw))).cpu().numpy()
+    for b in range(2):
+        tot = 0.0
+        for t in range(6):
+            s = torch.from_numpy(scores[b, t, :counts[b, t]])
+            h = -s * torch.log(s) - (1.0 - s) * torch.log(1 - s)
+            tot += float((h * torch.from_numpy(cw[labels[b, t, :counts[b, t]]])).sum())
+        np.testing.assert_allclose(e[b], tot, rtol=1e-5)
