@@ -206,6 +206,244 @@ __global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2: same decomposition, software-pipelined gather.  The v1 loop above is a dependent chain per
+// unit (index load -> wait -> row load -> wait -> split -> MFMA) whose latency only other waves
+// can hide.  Here every wave keeps a register ring of P units in flight: the neighbour index of
+// unit u+2P and the gathered row fragment of unit u+P are requested while unit u is multiplied,
+// so the counted vmcnt at each consume leaves P-1 row loads + P index loads outstanding.
+__device__ __attribute__((aligned(256))) float g_sw_zero[128];   // stays zero: target of masked gathers
+__device__ int g_sw_neg1 = -1;                                    // "no neighbour" for masked index loads
+
+template <int CIN, int COUT, int UPS, int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void sp_conv_wave2_kernel(const float* __restrict__ fin,
+                                                            const int* __restrict__ nbr, int K,
+                                                            const __bf16* __restrict__ wgt,   // [3][COUT][K][CIN]
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ residual, int relu,
+                                                            float* __restrict__ fout, int n_out)
+{
+    constexpr int KG = CIN / 16;
+    constexpr int TN = (COUT + 31) / 32;
+    constexpr int NROWS = COUT;
+    constexpr int UNIT_BYTES = 3 * NROWS * SW_PITCH;
+    constexpr int G = P / UPS;                           // slabs per unrolled group
+    static_assert(P % UPS == 0 && G >= 1, "ring depth must be a multiple of the slab size");
+    constexpr int SLAB_PIECES = UPS * 3 * NROWS * 2;
+    constexpr int PASSES = (SLAB_PIECES + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char Ws[2][UPS * UNIT_BYTES + 64];
+    __shared__ __attribute__((aligned(16))) unsigned char zrow[64];
+    __shared__ unsigned s_mask;
+    __shared__ int s_taps[32];
+    __shared__ int s_ntaps;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    // XCD-aware placement: blocks with equal blockIdx % 8 share an L2, so give each of the eight
+    // groups one contiguous range of row tiles (rows are in raster order, neighbours of a tile
+    // live in nearby tiles) instead of every eighth tile.  Bijective for any grid size.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int row0 = tile * SW_ROWS;
+    const int my_row = row0 + wave * 32 + fr;
+    const bool row_ok = my_row < n_out;
+    const int64_t plane = (int64_t)COUT * K * CIN;
+
+    if (tid < 16) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
+    if (tid == 0) s_mask = 0u;
+    __syncthreads();
+    // offsets with a neighbour in this wave's rows: all 14 index loads are issued before the first
+    // ballot (one memory latency per wave instead of fourteen)
+    unsigned wmask = 0u;
+    {
+        int nv[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int k = 2 * i + fh;
+            const int* ip = (k < K && row_ok) ? nbr + (int64_t)k * n_out + my_row : &g_sw_neg1;
+            nv[i] = *ip;
+        }
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const unsigned long long bal = __ballot(nv[i] >= 0);
+            if (bal & 0xffffffffull) wmask |= 1u << (2 * i);
+            if (bal >> 32) wmask |= 1u << (2 * i + 1);
+        }
+    }
+    wmask = __builtin_amdgcn_readfirstlane(wmask);
+    if (lane == 0 && wmask) atomicOr(&s_mask, wmask);
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        const unsigned m = s_mask;
+        for (int k = 0; k < K; ++k) if (m >> k & 1u) s_taps[c++] = k;
+        s_ntaps = c;
+        for (; c < 32; ++c) s_taps[c] = 31;             // bit 31 of wmask is never set
+    }
+    __syncthreads();
+    const int nunits = s_ntaps * KG;
+    const int nslabs = (nunits + UPS - 1) / UPS;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // every global load in the main loop is unconditional (clamped or redirected addresses): a
+    // branch around a VMEM op makes hipcc fall back to vmcnt(0) at each consume, which would
+    // serialise the ring.  The staged weight pieces are named scalars, not an array (hipcc
+    // otherwise promotes the array to LDS and waits for the loads at once).
+    static_assert(PASSES <= 3, "slab staging holds at most three 16-byte pieces per thread");
+    uint4 rw0 = make_uint4(0u, 0u, 0u, 0u), rw1 = rw0, rw2 = rw0;
+    auto slab_src = [&](int slab, int q) -> const uint4* {
+        int piece = tid + 256 * q;
+        piece = piece < SLAB_PIECES ? piece : SLAB_PIECES - 1;
+        const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
+        const int uu = (piece >> 1) / (NROWS * 3);
+        int unit = slab * UPS + uu;
+        unit = unit < nunits ? unit : nunits - 1;
+        const int tap = s_taps[unit / KG], g = unit % KG;
+        return reinterpret_cast<const uint4*>(wgt + pl * plane + ((int64_t)n * K + tap) * CIN + 16 * g + 8 * half);
+    };
+    auto load_slab = [&](int slab) {
+        rw0 = *slab_src(slab, 0);
+        if constexpr (PASSES > 1) rw1 = *slab_src(slab, 1);
+        if constexpr (PASSES > 2) rw2 = *slab_src(slab, 2);
+    };
+    auto store_piece = [&](int buf, int q, const uint4& v) {
+        const int piece = tid + 256 * q;
+        if (piece >= SLAB_PIECES) return;
+        const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
+        const int uu = (piece >> 1) / (NROWS * 3);
+        *reinterpret_cast<uint4*>(&Ws[buf][uu * UNIT_BYTES + (pl * NROWS + n) * SW_PITCH + 16 * half]) = v;
+    };
+    auto store_slab = [&](int buf) {
+        store_piece(buf, 0, rw0);
+        if constexpr (PASSES > 1) store_piece(buf, 1, rw1);
+        if constexpr (PASSES > 2) store_piece(buf, 2, rw2);
+    };
+
+    // Unit u = (u/KG)-th set bit of the workgroup's offset mask, channel group u%KG.  Three scalar
+    // cursors walk that sequence (consume at u, row gather at u+P, index load at u+2P) so the loop
+    // never has to look a unit up in LDS.
+    struct Cursor { unsigned rem; int g; };
+    const unsigned gmask = __builtin_amdgcn_readfirstlane(s_mask);
+    auto cur_tap = [&](const Cursor& c) -> int {                       // -1: past the end / not needed by this wave
+        const int t = c.rem ? __builtin_ctz(c.rem) : 31;
+        return (wmask >> t & 1u) ? t : -1;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.g == KG) { c.g = 0; c.rem &= c.rem - 1u; }
+    };
+    auto load_idx = [&](const Cursor& c) -> int {
+        const int t = cur_tap(c);
+        const int* ip = (t >= 0 && row_ok) ? nbr + (int64_t)t * n_out + my_row : &g_sw_neg1;
+        return *ip;                                                    // the loaded word is used as is, P units later
+    };
+    float4 dlo[P], dhi[P];
+    int ridx[P];
+    auto load_row = [&](const Cursor& c, int src, float4& lo, float4& hi) {
+        const float* rp = src >= 0 ? fin + (int64_t)src * CIN + 16 * c.g + 8 * fh : g_sw_zero + 8 * fh;
+        lo = *reinterpret_cast<const float4*>(rp);
+        hi = *reinterpret_cast<const float4*>(rp + 4);
+    };
+    Cursor cc{gmask, 0}, rc{gmask, 0}, ic{gmask, 0};                 // consume / row / index cursors
+#pragma unroll
+    for (int s = 0; s < P; ++s) { ridx[s] = load_idx(ic); advance(ic); }
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        load_row(rc, ridx[s], dlo[s], dhi[s]);
+        advance(rc);
+        ridx[s] = load_idx(ic);
+        advance(ic);
+    }
+    if (nslabs > 0) { load_slab(0); store_slab(0); }
+    __syncthreads();
+    for (int slab0 = 0; slab0 < nslabs; slab0 += G) {                  // tail slabs past nslabs are empty
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int slab = slab0 + gi;
+            const int buf = slab & 1;
+            load_slab(slab + 1 < nslabs ? slab + 1 : nslabs - 1);
+#pragma unroll
+            for (int i = 0; i < UPS; ++i) {
+                const int slot = gi * UPS + i;                          // compile-time after unrolling
+                if (cur_tap(cc) >= 0) {
+                    bf16x8 a0, a1, a2;
+                    sw_split8(dlo[slot], dhi[slot], a0, a1, a2);
+                    const unsigned char* ub = &Ws[buf][i * UNIT_BYTES];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = j * 32 + fr;
+                        const bool live = n < COUT;
+                        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(live ? ub + (0 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(live ? ub + (1 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(live ? ub + (2 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+                    }
+                }
+                advance(cc);
+                load_row(rc, ridx[slot], dlo[slot], dhi[slot]);
+                advance(rc);
+                ridx[slot] = load_idx(ic);
+                advance(ic);
+            }
+            store_slab(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = j * 32 + fr;
+        if (n >= COUT) continue;
+        const float sc = scale ? scale[n] : 1.0f;
+        const float sh = shift ? shift[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (row >= n_out) continue;
+            float v = acc[j][r] * sc + sh;
+            const int64_t o = (int64_t)row * COUT + n;
+            if (residual) v += residual[o];
+            if (relu) v = v > 0.f ? v : 0.f;
+            fout[o] = v;
+        }
+    }
+}
+
+#define SW2_DISPATCH(CI, CO, UPS, P)                                                                  \
+    if (cin == CI && cout == CO) {                                                                    \
+        hipLaunchKernelGGL((sp_conv_wave2_kernel<CI, CO, UPS, P>), dim3((unsigned)al3d_cdiv(n_out, SW_ROWS)), \
+                           dim3(256), 0, s, fin, nbr, K, (const __bf16*)wgt_bf16x3, scale, shift,     \
+                           residual, relu, fout, n_out);                                              \
+        AL3D_CHECK_LAUNCH("sp_conv_wave2_kernel");                                                    \
+        return AL3D_OK;                                                                               \
+    }
+
+extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3,
+                                         int cin, int cout, const float* scale, const float* shift,
+                                         const float* residual, int relu, float* fout, int n_out,
+                                         int n_in, int fmt, void* stream)
+{
+    AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_wave2_bf16x6: bad sizes");
+    AL3D_REQUIRE(fmt == 0, "al3d_sp_conv_wave2_bf16x6: f32 rows only");
+    if (n_out == 0) return AL3D_OK;
+    AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave2_bf16x6: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    SW2_DISPATCH(16, 16, 4, 8) SW2_DISPATCH(16, 32, 2, 4) SW2_DISPATCH(32, 32, 2, 4) SW2_DISPATCH(32, 64, 1, 4)
+    SW2_DISPATCH(64, 64, 1, 4) SW2_DISPATCH(64, 128, 1, 4) SW2_DISPATCH(128, 128, 1, 4)
+    return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_bf16x6: unsupported channel pair %d -> %d", cin, cout);
+}
+
 #define SW_DISPATCH(CI, CO)                                                                           \
     if (cin == CI && cout == CO) {                                                                    \
         hipLaunchKernelGGL((sp_conv_wave_kernel<CI, CO>), dim3((unsigned)al3d_cdiv(n_out, SW_ROWS)),   \

@@ -202,10 +202,12 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
                  _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     if mfma is None:
-        mfma = (cin, cout) in MFMA_PAIRS and (MATH if MATH == "bf16x6" else True)
-    if mfma in ("bf16x6", "wave"):
+        mfma = (cin, cout) in MFMA_PAIRS and ("wave2" if MATH == "bf16x6" else True)
+    if mfma in ("bf16x6", "wave", "wave2"):
         w6 = split_bf16x3(w.permute(2, 0, 1).contiguous())
-        lib.call("al3d_sp_conv_wave_bf16x6" if mfma == "wave" else "al3d_sp_conv_bf16x6", _ptr(feats), _ptr(nbr), K, _ptr(w6), cin, cout, _ptr(scale),
+        fn = {"bf16x6": "al3d_sp_conv_bf16x6", "wave": "al3d_sp_conv_wave_bf16x6",
+              "wave2": "al3d_sp_conv_wave2_bf16x6"}[mfma]
+        lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(w6), cin, cout, _ptr(scale),
                  _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, n, 0, st)
     elif mfma:
         w_ock = w.permute(2, 0, 1).contiguous()          # [Cout, K, Cin]

@@ -162,31 +162,25 @@ class _SparseEncoderBase(nn.Module):
         if residual is not None and residual.dtype == torch.bfloat16:
             fmt |= 4
         res_ptr = None if residual is None else _ptr(residual)
-        if fmt:
-            wave = D.SPCONV == "wave" or (D.SPCONV == "auto" and m.out_channels <= 64)
-            fn = "al3d_sp_conv_wave_bf16x6" if wave else "al3d_sp_conv_bf16x6"
+        mfma_pair = (m.in_channels, m.out_channels) in MFMA_PAIRS
+        if fmt or (mfma_pair and step["w"].dtype == torch.bfloat16):
+            # bf16x6 arithmetic.  Measured per channel pair on the real rulebooks
+            # (tools/bench_splayers.py): the software-pipelined wave kernel wins everywhere;
+            # AL3D_SPCONV=wave|tile selects the older structures (planes mode needs them).
+            if fmt or D.SPCONV == "wave":
+                fn = "al3d_sp_conv_wave_bf16x6"
+                if D.SPCONV == "tile" or (fmt and D.SPCONV == "auto" and m.out_channels > 64):
+                    fn = "al3d_sp_conv_bf16x6"
+            elif D.SPCONV == "tile":
+                fn = "al3d_sp_conv_bf16x6"
+            else:
+                fn = "al3d_sp_conv_wave2_bf16x6"
             lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
                      _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, n_in, fmt, st)
             return
-        if (m.in_channels, m.out_channels) in MFMA_PAIRS and step["w"].dtype == torch.bfloat16:
-            wave = D.SPCONV == "wave" or (D.SPCONV == "auto" and m.out_channels <= 64)
-            fn = "al3d_sp_conv_wave_bf16x6" if wave else "al3d_sp_conv_bf16x6"
-            lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
-                     _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, n_in, 0, st)
-            return
-        residual = res_ptr
-        if (m.in_channels, m.out_channels) in MFMA_PAIRS:
-            if step["w"].dtype == torch.bfloat16:
-                # measured per channel pair (profiles/): the wave-autonomous kernel wins up to 64
-                # output channels, the LDS-staged tile kernel at 128
-                wave = D.SPCONV == "wave" or (D.SPCONV == "auto" and m.out_channels <= 64)
-                fn = "al3d_sp_conv_wave_bf16x6" if wave else "al3d_sp_conv_bf16x6"
-            else:
-                fn = "al3d_sp_conv_mfma_f32"
-        else:
-            fn = "al3d_sp_conv_f32"
+        fn = "al3d_sp_conv_mfma_f32" if mfma_pair else "al3d_sp_conv_f32"
         lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
-                 _ptr(step["scale"]), _ptr(step["shift"]), residual, 1, _ptr(out), n, st)
+                 _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, st)
 
     def _level(self, shape, batch, device):
         key = tuple(int(s) for s in shape)

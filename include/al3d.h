@@ -258,6 +258,12 @@ int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void
 int al3d_sp_conv_wave_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                              int cout, const float* scale, const float* shift, const float* residual,
                              int relu, float* fout, int n_out, int n_in, int fmt, void* stream);
+/* al3d_sp_conv_wave_bf16x6 with a software-pipelined gather: every wave keeps a register ring of
+ * neighbour indices (2P units ahead) and gathered row fragments (P units ahead) in flight while it
+ * multiplies.  f32 rows only (fmt must be 0); results are bit-identical to the unpipelined kernel. */
+int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
+                              int cout, const float* scale, const float* shift, const float* residual,
+                              int relu, float* fout, int n_out, int n_in, int fmt, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
  * out must be zero-filled. */
 int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D, int H,

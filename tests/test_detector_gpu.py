@@ -25,7 +25,7 @@ def _t(a):
                                          (False, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
                                          (False, (3, 3, 3), (2, 2, 2), (0, 1, 1)),
                                          (False, (3, 1, 1), (2, 1, 1), (0, 0, 0))])
-@pytest.mark.parametrize("mfma", [False, True, "bf16x6", "wave"])
+@pytest.mark.parametrize("mfma", [False, True, "bf16x6", "wave", "wave2"])
 def test_sparse_conv_layer_vs_oracle(oracle, cin, cout, subm, k, s, p, mfma):
     from al3d import detector_ops as D
     from al3d.detector_ops import MFMA_PAIRS
@@ -47,6 +47,26 @@ def test_sparse_conv_layer_vs_oracle(oracle, cin, cout, subm, k, s, p, mfma):
     # row order of a strided conv's outputs is free: compare through the dense scatter
     np.testing.assert_allclose(to_dense(got, gco, batch, oshape), to_dense(ref, co, batch, oshape),
                                rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 64), (64, 64), (128, 128)])
+def test_sparse_conv_pipelined_kernel_is_bit_identical(cin, cout):
+    """The software-pipelined wave kernel performs the same MFMA sequence per output as the
+    unpipelined one: outputs must agree bit for bit (ragged tail, residual, sparse + dense taps)."""
+    from al3d import detector_ops as D
+    rng = np.random.default_rng(cin + cout)
+    shape, batch = [9, 40, 37], 3
+    feats, coords = random_sparse(rng, batch, shape, 4001, cin)
+    w = (rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+    res = rng.normal(size=(feats.shape[0], cout)).astype(np.float32) if cin == cout else None
+    outs = []
+    for mode in ("wave", "wave2", "bf16x6"):
+        got, _, _ = D.sparse_conv_layer(_t(feats), _t(coords), batch, shape, _t(w), (3, 3, 3), (1, 1, 1),
+                                        (0, 0, 0), True, residual=None if res is None else _t(res),
+                                        relu=True, mfma=mode)
+        outs.append(got.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[2])
 
 
 def test_sparse_conv_residual_and_empty(oracle):
