@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restri
 __device__ __attribute__((aligned(256))) float g_sw_zero[128];   // stays zero: target of masked gathers
 __device__ int g_sw_neg1 = -1;                                    // "no neighbour" for masked index loads
 
-template <int CIN, int COUT, int UPS, int P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void sp_conv_wave2_kernel(const float* __restrict__ fin,
+template <int CIN, int COUT, int NW, int UPS, int P>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4))) void sp_conv_wave2_kernel(const float* __restrict__ fin,
                                                             const int* __restrict__ nbr, int K,
                                                             const __bf16* __restrict__ wgt,   // [3][COUT][K][CIN]
                                                             const float* __restrict__ scale,
@@ -229,10 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     constexpr int TN = (COUT + 31) / 32;
     constexpr int NROWS = COUT;
     constexpr int UNIT_BYTES = 3 * NROWS * SW_PITCH;
-    constexpr int G = P / UPS;                           // slabs per unrolled group
-    static_assert(P % UPS == 0 && G >= 1, "ring depth must be a multiple of the slab size");
+    constexpr int NT = 64 * NW;                          // threads; the workgroup owns 32*NW output rows
+    constexpr int G = P > UPS ? P / UPS : 1;             // slabs per unrolled group (ring slots stay compile-time)
+    static_assert(P % UPS == 0 || UPS % P == 0, "ring depth and slab size must divide one another");
     constexpr int SLAB_PIECES = UPS * 3 * NROWS * 2;
-    constexpr int PASSES = (SLAB_PIECES + 255) / 256;
+    constexpr int PASSES = (SLAB_PIECES + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) unsigned char Ws[2][UPS * UNIT_BYTES + 64];
     __shared__ __attribute__((aligned(16))) unsigned char zrow[64];
     __shared__ unsigned s_mask;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     // live in nearby tiles) instead of every eighth tile.  Bijective for any grid size.
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int row0 = tile * SW_ROWS;
+    const int row0 = tile * (32 * NW);
     const int my_row = row0 + wave * 32 + fr;
     const bool row_ok = my_row < n_out;
     const int64_t plane = (int64_t)COUT * K * CIN;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     static_assert(PASSES <= 3, "slab staging holds at most three 16-byte pieces per thread");
     uint4 rw0 = make_uint4(0u, 0u, 0u, 0u), rw1 = rw0, rw2 = rw0;
     auto slab_src = [&](int slab, int q) -> const uint4* {
-        int piece = tid + 256 * q;
+        int piece = tid + NT * q;
         piece = piece < SLAB_PIECES ? piece : SLAB_PIECES - 1;
         const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
         const int uu = (piece >> 1) / (NROWS * 3);
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         if constexpr (PASSES > 2) rw2 = *slab_src(slab, 2);
     };
     auto store_piece = [&](int buf, int q, const uint4& v) {
-        const int piece = tid + 256 * q;
+        const int piece = tid + NT * q;
         if (piece >= SLAB_PIECES) return;
         const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
         const int uu = (piece >> 1) / (NROWS * 3);
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             load_slab(slab + 1 < nslabs ? slab + 1 : nslabs - 1);
 #pragma unroll
             for (int i = 0; i < UPS; ++i) {
-                const int slot = gi * UPS + i;                          // compile-time after unrolling
+                const int slot = (gi * UPS + i) % P;                    // compile-time after unrolling
                 if (cur_tap(cc) >= 0) {
                     bf16x8 a0, a1, a2;
                     sw_split8(dlo[slot], dhi[slot], a0, a1, a2);
@@ -420,11 +421,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
 }
 
-#define SW2_DISPATCH(CI, CO, UPS, P)                                                                  \
+#define SW2_DISPATCH(CI, CO, NW, UPS, P)                                                              \
     if (cin == CI && cout == CO) {                                                                    \
-        hipLaunchKernelGGL((sp_conv_wave2_kernel<CI, CO, UPS, P>), dim3((unsigned)al3d_cdiv(n_out, SW_ROWS)), \
-                           dim3(256), 0, s, fin, nbr, K, (const __bf16*)wgt_bf16x3, scale, shift,     \
-                           residual, relu, fout, n_out);                                              \
+        hipLaunchKernelGGL((sp_conv_wave2_kernel<CI, CO, NW, UPS, P>),                                \
+                           dim3((unsigned)al3d_cdiv(n_out, 32 * NW)), dim3(64 * NW), 0, s, fin, nbr, K, \
+                           (const __bf16*)wgt_bf16x3, scale, shift, residual, relu, fout, n_out);     \
         AL3D_CHECK_LAUNCH("sp_conv_wave2_kernel");                                                    \
         return AL3D_OK;                                                                               \
     }
@@ -439,8 +440,8 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
     if (n_out == 0) return AL3D_OK;
     AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave2_bf16x6: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    SW2_DISPATCH(16, 16, 4, 8) SW2_DISPATCH(16, 32, 2, 4) SW2_DISPATCH(32, 32, 2, 4) SW2_DISPATCH(32, 64, 1, 4)
-    SW2_DISPATCH(64, 64, 1, 4) SW2_DISPATCH(64, 128, 1, 4) SW2_DISPATCH(128, 128, 1, 4)
+    SW2_DISPATCH(16, 16, 4, 4, 4) SW2_DISPATCH(16, 32, 4, 2, 2) SW2_DISPATCH(32, 32, 4, 2, 2) SW2_DISPATCH(32, 64, 4, 2, 4)
+    SW2_DISPATCH(64, 64, 4, 2, 4) SW2_DISPATCH(64, 128, 4, 1, 2) SW2_DISPATCH(128, 128, 4, 1, 2)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_bf16x6: unsupported channel pair %d -> %d", cin, cout);
 }
 
