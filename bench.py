@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scenes", type=int, default=SCENES_PER_RANK, help="scenes per rank")
-    ap.add_argument("--batch", type=int, default=16, help="frames per detector launch")
+    ap.add_argument("--batch", type=int, default=32, help="frames per detector launch")
     ap.add_argument("--budget", type=int, default=None,
                     help="cost budget (default 600; scaled down for pools under 64 scenes, whose "
                          "total labelling cost is below 600)")
@@ -86,6 +86,24 @@ class ConvTimer:
 
         model.neck.forward = neck
         model.bbox_head.forward = head
+
+    @staticmethod
+    def isolated(timer, model, loader, dev, batches=4):
+        """Neck+head regions of a few batches with the two-stream pipeline off (nothing else runs)."""
+        from al3d.sweep import example_to_device
+        saved = (timer.pairs, timer.launches, timer.frames)
+        timer.pairs, timer.launches, timer.frames = [], 0, 0
+        timer.enabled = True
+        with torch.no_grad():
+            for i, data_batch in enumerate(loader):
+                if i >= batches:
+                    break
+                model(example_to_device(data_batch, dev), return_loss=False, estimate=True)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        res = timer.result()
+        timer.pairs, timer.launches, timer.frames = saved
+        return res
 
     def result(self):
         if not self.pairs:
@@ -263,6 +281,19 @@ def main():
         }
         roof = timer.result()
         if roof:
+            from al3d import sweep as _sweep
+            roof["measured"] = ("HIP events around every neck+head region of the timed steps"
+                                + ("; the sparse half of the next batch runs concurrently on a second "
+                                   "stream (AL3D_PIPELINE=1), so these durations include that contention"
+                                   if _sweep.PIPELINE else ""))
+            if _sweep.PIPELINE:
+                # the same kernels with nothing else on the device: a short serial pass (untimed,
+                # after the timed region) so the kernel's own roofline fraction is visible too
+                iso = ConvTimer.isolated(timer, model, loader, dev, batches=4)
+                if iso:
+                    roof["isolated"] = {k: iso[k] for k in ("achieved", "frac", "executed_tflops", "avg_launch_us")
+                                        if k in iso}
+                    roof["isolated"]["note"] = "4 batches, pipeline off, same process, after the timed steps"
             out["roofline"] = roof
         if not args.no_verify:
             out["selected_equals_oracle"] = verify_selection(infos, state["feats"], state["selected"])

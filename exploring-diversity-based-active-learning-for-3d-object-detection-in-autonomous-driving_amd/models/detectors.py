@@ -66,14 +66,24 @@ class FPNVoxelNet(SingleStageDetector):
             middle.append(NHWCFeature(x))
         return x, middle
 
-    def forward(self, example, return_loss=True, finetune=False, **kwargs):
-        if return_loss:
-            raise NotImplementedError("al3d implements the inference sweep, not training")
+    # The forward pass is exposed in two halves so that the sweep can run the sparse half of batch
+    # i+1 (voxel features -> sparse encoder -> dense BEV; latency-bound gathers) on one HIP stream
+    # while the dense half of batch i (neck + head + decode; matrix-core bound) runs on another.
+    def sparse_stage(self, example):
         num_voxels = example["num_voxels"]
         data = dict(features=example.get("voxels"), num_voxels=example.get("num_points"),
                     mean_features=example.get("voxel_features"), coors=example["coordinates"],
                     batch_size=len(num_voxels), input_shape=example["shape"][0])
-        x, middle = self.extract_feat(data)
+        if data.get("mean_features") is not None:     # device voxelizer already reduced the points
+            input_features = data["mean_features"]
+        else:
+            input_features = self.reader(data["features"], data["num_voxels"])
+        return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+
+    def dense_stage(self, example, x, middle, finetune=False, **kwargs):
+        if self.with_neck:
+            x = self.neck(x)
+            middle.append(NHWCFeature(x))
         preds = self.bbox_head(x, finetune=finetune)
         if kwargs.get("get_preds", False):
             return preds
@@ -81,6 +91,12 @@ class FPNVoxelNet(SingleStageDetector):
         if kwargs.get("estimate", False):
             return out, middle
         return out
+
+    def forward(self, example, return_loss=True, finetune=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError("al3d implements the inference sweep, not training")
+        x, middle = self.sparse_stage(example)
+        return self.dense_stage(example, x, middle, finetune=finetune, **kwargs)
 
 
 @DETECTORS.register_module

@@ -62,6 +62,36 @@ def gather_in_dataset_order(local_feats, local_index, num_frames):
     return out
 
 
+import os as _os
+
+PIPELINE = _os.environ.get("AL3D_PIPELINE", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def _tensors_of(obj):
+    """Every CUDA tensor reachable from a nest of dicts / lists / tuples / objects with tensor fields."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+    elif hasattr(obj, "__dict__") and not isinstance(obj, type):
+        for v in vars(obj).values():
+            if isinstance(v, (torch.Tensor, dict, list, tuple)):
+                yield from _tensors_of(v)
+
+
 def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy=False,
                      batch_local_weights=None):
     """Run ``detector(example, return_loss=False, estimate=True)`` over the loader and
@@ -78,24 +108,61 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
     if sampler is not None and hasattr(sampler, "__iter__") and not isinstance(
             sampler, torch.utils.data.SequentialSampler):
         sampler_idx = list(iter(sampler))
+    def finish(example, preds, middle):
+        nonlocal seen
+        emb = gap_embedding(middle[-1])
+        if batch_local_weights is not None:
+            from . import selector_ops as ops
+            emb = ops.scale_rows(emb.contiguous(), batch_local_weights[: emb.shape[0]].contiguous())
+        if with_entropy:
+            ents.append(preds.frame_entropy() if hasattr(preds, "frame_entropy")
+                        else torch.stack([_entropy_of(p["scores"]) for p in preds]))
+        feats.append(emb)
+        b = emb.shape[0]
+        if sampler_idx is not None:
+            index.extend(sampler_idx[seen:seen + b])
+        else:
+            index.extend(range(seen, seen + b))
+        seen += b
+
+    pipelined = (PIPELINE and torch.device(device).type == "cuda" and hasattr(detector, "sparse_stage")
+                 and hasattr(detector, "dense_stage"))
     with torch.no_grad():
-        for data_batch in dataloader:
-            example = example_to_device(data_batch, device, non_blocking=False)
-            preds, middle = detector(example, return_loss=False, estimate=True)
-            emb = gap_embedding(middle[-1])
-            if batch_local_weights is not None:
-                from . import selector_ops as ops
-                emb = ops.scale_rows(emb.contiguous(), batch_local_weights[: emb.shape[0]].contiguous())
-            if with_entropy:
-                ents.append(preds.frame_entropy() if hasattr(preds, "frame_entropy")
-                            else torch.stack([_entropy_of(p["scores"]) for p in preds]))
-            feats.append(emb)
-            b = emb.shape[0]
-            if sampler_idx is not None:
-                index.extend(sampler_idx[seen:seen + b])
-            else:
-                index.extend(range(seen, seen + b))
-            seen += b
+        if not pipelined:
+            for data_batch in dataloader:
+                example = example_to_device(data_batch, device, non_blocking=False)
+                preds, middle = detector(example, return_loss=False, estimate=True)
+                finish(example, preds, middle)
+        else:
+            # Two-stage software pipeline over batches: the sparse half of batch i+1 is enqueued on a
+            # side stream while the dense half of batch i runs on the caller's stream.  The dense
+            # half is enqueued FIRST (it has no host synchronisation), so the device keeps working
+            # on it while the host waits for the sparse half's row counts.
+            main = torch.cuda.current_stream(device)
+            side = _side_stream(device)
+            side.wait_stream(main)
+            pending = None                      # (example, x, middle, event) of the batch whose dense half is due
+            it = iter(dataloader)
+            while True:
+                if pending is not None:
+                    example, x, middle, ev = pending
+                    main.wait_event(ev)
+                    preds, middle = detector.dense_stage(example, x, middle, estimate=True)
+                    finish(example, preds, middle)
+                    pending = None
+                with torch.cuda.stream(side):
+                    try:
+                        data_batch = next(it)
+                    except StopIteration:
+                        break
+                    example = example_to_device(data_batch, device, non_blocking=False)
+                    x, middle = detector.sparse_stage(example)
+                    for t in _tensors_of((example, x, middle)):
+                        t.record_stream(main)   # produced on the side stream, consumed on the main one
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                pending = (example, x, middle, ev)
+            main.wait_stream(side)
     local = torch.cat(feats, dim=0)
     idx = torch.as_tensor(index, dtype=torch.int64, device=local.device)
     n = num_frames if num_frames is not None else int(idx.max().item()) + 1
