@@ -36,13 +36,15 @@ __device__ __forceinline__ float l1_term(float d)
 
 template <int P>
 __global__ __launch_bounds__(256) void l1_map_kernel(const float* __restrict__ feats, int64_t n,
-                                                     int64_t c, float* __restrict__ out)
+                                                     int64_t c, int64_t row0, int64_t nrows,
+                                                     float* __restrict__ out)   // out: rows [row0, row0+nrows)
 {
     __shared__ __attribute__((aligned(16))) float As[L1_KC][L1_TILE];
     __shared__ __attribute__((aligned(16))) float Bs[L1_KC][L1_TILE];
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int64_t i0 = (int64_t)blockIdx.y * L1_TILE;  // rows: feats[i]
+    const int64_t i0 = row0 + (int64_t)blockIdx.y * L1_TILE;  // rows: feats[i]
+    const int64_t iend = row0 + nrows;
     const int64_t j0 = (int64_t)blockIdx.x * L1_TILE;  // cols: feats[j]
     float acc[4][4];
 #pragma unroll
@@ -82,32 +84,44 @@ __global__ __launch_bounds__(256) void l1_map_kernel(const float* __restrict__ f
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int64_t i = i0 + ty * 4 + r;
-        if (i >= n) continue;
+        if (i >= n || i >= iend) continue;
         int64_t j = j0 + tx * 4;
+        float* orow = out + (i - row0) * n;
         if (j + 3 < n && (n & 3) == 0) {
-            *reinterpret_cast<float4*>(&out[i * n + j]) =
+            *reinterpret_cast<float4*>(&orow[j]) =
                 make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                if (j + s < n) out[i * n + j + s] = acc[r][s];
+                if (j + s < n) orow[j + s] = acc[r][s];
         }
     }
+}
+
+extern "C" int al3d_l1_distance_rows_f32(const float* feats, int64_t n, int64_t c, int p, int64_t row0,
+                                         int64_t nrows, float* out, void* stream)
+{
+    AL3D_REQUIRE(n >= 0 && c >= 0, "al3d_l1_distance_rows_f32: negative size");
+    AL3D_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= n, "al3d_l1_distance_rows_f32: bad row range");
+    AL3D_REQUIRE(p == 1 || p == 2, "al3d_l1_distance_rows_f32: p must be 1 or 2 (got %d)", p);
+    if (n == 0 || nrows == 0) return AL3D_OK;
+    AL3D_REQUIRE(feats && out, "al3d_l1_distance_rows_f32: null pointer");
+    AL3D_REQUIRE(((uintptr_t)out & 15) == 0, "al3d_l1_distance_rows_f32: out must be 16-byte aligned");
+    dim3 grid((unsigned)al3d_cdiv(n, L1_TILE), (unsigned)al3d_cdiv(nrows, L1_TILE));
+    hipStream_t s = (hipStream_t)stream;
+    if (p == 1) hipLaunchKernelGGL(l1_map_kernel<1>, grid, dim3(256), 0, s, feats, n, c, row0, nrows, out);
+    else hipLaunchKernelGGL(l1_map_kernel<2>, grid, dim3(256), 0, s, feats, n, c, row0, nrows, out);
+    AL3D_CHECK_LAUNCH("l1_map_kernel");
+    return AL3D_OK;
 }
 
 extern "C" int al3d_l1_distance_f32(const float* feats, int64_t n, int64_t c, int p, float* out,
                                     void* stream)
 {
-    AL3D_REQUIRE(feats && out, "al3d_l1_distance_f32: null pointer");
     AL3D_REQUIRE(n >= 0 && c >= 0, "al3d_l1_distance_f32: negative size");
-    AL3D_REQUIRE(p == 1 || p == 2, "al3d_l1_distance_f32: p must be 1 or 2 (got %d)", p);
     if (n == 0) return AL3D_OK;
-    dim3 grid((unsigned)al3d_cdiv(n, L1_TILE), (unsigned)al3d_cdiv(n, L1_TILE));
-    hipStream_t s = (hipStream_t)stream;
-    if (p == 1) hipLaunchKernelGGL(l1_map_kernel<1>, grid, dim3(256), 0, s, feats, n, c, out);
-    else hipLaunchKernelGGL(l1_map_kernel<2>, grid, dim3(256), 0, s, feats, n, c, out);
-    AL3D_CHECK_LAUNCH("l1_map_kernel");
-    return AL3D_OK;
+    AL3D_REQUIRE(feats && out, "al3d_l1_distance_f32: null pointer");
+    return al3d_l1_distance_rows_f32(feats, n, c, p, 0, n, out, stream);
 }
 
 // ------------------------------------------------------------------ combine

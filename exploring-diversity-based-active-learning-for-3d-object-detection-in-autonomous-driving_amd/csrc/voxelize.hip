@@ -128,6 +128,60 @@ __global__ void vox_bucket_kernel(int64_t npts, const int* __restrict__ prow, co
 // pass 6: one thread per voxel: its max_points smallest point indices, ascending;
 // padded voxel tensor, clipped count and the mean feature.
 #define VX_MAXP 32
+// One thread per voxel: keep the MAXP smallest point indices of the voxel's bucket in a sorted
+// register array (compile-time indexed compare-exchange chain -- a runtime-indexed array would live
+// in scratch memory), then read each kept point's features once and accumulate the per-feature sums
+// in ascending point order (the order the reference's reduction sees).
+template <int MAXP, int NFEAT>
+__global__ __launch_bounds__(128) void vox_gather_fixed_kernel(const float* __restrict__ pts, int rows,
+                                  const int* __restrict__ boff, const int* __restrict__ cnt,
+                                  const int* __restrict__ bucket, const int* __restrict__ row_base,
+                                  int B, float* __restrict__ voxels,
+                                  int* __restrict__ num_points, float* __restrict__ feat)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows || row >= row_base[B]) return;
+    const int n = cnt[row], o = boff[row];
+    const int keep = n < MAXP ? n : MAXP;
+    int sel[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) sel[i] = 0x7fffffff;
+    for (int t = 0; t < n; ++t) {
+        int idx = bucket[o + t];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {       // sorted insert: carry the larger value down the chain
+            const int lo = idx < sel[i] ? idx : sel[i];
+            const int hi = idx < sel[i] ? sel[i] : idx;
+            sel[i] = lo;
+            idx = hi;
+        }
+    }
+    num_points[row] = keep;
+    float sum[NFEAT];
+#pragma unroll
+    for (int f = 0; f < NFEAT; ++f) sum[f] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+        float v[NFEAT];
+#pragma unroll
+        for (int f = 0; f < NFEAT; ++f) v[f] = 0.f;
+        if (t < keep) {
+            const float* pp = pts + (int64_t)sel[t] * NFEAT;
+#pragma unroll
+            for (int f = 0; f < NFEAT; ++f) v[f] = pp[f];
+        }
+#pragma unroll
+        for (int f = 0; f < NFEAT; ++f) sum[f] += v[f];
+        if (voxels) {
+#pragma unroll
+            for (int f = 0; f < NFEAT; ++f) voxels[((int64_t)row * MAXP + t) * NFEAT + f] = v[f];
+        }
+    }
+    const float denom = (float)keep;
+#pragma unroll
+    for (int f = 0; f < NFEAT; ++f) feat[(int64_t)row * NFEAT + f] = sum[f] / denom;
+}
+
 __global__ void vox_gather_kernel(const float* __restrict__ pts, VoxCfg c, int rows,
                                   const int* __restrict__ boff, const int* __restrict__ cnt,
                                   const int* __restrict__ bucket, const int* __restrict__ row_base,
@@ -252,8 +306,12 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
     rc = al3d_exclusive_scan_i32(cnt, boff, rows + 1, scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_bucket_kernel, dim3(pb), dim3(256), 0, s, npts, prow, boff, cursor, bucket);
-    hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s, points, c,
-                       (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);
+    if (c.max_points == 10 && c.nfeat == 5)      // the nuScenes configuration: register-resident selection
+        hipLaunchKernelGGL((vox_gather_fixed_kernel<10, 5>), dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s,
+                           points, (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);
+    else
+        hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s, points, c,
+                           (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);
     hipLaunchKernelGGL(vox_restore_kernel, dim3(pb), dim3(256), 0, s, npts, cells, pframe, pcell, first);
     AL3D_CHECK_LAUNCH("voxelize");
     return AL3D_OK;

@@ -27,6 +27,7 @@ SIGNATURES = {
     "al3d_abi_version": (c_int, []),
     "al3d_last_error": (ctypes.c_char_p, []),
     "al3d_l1_distance_f32": (c_int, [c_p, c_i64, c_i64, c_int, c_p, c_p]),
+    "al3d_l1_distance_rows_f32": (c_int, [c_p, c_i64, c_i64, c_int, c_i64, c_i64, c_p, c_p]),
     "al3d_combine_maps_f64": (c_int, [c_p, c_p, c_p, c_i64, c_int, c_int, c_dbl, c_dbl, c_dbl,
                                       c_dbl, c_p, c_p]),
     "al3d_euclid_map_f64": (c_int, [c_p, c_p, c_i64, c_p, c_p]),

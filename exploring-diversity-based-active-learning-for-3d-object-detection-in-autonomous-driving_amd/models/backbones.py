@@ -142,10 +142,21 @@ class _SparseEncoderBase(nn.Module):
         self._levels = {}
 
     @staticmethod
+    def _pad_cin(m):
+        """Input channels the layer is run with: a narrow first layer (5 -> 16) is zero-padded to
+        16 input channels so it runs on the matrix cores like every other layer (bf16x6 only)."""
+        if D.MATH == "bf16x6" and m.in_channels < 16 and (16, m.out_channels) in MFMA_PAIRS:
+            return 16
+        return m.in_channels
+
+    @staticmethod
     def _pack(m, device):
         """[kz,ky,kx,Cin,Cout] -> [K,Cin,Cout] (VALU kernel) or [Cout,K,Cin] (MFMA kernel)."""
         w = m.weight.detach().reshape(-1, m.in_channels, m.out_channels).float()
-        if (m.in_channels, m.out_channels) in MFMA_PAIRS:
+        cin = _SparseEncoderBase._pad_cin(m)
+        if cin != m.in_channels:
+            w = torch.nn.functional.pad(w, (0, 0, 0, cin - m.in_channels))
+        if (cin, m.out_channels) in MFMA_PAIRS:
             w = w.permute(2, 0, 1).contiguous().to(device)
             return D.split_bf16x3(w) if D.MATH == "bf16x6" else w
         return w.contiguous().to(device)
@@ -162,7 +173,8 @@ class _SparseEncoderBase(nn.Module):
         if residual is not None and residual.dtype == torch.bfloat16:
             fmt |= 4
         res_ptr = None if residual is None else _ptr(residual)
-        mfma_pair = (m.in_channels, m.out_channels) in MFMA_PAIRS
+        cin = feats.shape[-1]                    # == m.in_channels, or 16 for a zero-padded narrow first layer
+        mfma_pair = (cin, m.out_channels) in MFMA_PAIRS
         if fmt or (mfma_pair and step["w"].dtype == torch.bfloat16):
             # bf16x6 arithmetic.  Measured per channel pair on the real rulebooks
             # (tools/bench_splayers.py): the software-pipelined wave kernel wins everywhere;
@@ -175,11 +187,11 @@ class _SparseEncoderBase(nn.Module):
                 fn = "al3d_sp_conv_bf16x6"
             else:
                 fn = "al3d_sp_conv_wave2_bf16x6"
-            lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
+            lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), cin, m.out_channels,
                      _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, n_in, fmt, st)
             return
         fn = "al3d_sp_conv_mfma_f32" if mfma_pair else "al3d_sp_conv_f32"
-        lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), m.in_channels, m.out_channels,
+        lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), cin, m.out_channels,
                  _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, st)
 
     def _level(self, shape, batch, device):
@@ -245,6 +257,8 @@ class _SparseEncoderBase(nn.Module):
                     lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
                              _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
                     nbr_key = key
+                if feats.shape[-1] != self._pad_cin(m) and feats.dtype == torch.float32:
+                    feats = torch.nn.functional.pad(feats, (0, self._pad_cin(m) - feats.shape[-1]))
                 feats = as_input(feats, m)
                 if step.get("block_start"):
                     identity = feats

@@ -9,6 +9,7 @@ import torch
 from . import lib
 
 NORMALIZE = {None: 0, "none": 0, "exp": 1, "linear": 2}
+SHARD_MIN_ROWS = 4096          # pools below this are cheaper to map on every rank than to gather
 AGGREGATE = {"sum": 0, "min": 1, "max": 2}
 
 
@@ -32,11 +33,23 @@ def _ptr(t):
 
 def l1_distance(feats, p=2):
     """[N,C] f32 embeddings -> [N,N] f32 L1 map (feature_selector.py:87-109)."""
+    import torch.distributed as dist
     feats = _dev(feats, torch.float32, "feats")
     n, c = feats.shape
-    out = torch.empty((n, n), dtype=torch.float32, device=feats.device)
-    lib.call("al3d_l1_distance_f32", _ptr(feats), n, c, int(p), _ptr(out), _stream())
-    return out
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or n < SHARD_MIN_ROWS:
+        out = torch.empty((n, n), dtype=torch.float32, device=feats.device)
+        lib.call("al3d_l1_distance_f32", _ptr(feats), n, c, int(p), _ptr(out), _stream())
+        return out
+    # N>1: every rank holds all embeddings (they were all-gathered); each computes a block of rows
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = (n + world - 1) // world
+    r0 = min(n, rank * per)
+    nrows = min(n, r0 + per) - r0
+    block = torch.empty((per, n), dtype=torch.float32, device=feats.device)
+    lib.call("al3d_l1_distance_rows_f32", _ptr(feats), n, c, int(p), r0, nrows, _ptr(block), _stream())
+    full = torch.empty((world * per, n), dtype=torch.float32, device=feats.device)
+    dist.all_gather_into_tensor(full, block)
+    return full[:n]
 
 
 def combine_maps(n, spatial=None, temporal_id=None, feat=None, normalize="exp", aggregate="sum",
@@ -102,7 +115,7 @@ def spatial_map(xy, k=8):
     import torch.distributed as dist
     d, i = knn_2d(xy, k + 1)
     n = d.shape[0]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or n < 4096:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or n < SHARD_MIN_ROWS:
         return apsp_knn(d, i)
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n + world - 1) // world

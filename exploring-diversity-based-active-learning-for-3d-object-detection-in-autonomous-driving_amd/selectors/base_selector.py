@@ -178,10 +178,37 @@ class BaseSelector(object):
                 count = 1
         return best
 
+    def prefetch_spatial_map(self, device):
+        """Start the geodesic map on a side stream.  It depends only on the pool's poses, so the
+        sweep that produces the embeddings can run at the same time; ``_spatial_map`` then just
+        waits for the event.  Under torch.distributed the row blocks are all-gathered on that
+        stream too (every rank must call this -- the sweep mixin does)."""
+        device = torch.device(device)
+        if device.type != "cuda" or getattr(self, "_spatial_prefetch", None) is not None:
+            return
+        if not (hasattr(self, "k") and hasattr(self, "distance_store_file")):
+            return
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            spatial = self._spatial_map(device, self.k, self.distance_store_file,
+                                        getattr(self, "logs_file", None))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._spatial_prefetch = (spatial, ev)
+
     def _spatial_map(self, device, k, distance_store_file, logs_file=None):
         """kNN-graph geodesic map on device; cached as ``.npy`` like the reference
         (spatial_temporal_selector.py:60-63,106)."""
         from .. import selector_ops as ops
+        pre = getattr(self, "_spatial_prefetch", None)
+        if pre is not None:                      # started on a side stream by prefetch_spatial_map()
+            spatial, ev = pre
+            self._spatial_prefetch = None
+            cur = torch.cuda.current_stream(spatial.device)
+            cur.wait_event(ev)
+            spatial.record_stream(cur)
+            return spatial
         if distance_store_file and os.path.exists(distance_store_file):
             self.logger.info(f"begin to load the distance map from {distance_store_file}")
             return torch.from_numpy(np.load(distance_store_file)).to(device)

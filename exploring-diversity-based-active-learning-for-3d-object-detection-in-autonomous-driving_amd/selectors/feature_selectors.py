@@ -29,6 +29,8 @@ class _SweepMixin:
         self.logger.info(
             f"begin predict all results of samples and save them as {self.buffer_path}")
         device = self._device(kwargs)
+        if getattr(self, "uses_spatial_map", False):
+            self.prefetch_spatial_map(device)        # overlaps the sweep (needs poses only)
         prediction = sweep_embeddings(self.detector, self.dataloader, device,
                                       num_frames=len(self.infos_origin))
         if self.buffer_path:
@@ -97,6 +99,7 @@ class FeatureSelector(_SweepMixin, BaseSelector):
 class SpatialTemporalFeatureSelector(_SweepMixin, BaseSelector):
     """spatial_temporal_feature_selector.py:17-258:
     D = S' + lambda_t T' + lambda_f F'  with X' = 1 - exp(-X), F in float32."""
+    uses_spatial_map = True
 
     def __init__(
             self,
@@ -155,6 +158,7 @@ class SpatialTemporalFeatureSelector(_SweepMixin, BaseSelector):
 class SpatialFeatureSelector(_SweepMixin, BaseSelector):
     """spatial_feature_selector.py:18-234: fps seeded from the normalised *spatial*
     map, iterated on the aggregate of spatial and feature maps (A.1 quirk 9)."""
+    uses_spatial_map = True
 
     def __init__(
             self,

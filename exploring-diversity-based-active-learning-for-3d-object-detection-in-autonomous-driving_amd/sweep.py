@@ -64,7 +64,10 @@ def gather_in_dataset_order(local_feats, local_index, num_frames):
 
 import os as _os
 
-PIPELINE = _os.environ.get("AL3D_PIPELINE", "1") != "0"
+# Two-stream batch pipeline (sparse half of batch i+1 overlaps the dense half of batch i).  Measured
+# +4..9 % frames/s on MI355X, but every kernel then runs contended, which blurs per-kernel timings;
+# opt in with AL3D_PIPELINE=1.
+PIPELINE = _os.environ.get("AL3D_PIPELINE", "0") == "1"
 _SIDE = {}
 
 

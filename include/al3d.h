@@ -51,6 +51,10 @@ const char* al3d_last_error(void);
  * p==2 -> sum sqrt((a-b)^2)  (also L1, bug-compatible).  Sum order c=0..C-1. */
 int al3d_l1_distance_f32(const float* feats, int64_t n, int64_t c, int p,
                          float* out, void* stream);
+/* Rows [row0, row0+nrows) of the same map into out [nrows, n] (16-byte aligned): the N>1 path
+ * computes one block of rows per rank and all-gathers them. */
+int al3d_l1_distance_rows_f32(const float* feats, int64_t n, int64_t c, int p, int64_t row0,
+                              int64_t nrows, float* out, void* stream);
 
 /* Normalise + aggregate the spatial (f64 [n,n] or NULL), temporal (derived on
  * the fly from temporal_id [n] or NULL: |i-j| if ids equal else 1e6) and

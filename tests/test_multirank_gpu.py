@@ -33,6 +33,15 @@ def _worker(rank, world, port, q):
         d, i = ops.knn_2d(xy, 9)
         S1 = ops.apsp_knn(d, i)                                 # single-process reference
         ok_map = bool(torch.equal(S.view(torch.int64), S1.view(torch.int64)))
+        # feature map: row blocks per rank + all-gather == the single-process map, bit for bit
+        from al3d import lib
+        g = torch.Generator(device="cpu").manual_seed(5)
+        feats = torch.randn(xy.shape[0], 48, generator=g).to(dev)
+        F = ops.l1_distance(feats, 2)
+        F1 = torch.empty_like(F)
+        lib.call("al3d_l1_distance_f32", feats.data_ptr(), feats.shape[0], feats.shape[1], 2, F1.data_ptr(),
+                 torch.cuda.current_stream().cuda_stream)
+        ok_map = ok_map and bool(torch.equal(F.view(torch.int32), F1.view(torch.int32)))
         n = 37
         full = torch.arange(n * 4, dtype=torch.float32, device=dev).view(n, 4)
         per = (n + world - 1) // world
