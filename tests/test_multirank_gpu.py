@@ -64,3 +64,60 @@ def test_two_ranks_on_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert results == [(0, True, True), (1, True, True)]
+
+
+def _select_worker(rank, world, port, tmp, q):
+    """Both ranks run the whole SpatialTemporalFeatureSelector selection (as bench.py does under
+    torch.distributed): geodesic map prefetched on a side stream with its rows sharded + gathered,
+    feature map row-sharded + gathered, greedy replicated."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import random
+        from al3d.selectors import build_selector
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        cfg = dict(type="SpatialTemporalFeatureSelector", budget=120, buffer_file=os.path.join(tmp, "buffer.json"),
+                   infos_origin=os.path.join(tmp, "infos.pkl"), logs_file=os.path.join(tmp, "log.json"),
+                   buffer_path=os.path.join(tmp, "feats.pt"), distance_store_file=None, pred=False)
+        random.seed(3407)
+        sel = build_selector(cfg)
+        sel.prefetch_spatial_map(dev)                 # what _SweepMixin.buffer_pred does before the sweep
+        sel.select_samples(local_rank=0)
+        q.put((rank, sel.selected_index[sel.current_budget]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_selection_equals_oracle(oracle, tmp_path):
+    import json
+    import pickle
+    import random
+    from al3d import synthetic
+    tmp = str(tmp_path)
+    infos, logs = synthetic.make_pool(110, seed=4)                  # N = 4400 -> sharded maps
+    n = len(infos)
+    feats = synthetic.make_embeddings(n, seed=2, scale=0.01)[:, :64].copy()
+    pickle.dump(infos, open(os.path.join(tmp, "infos.pkl"), "wb"))
+    json.dump(logs, open(os.path.join(tmp, "log.json"), "w"))
+    json.dump({"0": []}, open(os.path.join(tmp, "buffer.json"), "w"))
+    torch.save(torch.from_numpy(feats), os.path.join(tmp, "feats.pt"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_select_worker, args=(r, 2, port, tmp, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfgm, run_id, n_boxes = synthetic.pool_arrays(infos)
+    xy = np.stack([(-(c[:3, 3].T @ c[:3, :3]))[:2] for c in cfgm])
+    random.seed(3407)
+    first = random.choice(range(n))
+    D = oracle.combine(n, spatial=oracle.spatial_map(xy, 8), temporal_id=run_id, feat=oracle.l1_map_f32(feats, 2),
+                       normalize="exp", aggregate="sum", lambda_t=1.0, lambda_f=1.0)
+    rc, picks = oracle.greedy(D, [], first, np.array([int(b) * 0.04 for b in n_boxes]), 0.12, 0.0, 120.0)
+    assert rc == 0
+    assert results[0] == picks.tolist() and results[1] == picks.tolist()
