@@ -87,24 +87,6 @@ class ConvTimer:
         model.neck.forward = neck
         model.bbox_head.forward = head
 
-    @staticmethod
-    def isolated(timer, model, loader, dev, batches=4):
-        """Neck+head regions of a few batches with the two-stream pipeline off (nothing else runs)."""
-        from al3d.sweep import example_to_device
-        saved = (timer.pairs, timer.launches, timer.frames)
-        timer.pairs, timer.launches, timer.frames = [], 0, 0
-        timer.enabled = True
-        with torch.no_grad():
-            for i, data_batch in enumerate(loader):
-                if i >= batches:
-                    break
-                model(example_to_device(data_batch, dev), return_loss=False, estimate=True)
-        torch.cuda.synchronize()
-        timer.enabled = False
-        res = timer.result()
-        timer.pairs, timer.launches, timer.frames = saved
-        return res
-
     def result(self):
         if not self.pairs:
             return None
@@ -286,14 +268,6 @@ def main():
                                 + ("; the sparse half of the next batch runs concurrently on a second "
                                    "stream (AL3D_PIPELINE=1), so these durations include that contention"
                                    if _sweep.PIPELINE else ""))
-            if _sweep.PIPELINE:
-                # the same kernels with nothing else on the device: a short serial pass (untimed,
-                # after the timed region) so the kernel's own roofline fraction is visible too
-                iso = ConvTimer.isolated(timer, model, loader, dev, batches=4)
-                if iso:
-                    roof["isolated"] = {k: iso[k] for k in ("achieved", "frac", "executed_tflops", "avg_launch_us")
-                                        if k in iso}
-                    roof["isolated"]["note"] = "4 batches, pipeline off, same process, after the timed steps"
             out["roofline"] = roof
         if not args.no_verify:
             out["selected_equals_oracle"] = verify_selection(infos, state["feats"], state["selected"])
