@@ -45,6 +45,13 @@ class PoolFrames:
         return cls(frames)
 
     @classmethod
+    def from_files(cls, infos, device, nsweeps=10, root=None):
+        """Real nuScenes frames: raw sweep files -> pinned staging -> device merge kernel (a1)."""
+        from .nusc_files import load_frame_points_device
+        frames = [load_frame_points_device(info, device, nsweeps=nsweeps, root=root) for info in infos]
+        return cls(frames, tokens=[str(i.get("token", f"frame{k:06d}")) for k, i in enumerate(infos)])
+
+    @classmethod
     def from_numpy(cls, arrays, device):
         return cls([torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
                     for a in arrays])

@@ -48,6 +48,8 @@ SIGNATURES = {
     "al3d_apsp_workspace_bytes": (c_i64, [c_i64, c_int]),
     "al3d_apsp_knn_f64": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p, c_p]),
     "al3d_apsp_knn_rows_f64": (c_int, [c_p, c_p, c_i64, c_int, c_i64, c_i64, c_p, c_p, c_p]),
+    "al3d_merge_sweeps_workspace_bytes": (c_i64, [c_i64]),
+    "al3d_merge_sweeps_f32": (c_int, [c_p, c_p, c_int, c_i64, c_p, c_p, c_p, ctypes.c_float, c_p, c_p, c_p, c_p]),
     "al3d_voxelize_grid_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "al3d_voxelize_grid_init": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p]),
     "al3d_voxelize_workspace_bytes": (c_i64, [c_i64, c_int, c_int]),

@@ -144,6 +144,27 @@ int al3d_apsp_knn_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int 
 int al3d_apsp_knn_rows_f64(const double* knn_d, const int64_t* knn_i, int64_t n, int kq,
                            int64_t row0, int64_t nrows, double* out, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------- detector: sweep merge (a1) */
+
+/* One frame's point cloud from its key-frame file and sweep files, on device.  Replaces read_file /
+ * remove_close / read_sweep / LoadPointCloudFromFile.__call__ (NuScenesDataset branch)
+ * (det3d/datasets/pipelines/loading.py:17-63,98-126).
+ *   raw        [total_rows, 5] f32 rows (x, y, z, intensity, ring) of all files back to back;
+ *              file f owns rows [file_off[f], file_off[f+1]) (file_off: nfiles+1 int64, device)
+ *   file 0     is the key frame: kept whole, not moved, time 0
+ *   file f>0   drops points with |x| < min_distance && |y| < min_distance (in the sweep's own
+ *              frame), then, if has_xform[f], is moved by xform[12*f .. 12*f+12) = the first three
+ *              rows of the reference's float64 transform_matrix (row-major 3x4), evaluated as
+ *              ((T0*x + T1*y) + T2*z) + T3 in float64 and rounded once to float32; its points get
+ *              time = (float)time_lag[f]
+ *   out        [<= total_rows, 5] f32 (x, y, z, intensity, dt), file order then point order
+ *   out_count  rows written (device int)
+ *   workspace  >= al3d_merge_sweeps_workspace_bytes(total_rows) */
+int64_t al3d_merge_sweeps_workspace_bytes(int64_t total_rows);
+int al3d_merge_sweeps_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                          const double* xform, const unsigned char* has_xform, const double* time_lag,
+                          float min_distance, float* out, int* out_count, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------- detector: voxelize */
 
 /* Voxelise a batch of point clouds and reduce each voxel to its mean point (VFE).

@@ -267,3 +267,32 @@ int64_t al3d_oracle_rotate_nms(const float* dets, int64_t n, float thresh, int64
     free(cx); free(cy); free(sb); free(sup);
     return kept;
 }
+
+/* ---------------------------------------------------------------- a1: sweep merge
+ * CPU restatement of read_file / remove_close / read_sweep / LoadPointCloudFromFile.__call__
+ * (det3d/datasets/pipelines/loading.py:17-63,98-126); same argument meaning as
+ * al3d_merge_sweeps_f32 (include/al3d.h).  Returns the number of rows written. */
+int64_t al3d_oracle_merge_sweeps(const float* raw, const int64_t* file_off, int nfiles,
+                                 const double* xform, const unsigned char* has_xform,
+                                 const double* time_lag, float min_distance, float* out)
+{
+    int64_t n = 0;
+    for (int f = 0; f < nfiles; ++f) {
+        for (int64_t i = file_off[f]; i < file_off[f + 1]; ++i) {
+            float x = raw[5 * i], y = raw[5 * i + 1], z = raw[5 * i + 2];
+            if (f > 0 && fabsf(x) < min_distance && fabsf(y) < min_distance) continue;
+            if (f > 0 && has_xform[f]) {
+                const double* t = xform + 12 * f;
+                const double xd = x, yd = y, zd = z;
+                const float nx = (float)(((t[0] * xd + t[1] * yd) + t[2] * zd) + t[3]);
+                const float ny = (float)(((t[4] * xd + t[5] * yd) + t[6] * zd) + t[7]);
+                const float nz = (float)(((t[8] * xd + t[9] * yd) + t[10] * zd) + t[11]);
+                x = nx; y = ny; z = nz;
+            }
+            float* o = out + 5 * n++;
+            o[0] = x; o[1] = y; o[2] = z; o[3] = raw[5 * i + 3];
+            o[4] = f == 0 ? 0.0f : (float)time_lag[f];
+        }
+    }
+    return n;
+}

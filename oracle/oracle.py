@@ -265,3 +265,23 @@ def frame_entropy(scores):
         return np.float32(np.nan)
     h = -s * np.log(s) - (np.float32(1.0) - s) * np.log(np.float32(1.0) - s)
     return h.astype(np.float32).mean(dtype=np.float32)
+
+
+def merge_sweeps(files, xforms, time_lags, min_distance=1.0):
+    """a1 restatement.  files: list of raw [p,5] f32 arrays (file 0 = key frame); xforms: list of
+    4x4 f64 or None; time_lags: list of float.  Returns the combined [P,5] f32 cloud."""
+    raw = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=np.float32).reshape(-1, 5) for f in files]))
+    off = np.zeros(len(files) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([np.asarray(f).reshape(-1, 5).shape[0] for f in files])
+    xf = np.zeros((len(files), 12), dtype=np.float64)
+    has = np.zeros(len(files), dtype=np.uint8)
+    for i, t in enumerate(xforms):
+        if t is not None:
+            xf[i] = np.asarray(t, dtype=np.float64)[:3, :].reshape(12)
+            has[i] = 1
+    tl = np.ascontiguousarray(np.asarray(time_lags, dtype=np.float64))
+    out = np.empty((raw.shape[0], 5), dtype=np.float32)
+    fn = lib().al3d_oracle_merge_sweeps
+    fn.restype = c_i64
+    n = fn(_p(raw), _p(off), c_int(len(files)), _p(xf), _p(has), _p(tl), ctypes.c_float(min_distance), _p(out))
+    return out[:n].copy()

@@ -89,7 +89,6 @@ def main():
     model = loader = None
     if args.pred:
         from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
-        from al3d.datasets.nusc_files import load_frame_points
         from al3d.models import build_detector
         dev = torch.device("cuda", local_rank)
         model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
@@ -109,8 +108,8 @@ def main():
         if args.synthetic_scenes:
             pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
         else:
-            pool = PoolFrames.from_numpy([load_frame_points(infos[i], cfg.nsweeps, cfg.data_root)
-                                          for i in mine], dev)
+            pool = PoolFrames.from_files([infos[i] for i in mine], dev, nsweeps=cfg.nsweeps,
+                                         root=cfg.data_root)
         anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
         loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
         loader.sampler = mine
