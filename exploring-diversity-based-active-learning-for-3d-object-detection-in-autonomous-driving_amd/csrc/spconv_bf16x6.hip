@@ -31,10 +31,8 @@ __global__ __launch_bounds__(256, 2) void sp_conv_bf16x6_kernel(const float* __r
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ residual, int relu,
-                                                                float* __restrict__ fout, int n_out, int n_in,
-                                                                int fmt)
+                                                                float* __restrict__ fout, int n_out)
 {
-    // fmt: bit0 input planes, bit1 output planes, bit2 residual planes (see spconv_wave.hip)
     constexpr int NP = COUT < 32 ? 32 : COUT;
     constexpr int WN = NP >= 128 ? 64 : 32;
     constexpr int WAVES_N = NP / WN;
@@ -102,7 +100,6 @@ __global__ __launch_bounds__(256, 2) void sp_conv_bf16x6_kernel(const float* __r
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[2];
-    uint2 rap[3][2];               // pre-split input: 4 bf16 per plane and pass
     uint4 rb[3][B_PASSES];
     int src[2], src_n[2];
     int cur_tap = -1, nxt_tap = -1;
@@ -122,21 +119,10 @@ __global__ __launch_bounds__(256, 2) void sp_conv_bf16x6_kernel(const float* __r
             const int ti = step / KCHUNKS + 1;
             if (ti < s_ntaps) { nxt_tap = s_taps[ti]; fetch_idx(nxt_tap, src_n); }
         }
-        if (fmt & 1) {
-            const int64_t pin = (int64_t)n_in * CIN;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    rap[pl][i] = src[i] >= 0 ? *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(fin) + pl * pin +
-                                                                              (int64_t)src[i] * CIN + c0 + 4 * aq)
-                                             : make_uint2(0u, 0u);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                ra[i] = src[i] >= 0 ? *reinterpret_cast<const float4*>(fin + (int64_t)src[i] * CIN + c0 + 4 * aq)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < 2; ++i)
+            ra[i] = src[i] >= 0 ? *reinterpret_cast<const float4*>(fin + (int64_t)src[i] * CIN + c0 + 4 * aq)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < B_PASSES; ++q) {
             const int piece = tid + 256 * q;          // piece -> (row n, half)
@@ -152,18 +138,13 @@ __global__ __launch_bounds__(256, 2) void sp_conv_bf16x6_kernel(const float* __r
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int off = (ar + 64 * i) * S6_LDB + 8 * aq;
-            if (fmt & 1) {
+            const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            bf16x4 h, m, l;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(&As[buf][pl][off]) = rap[pl][i];
-            } else {
-                const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-                bf16x4 h, m, l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; s6_split3(v[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
-                *reinterpret_cast<bf16x4*>(&As[buf][0][off]) = h;
-                *reinterpret_cast<bf16x4*>(&As[buf][1][off]) = m;
-                *reinterpret_cast<bf16x4*>(&As[buf][2][off]) = l;
-            }
+            for (int e = 0; e < 4; ++e) { __bf16 a, b, c; s6_split3(v[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
+            *reinterpret_cast<bf16x4*>(&As[buf][0][off]) = h;
+            *reinterpret_cast<bf16x4*>(&As[buf][1][off]) = m;
+            *reinterpret_cast<bf16x4*>(&As[buf][2][off]) = l;
         }
 #pragma unroll
         for (int q = 0; q < B_PASSES; ++q) {
@@ -226,20 +207,10 @@ __global__ __launch_bounds__(256, 2) void sp_conv_bf16x6_kernel(const float* __r
                 const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (row >= n_out) continue;
                 float v = acc[i][j][r] * sc + sh;
-                const int64_t o = (int64_t)row * COUT + n, pout = (int64_t)n_out * COUT;
-                if (residual) {
-                    if (fmt & 4) {
-                        const __bf16* rp = reinterpret_cast<const __bf16*>(residual) + o;
-                        v += ((float)rp[0] + (float)rp[pout]) + (float)rp[2 * pout];
-                    } else v += residual[o];
-                }
+                const int64_t o = (int64_t)row * COUT + n;
+                if (residual) v += residual[o];
                 if (relu) v = v > 0.f ? v : 0.f;
-                if (fmt & 2) {
-                    __bf16* op = reinterpret_cast<__bf16*>(fout) + o;
-                    __bf16 h, m, l;
-                    s6_split3(v, h, m, l);
-                    op[0] = h; op[pout] = m; op[2 * pout] = l;
-                } else fout[o] = v;
+                fout[o] = v;
             }
         }
     }
@@ -249,15 +220,15 @@ __global__ __launch_bounds__(256, 2) void sp_conv_bf16x6_kernel(const float* __r
     if (cin == CI && cout == CO) {                                                                    \
         hipLaunchKernelGGL((sp_conv_bf16x6_kernel<CI, CO>), dim3((unsigned)al3d_cdiv(n_out, S6_BM)),   \
                            dim3(256), 0, s, fin, nbr, K, (const __bf16*)wgt_bf16x3, scale, shift,     \
-                           residual, relu, fout, n_out, n_in, fmt);                                   \
+                           residual, relu, fout, n_out);                                   \
         AL3D_CHECK_LAUNCH("sp_conv_bf16x6_kernel");                                                   \
         return AL3D_OK;                                                                               \
     }
 
 extern "C" int al3d_sp_conv_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3,
                                    int cin, int cout, const float* scale, const float* shift,
-                                   const float* residual, int relu, float* fout, int n_out, int n_in,
-                                   int fmt, void* stream)
+                                   const float* residual, int relu, float* fout, int n_out,
+                                   void* stream)
 {
     AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_bf16x6: bad sizes");
     if (n_out == 0) return AL3D_OK;

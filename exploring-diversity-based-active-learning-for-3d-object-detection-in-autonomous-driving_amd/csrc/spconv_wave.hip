@@ -58,11 +58,8 @@ __global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restri
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ residual, int relu,
-                                                           float* __restrict__ fout, int n_out, int n_in,
-                                                           int fmt)
+                                                           float* __restrict__ fout, int n_out)
 {
-    // fmt bit0: fin is bf16 planes [3][n_in][CIN]; bit1: fout is bf16 planes [3][n_out][COUT];
-    // bit2: residual is bf16 planes [3][n_out][COUT]  (planes = exact x1+x2+x3 split, see al3d.h)
     constexpr int KG = CIN / 16;                         // 16-channel groups per offset
     constexpr int TN = (COUT + 31) / 32;                 // 32-wide output tiles per wave
     constexpr int NROWS = COUT;                          // weight rows per unit
@@ -156,26 +153,13 @@ __global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restri
                 src = my_row < n_out ? nbr[(int64_t)tap * n_out + my_row] : -1;
             }
             bf16x8 a0, a1, a2;
-            if (fmt & 1) {                                              // pre-split rows: pure loads
-                if (src >= 0) {
-                    const __bf16* rp = reinterpret_cast<const __bf16*>(fin) + (int64_t)src * CIN + 16 * g + 8 * fh;
-                    const int64_t pin = (int64_t)n_in * CIN;
-                    a0 = *reinterpret_cast<const bf16x8*>(rp);
-                    a1 = *reinterpret_cast<const bf16x8*>(rp + pin);
-                    a2 = *reinterpret_cast<const bf16x8*>(rp + 2 * pin);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { a0[e] = (__bf16)0.f; a1[e] = (__bf16)0.f; a2[e] = (__bf16)0.f; }
-                }
-            } else {
-                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-                if (src >= 0) {
-                    const float* rp = fin + (int64_t)src * CIN + 16 * g + 8 * fh;
-                    lo = *reinterpret_cast<const float4*>(rp);
-                    hi = *reinterpret_cast<const float4*>(rp + 4);
-                }
-                sw_split8(lo, hi, a0, a1, a2);
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (src >= 0) {
+                const float* rp = fin + (int64_t)src * CIN + 16 * g + 8 * fh;
+                lo = *reinterpret_cast<const float4*>(rp);
+                hi = *reinterpret_cast<const float4*>(rp + 4);
             }
+            sw_split8(lo, hi, a0, a1, a2);
             const unsigned char* ub = &Ws[buf][(unit - u0) * UNIT_BYTES];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -207,21 +191,10 @@ __global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restri
             const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
             if (row >= n_out) continue;
             float v = acc[j][r] * sc + sh;
-            const int64_t o = (int64_t)row * COUT + n, pout = (int64_t)n_out * COUT;
-            if (residual) {
-                if (fmt & 4) {
-                    const __bf16* rp = reinterpret_cast<const __bf16*>(residual) + o;
-                    v += ((float)rp[0] + (float)rp[pout]) + (float)rp[2 * pout];   // exact x1+x2+x3
-                } else v += residual[o];
-            }
+            const int64_t o = (int64_t)row * COUT + n;
+            if (residual) v += residual[o];
             if (relu) v = v > 0.f ? v : 0.f;
-            if (fmt & 2) {
-                __bf16* op = reinterpret_cast<__bf16*>(fout) + o;
-                const __bf16 h = (__bf16)v;
-                const float r1 = v - (float)h;
-                const __bf16 m = (__bf16)r1;
-                op[0] = h; op[pout] = m; op[2 * pout] = (__bf16)(r1 - (float)m);
-            } else fout[o] = v;
+            fout[o] = v;
         }
     }
 }
@@ -453,10 +426,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4)))
 extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3,
                                          int cin, int cout, const float* scale, const float* shift,
                                          const float* residual, int relu, float* fout, int n_out,
-                                         int n_in, int fmt, void* stream)
+                                         void* stream)
 {
     AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_wave2_bf16x6: bad sizes");
-    AL3D_REQUIRE(fmt == 0, "al3d_sp_conv_wave2_bf16x6: f32 rows only");
     if (n_out == 0) return AL3D_OK;
     AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave2_bf16x6: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -469,7 +441,7 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
     if (cin == CI && cout == CO) {                                                                    \
         hipLaunchKernelGGL((sp_conv_wave_kernel<CI, CO>), dim3((unsigned)al3d_cdiv(n_out, SW_ROWS)),   \
                            dim3(256), 0, s, fin, nbr, K, (const __bf16*)wgt_bf16x3, scale, shift,     \
-                           residual, relu, fout, n_out, n_in, fmt);                                   \
+                           residual, relu, fout, n_out);                                   \
         AL3D_CHECK_LAUNCH("sp_conv_wave_kernel");                                                     \
         return AL3D_OK;                                                                               \
     }
@@ -477,7 +449,7 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
 extern "C" int al3d_sp_conv_wave_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3,
                                         int cin, int cout, const float* scale, const float* shift,
                                         const float* residual, int relu, float* fout, int n_out,
-                                        int n_in, int fmt, void* stream)
+                                        void* stream)
 {
     AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_wave_bf16x6: bad sizes");
     if (n_out == 0) return AL3D_OK;

@@ -46,10 +46,9 @@ def split_bf16x3(w_packed):
 # matrix cores (default), "f32" = fp32-input MFMA (bitwise an fp32 FMA chain).
 import os as _os
 MATH = _os.environ.get("AL3D_MATH", "bf16x6")
-# sparse-conv structure for the bf16x6 arithmetic: "wave" (A operand in registers, wave-autonomous)
-# or "tile" (LDS-staged 128-row tile); "auto" picks per layer
+# sparse-conv structure for the bf16x6 arithmetic: "auto" = the software-pipelined wave kernel;
+# "wave" (unpipelined wave kernel) and "tile" (LDS-staged 128-row tile) give the same bits, for A/B
 SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
-SP_PLANES = _os.environ.get("AL3D_SP_PLANES", "0") == "1"
 
 
 # ------------------------------------------------------------------ kernels
@@ -208,7 +207,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
         fn = {"bf16x6": "al3d_sp_conv_bf16x6", "wave": "al3d_sp_conv_wave_bf16x6",
               "wave2": "al3d_sp_conv_wave2_bf16x6"}[mfma]
         lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(w6), cin, cout, _ptr(scale),
-                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, n, 0, st)
+                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
     elif mfma:
         w_ock = w.permute(2, 0, 1).contiguous()          # [Cout, K, Cin]
         lib.call("al3d_sp_conv_mfma_f32", _ptr(feats), _ptr(nbr), K, _ptr(w_ock), cin, cout, _ptr(scale),

@@ -61,27 +61,12 @@ class SparseBasicBlock(nn.Module):
 
 
 class SparseTensor:
-    """Minimal stand-in for spconv.SparseConvTensor: features [N,C] f32, indices [N,4] i32.
-    Inside the encoder features may be held pre-split (bf16 planes [3,N,C]); ``features``
-    merges them back (exactly) on first access."""
+    """Minimal stand-in for spconv.SparseConvTensor: features [N,C] f32, indices [N,4] i32."""
 
     def __init__(self, features, indices, spatial_shape, batch_size):
-        self._f = features
+        self.features = features
         self.indices = indices
         self.spatial_shape, self.batch_size = list(spatial_shape), batch_size
-
-    @property
-    def features(self):
-        if self._f.dtype == torch.bfloat16:
-            pl = self._f.contiguous()
-            out = torch.empty(pl.shape[1:], dtype=torch.float32, device=pl.device)
-            lib.call("al3d_merge_bf16x3", _ptr(pl), out.numel(), _ptr(out), _stream())
-            self._f = out
-        return self._f
-
-    @features.setter
-    def features(self, v):
-        self._f = v
 
 
 def _bn(c):
@@ -163,34 +148,18 @@ class _SparseEncoderBase(nn.Module):
 
     @staticmethod
     def _conv(m, feats, nbr, K, step, residual, out, n, st):
-        """One fused sparse layer.  Tensors of dtype bfloat16 are pre-split planes [3,n,C]."""
-        fmt = 0
-        n_in = feats.shape[-2]
-        if feats.dtype == torch.bfloat16:
-            fmt |= 1
-        if out.dtype == torch.bfloat16:
-            fmt |= 2
-        if residual is not None and residual.dtype == torch.bfloat16:
-            fmt |= 4
+        """One fused sparse layer (conv + folded BN + optional residual + ReLU)."""
         res_ptr = None if residual is None else _ptr(residual)
         cin = feats.shape[-1]                    # == m.in_channels, or 16 for a zero-padded narrow first layer
         mfma_pair = (cin, m.out_channels) in MFMA_PAIRS
-        if fmt or (mfma_pair and step["w"].dtype == torch.bfloat16):
+        if mfma_pair and step["w"].dtype == torch.bfloat16:
             # bf16x6 arithmetic.  Measured per channel pair on the real rulebooks
             # (tools/bench_splayers.py): the software-pipelined wave kernel wins everywhere;
-            # AL3D_SPCONV=wave|tile selects the older structures (planes mode needs them).
-            if fmt or D.SPCONV == "wave":
-                fn = "al3d_sp_conv_wave_bf16x6"
-                if D.SPCONV == "tile" or (fmt and D.SPCONV == "auto" and m.out_channels > 64):
-                    fn = "al3d_sp_conv_bf16x6"
-            elif D.SPCONV == "tile":
-                fn = "al3d_sp_conv_bf16x6"
-            else:
-                fn = "al3d_sp_conv_wave2_bf16x6"
-            lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), cin, m.out_channels,
-                     _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, n_in, fmt, st)
-            return
-        fn = "al3d_sp_conv_mfma_f32" if mfma_pair else "al3d_sp_conv_f32"
+            # AL3D_SPCONV=wave|tile selects the older structures (same results bit for bit).
+            fn = {"wave": "al3d_sp_conv_wave_bf16x6", "tile": "al3d_sp_conv_bf16x6"}.get(
+                D.SPCONV, "al3d_sp_conv_wave2_bf16x6")
+        else:
+            fn = "al3d_sp_conv_mfma_f32" if mfma_pair else "al3d_sp_conv_f32"
         lib.call(fn, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), cin, m.out_channels,
                  _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, st)
 
@@ -224,25 +193,8 @@ class _SparseEncoderBase(nn.Module):
         nbr, nbr_key = None, None
         middle = []
         identity = None
-        # Optional: keep activations pre-split (bf16 planes) between sparse layers so the split
-        # happens once per element instead of once per gather.  Measured SLOWER on MI355X (2-byte
-        # plane stores in the epilogue + 1.5x gather bytes: 764 vs 848 frames/s), so it is off
-        # unless AL3D_SP_PLANES=1; the last layer always writes f32 for dense().
-        planes = D.MATH == "bf16x6" and D.SP_PLANES
-        convs = [s_ for s_ in self._plan if s_["kind"] != "stage_end"]
-        last = convs[-1]
-
         def new_out(rows, m, step):
-            ok = planes and step is not last and (m.in_channels, m.out_channels) in MFMA_PAIRS
-            if ok:
-                return torch.empty((3, rows, m.out_channels), dtype=torch.bfloat16, device=dev)
             return torch.empty((rows, m.out_channels), dtype=torch.float32, device=dev)
-
-        def as_input(t, m):
-            """f32 rows feeding an MFMA layer in planes mode are split once here (first layer)."""
-            if planes and t.dtype != torch.bfloat16 and (m.in_channels, m.out_channels) in MFMA_PAIRS:
-                return D.split_bf16x3(t)
-            return t
 
         for step in self._plan:
             if step["kind"] == "stage_end":
@@ -259,7 +211,6 @@ class _SparseEncoderBase(nn.Module):
                     nbr_key = key
                 if feats.shape[-1] != self._pad_cin(m) and feats.dtype == torch.float32:
                     feats = torch.nn.functional.pad(feats, (0, self._pad_cin(m) - feats.shape[-1]))
-                feats = as_input(feats, m)
                 if step.get("block_start"):
                     identity = feats
                 out = new_out(n, m, step)
@@ -282,7 +233,6 @@ class _SparseEncoderBase(nn.Module):
                 dnbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
                 lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
                          lv.W, _ptr(lv.grid), _ptr(dnbr), st)
-                feats = as_input(feats, m)
                 out = new_out(n_out, m, step)
                 self._conv(m, feats, dnbr, K, step, None, out, n_out, st)
                 feats, coords, n, shape, lv = out, ocoords, n_out, oshape, olv

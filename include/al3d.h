@@ -263,32 +263,25 @@ int al3d_sp_conv_mfma_f32(const float* fin, const int* nbr, int K, const float* 
                           int relu, float* fout, int n_out, void* stream);
 /* fp32-faithful bf16x6 variant (see al3d_conv2d_nhwc_bf16x6): weights = al3d_split_bf16x3 of
  * the [Cout, K, Cin] packing; same channel pairs as the fp32-MFMA entry point plus 16->16.
- * Feature formats (`fmt` bits): activations may stay pre-split between sparse layers -- bf16
- * planes [3][n][C] (hi, mid, lo; x = (x1+x2)+x3 exactly) instead of f32 [n][C] -- so the split is
- * done once by the producing layer's epilogue instead of once per (row, offset) gather.
- * bit0: fin is planes [3][n_in][cin]; bit1: fout is planes [3][n_out][cout]; bit2: residual is
- * planes [3][n_out][cout].  fmt = 0 is plain f32 everywhere. */
-#define AL3D_FMT_IN_PLANES 1
-#define AL3D_FMT_OUT_PLANES 2
-#define AL3D_FMT_RES_PLANES 4
+ * Three kernel structures, one arithmetic (the MFMA sequence per output element is the same, so
+ * their results are bit-identical):
+ *   al3d_sp_conv_bf16x6        128-row LDS-staged tile (gathered rows split into LDS like a dense GEMM)
+ *   al3d_sp_conv_wave_bf16x6   each wave owns 32 output rows and all output channels; gathered rows
+ *                              go straight into its MFMA fragments, only weight slabs pass through LDS
+ *   al3d_sp_conv_wave2_bf16x6  the wave kernel with a software-pipelined gather (register ring of
+ *                              neighbour indices 2P units ahead and row fragments P units ahead,
+ *                              branch-free loads, XCD-contiguous tiles) -- the encoder's default. */
 int al3d_sp_conv_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                         int cout, const float* scale, const float* shift, const float* residual,
-                        int relu, float* fout, int n_out, int n_in, int fmt, void* stream);
-/* planes [3][count] bf16 -> f32 [count], exact (inverse of al3d_split_bf16x3) */
-int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void* stream);
-/* Same arithmetic and weight packing as al3d_sp_conv_bf16x6, different structure: each wave owns
- * 32 output rows and all output channels, the gathered rows go straight into its MFMA fragments
- * (no LDS staging of activations), only weight slabs are shared through LDS.  The encoder's
- * default for the bf16x6 arithmetic. */
+                        int relu, float* fout, int n_out, void* stream);
 int al3d_sp_conv_wave_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                              int cout, const float* scale, const float* shift, const float* residual,
-                             int relu, float* fout, int n_out, int n_in, int fmt, void* stream);
-/* al3d_sp_conv_wave_bf16x6 with a software-pipelined gather: every wave keeps a register ring of
- * neighbour indices (2P units ahead) and gathered row fragments (P units ahead) in flight while it
- * multiplies.  f32 rows only (fmt must be 0); results are bit-identical to the unpipelined kernel. */
+                             int relu, float* fout, int n_out, void* stream);
 int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                               int cout, const float* scale, const float* shift, const float* residual,
-                              int relu, float* fout, int n_out, int n_in, int fmt, void* stream);
+                              int relu, float* fout, int n_out, void* stream);
+/* planes [3][count] bf16 -> f32 [count], exact (inverse of al3d_split_bf16x3) */
+int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
  * out must be zero-filled. */
 int al3d_sp_to_dense_nhwc(const float* feat, const int* coords, int n, int C, int B, int D, int H,

@@ -45,7 +45,7 @@ for (m, feats, nbr, K, step, residual, n) in calls:
         out = torch.empty((n, co), device=dev)
         def call():
             lib.call(f, _ptr(feats), _ptr(nbr), K, _ptr(step["w"]), ci, co, _ptr(step["scale"]), _ptr(step["shift"]),
-                     None if residual is None else _ptr(residual), 1, _ptr(out), n, feats.shape[-2], 0, _stream())
+                     None if residual is None else _ptr(residual), 1, _ptr(out), n, _stream())
         try:
             call()
         except lib.Al3dError as e:
