@@ -281,6 +281,42 @@ def test_detector_batch_invariance_and_determinism():
         assert p["metadata"]["token"].startswith("frame")
 
 
+def test_full_size_frames_kernel_structures_and_pipeline_agree():
+    """BASELINE-size inputs (10-sweep ~250k-point frames, 60k-voxel cap): properties that need no
+    oracle at this size -- the three sparse-conv kernel structures give bit-identical embeddings,
+    the two-stream batch pipeline gives the same bits as the serial sweep, and the sweep is
+    invariant to the batch size."""
+    from al3d import detector_ops as D, sweep as S, synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    pool = PoolFrames.from_synthetic(6, DEV, num_base=3, seed=7)
+    assert min(f.shape[0] for f in pool.frames) > 200000
+
+    def run(batch):
+        return S.sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch, device=DEV),
+                                  DEV, len(pool))
+    saved = (D.SPCONV, S.PIPELINE)
+    try:
+        ref = run(4)
+        assert ref.shape == (6, 512) and torch.isfinite(ref).all()
+        assert torch.equal(run(3), ref)
+        for mode in ("wave", "tile"):
+            D.SPCONV = mode
+            assert torch.equal(run(4), ref), mode
+        D.SPCONV = saved[0]
+        S.PIPELINE = True
+        assert torch.equal(run(2), ref)
+    finally:
+        D.SPCONV, S.PIPELINE = saved
+
+
 def test_uncertainty_sweeps_compose(oracle, tmp_path):
     """pred=True paths of Entropy / Badge / UWE: the swept quantities must equal what the
     reference expressions give on the detector's own outputs (entropy from the post-NMS scores,
