@@ -31,12 +31,17 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def l1_distance(feats, p=2):
-    """[N,C] f32 embeddings -> [N,N] f32 L1 map (feature_selector.py:87-109)."""
+def l1_distance(feats, p=2, shard=True):
+    """[N,C] f32 embeddings -> [N,N] f32 L1 map (feature_selector.py:87-109).
+
+    Under torch.distributed (and ``shard``) this is a COLLECTIVE: every rank computes one block of
+    rows and the blocks are all-gathered, so every rank must call it.  ``shard=False`` computes the
+    whole map locally (what a rank-0-only checker needs)."""
     import torch.distributed as dist
     feats = _dev(feats, torch.float32, "feats")
     n, c = feats.shape
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or n < SHARD_MIN_ROWS:
+    if (not shard or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1
+            or n < SHARD_MIN_ROWS):
         out = torch.empty((n, n), dtype=torch.float32, device=feats.device)
         lib.call("al3d_l1_distance_f32", _ptr(feats), n, c, int(p), _ptr(out), _stream())
         return out
@@ -111,7 +116,8 @@ def spatial_map(xy, k=8):
     """kNN(k)-graph geodesic map, f64 [N,N] (spatial_temporal_selector.py:92-104).
 
     Under torch.distributed the N source rows are sharded over the ranks (each computes a
-    contiguous block) and all-gathered -- the sweeps are independent per source."""
+    contiguous block) and all-gathered -- the sweeps are independent per source.  That makes this a
+    COLLECTIVE (every rank must call it); ``knn_2d`` + ``apsp_knn`` is the local form."""
     import torch.distributed as dist
     d, i = knn_2d(xy, k + 1)
     n = d.shape[0]
