@@ -210,7 +210,7 @@ __device__ __attribute__((aligned(256))) float g_sw_zero[128];   // stays zero: 
 __device__ int g_sw_neg1 = -1;                                    // "no neighbour" for masked index loads
 
 template <int CIN, int COUT, int NW, int UPS, int P>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 4))) void sp_conv_wave2_kernel(const float* __restrict__ fin,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8))) void sp_conv_wave2_kernel(const float* __restrict__ fin,
                                                             const int* __restrict__ nbr, int K,
                                                             const __bf16* __restrict__ wgt,   // [3][COUT][K][CIN]
                                                             const float* __restrict__ scale,
