@@ -79,7 +79,8 @@ SIGNATURES = {
     "al3d_merge_bf16x3": (c_int, [c_p, c_i64, c_p, c_p]),
     "al3d_sp_to_dense_nhwc": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_head_decode_nms": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                     c_flt, c_flt, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+                                     c_flt, c_flt, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "al3d_head_decode_nms_workspace_bytes": (c_i64, [c_int, c_int, c_p]),
     "al3d_box_decode_f32": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
     "al3d_vfe_mean_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
     "al3d_conv2d_nhwc_f32": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p]),

@@ -194,13 +194,16 @@ class MultiGroupHead(nn.Module):
             fused.record_stream(self._side)
             for a in a_dev:
                 a.record_stream(self._side)
+            task_a = IntA(*[a.shape[0] for a in a_dev])
+            ws = torch.empty(lib.load().al3d_head_decode_nms_workspace_bytes(B, nt, task_a), dtype=torch.uint8,
+                             device=dev)
             lib.call("al3d_head_decode_nms", _ptr(fused), B, H * W, CH, nt,
                      (ctypes.c_void_p * nt)(*[a.data_ptr() for a in a_dev]),
-                     IntA(*[a.shape[0] for a in a_dev]), IntA(*self.num_anchor_per_locs),
+                     task_a, IntA(*self.num_anchor_per_locs),
                      IntA(*self.num_classes), IntA(*self._box_off), IntA(*self._cls_off), IntA(*label_off),
                      float(test_cfg["score_threshold"]), float(nms["nms_iou_threshold"]),
                      int(nms["nms_pre_max_size"]), post, (ctypes.c_float * 6)(*[float(v) for v in rng]),
-                     _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), self._side.cuda_stream)
+                     _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), _ptr(ws), self._side.cuda_stream)
             done = torch.cuda.Event()
             done.record(self._side)
         meta = example.get("metadata") or [None] * B

@@ -212,7 +212,11 @@ int al3d_head_decode_nms(const float* hout, int B, int HW, int CH, int ntasks,
                          const int* task_nc, const int* box_off, const int* cls_off,
                          const int* label_off, float score_thresh, float iou_thresh, int pre_max,
                          int post_max, const float* range6, float* boxes, float* scores, int* labels,
-                         int* counts, void* stream);
+                         int* counts, void* workspace, void* stream);
+/* workspace of al3d_head_decode_nms: one 32-bit score word per (sample, task, anchor); a whole-GPU
+ * pre-pass fills it so that the per-(sample, task) workgroups stream compact scores instead of
+ * re-reading the strided head output in every select pass.  task_A: host array [ntasks]. */
+int64_t al3d_head_decode_nms_workspace_bytes(int B, int ntasks, const int* task_A);
 
 /* Residual box decode (9-dim boxes, vector-encoded angle): enc [n,10], anchors [n,9] -> [n,9].
  * Replaces GroundBox3dCoderTorch.decode_torch -> second_box_decode
