@@ -10,8 +10,9 @@ from .feature_selectors import (FeatureSelector, SpatialFeatureSelector,
                                 SpatialTemporalFeatureSelector)
 
 from .uncertainty_selectors import EntropySelector, BadgeSelector, UWESelector, PPALSelector
+from .cald_selector import CaldSelector
 
-__all__ = ["EntropySelector", "BadgeSelector", "UWESelector", "PPALSelector","BaseSelector", "RandomSelector", "SpatialSelector", "EuSpatialSelector",
+__all__ = ["EntropySelector", "BadgeSelector", "UWESelector", "PPALSelector", "CaldSelector", "BaseSelector", "RandomSelector", "SpatialSelector", "EuSpatialSelector",
            "TemporalSelector", "SpatialTemporalSelector", "FeatureSelector",
            "SpatialFeatureSelector", "SpatialTemporalFeatureSelector",
            "SELECTORS", "build_selector"]

@@ -140,3 +140,30 @@ def test_real_file_loader_rules(tmp_path):
     assert np.all(pts[50:85, 4] == np.float32(0.05)) and np.all(pts[85:, 4] == np.float32(0.1))
     with pytest.raises(AssertionError):
         load_frame_points(info, nsweeps=10, root=str(tmp_path))
+
+
+def test_cald_selector_replays_reference_golden(tmp_path):
+    """CaldSelector is host-only list logic; golden from the reference class (oracle/gen_golden_cald.py)."""
+    import pickle
+    from al3d import synthetic
+    from al3d.selectors import build_selector
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "selector_cald_seeded.npz"), allow_pickle=False)
+    infos, _ = synthetic.make_pool(int(z["pool_scenes"]), seed=int(z["pool_seed"]))
+    assert [len(i["gt_names"]) for i in infos] == z["n_boxes"].tolist()
+    ip, bp, sp, jp = (str(tmp_path / f) for f in ("infos.pkl", "buffer.json", "sorted.json", "jsdiv.pkl"))
+    pickle.dump(infos, open(ip, "wb"))
+    open(bp, "w").write(str(z["buffer_json"]))
+    json.dump(z["sorted_idx"].tolist(), open(sp, "w"))
+    pickle.dump(dict(zip(z["jsdiv_keys"].tolist(), z["jsdiv_vals"].tolist())), open(jp, "wb"))
+    sel = build_selector(dict(type="CaldSelector", budget=int(z["budget"]), buffer_file=bp, infos_origin=ip,
+                              buffer_path=sp, jsdiv_path=jp))
+    sel.select_samples(local_rank=0)
+    assert sel.current_budget == str(z["current_budget"])
+    assert sel.selected_index[sel.current_budget] == z["selected"].tolist()
+    # the same ranking as JSON
+    jj = str(tmp_path / "jsdiv.json")
+    json.dump({str(k): v for k, v in zip(z["jsdiv_keys"].tolist(), z["jsdiv_vals"].tolist())}, open(jj, "w"))
+    sel2 = build_selector(dict(type="CaldSelector", budget=int(z["budget"]), buffer_file=bp, infos_origin=ip,
+                               buffer_path=sp, jsdiv_path=jj))
+    sel2.select_samples(local_rank=0)
+    assert sel2.selected_index[sel2.current_budget] == z["selected"].tolist()
