@@ -65,7 +65,7 @@ def main():
                sorted_idx=np.array(sorted_idx, dtype=np.int64), jsdiv_keys=np.array(jsdiv_keys, dtype=np.int64),
                jsdiv_vals=np.array(jsdiv_vals, dtype=np.float64), current_budget=np.array(key),
                selected=np.array(selected, dtype=np.int64), pool_seed=np.int64(21), pool_scenes=np.int64(8))
-    path = os.path.join(ROOT, "tests", "golden", "selector_cald_seeded.npz")
+    path = os.path.join(ROOT, "tests", "golden", "cald_seeded.npz")
     np.savez_compressed(path, **out)
     print("cald: key", key, "picked", len(selected), "first", selected[:8])
 

@@ -147,7 +147,7 @@ def test_cald_selector_replays_reference_golden(tmp_path):
     import pickle
     from al3d import synthetic
     from al3d.selectors import build_selector
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "selector_cald_seeded.npz"), allow_pickle=False)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cald_seeded.npz"), allow_pickle=False)
     infos, _ = synthetic.make_pool(int(z["pool_scenes"]), seed=int(z["pool_seed"]))
     assert [len(i["gt_names"]) for i in infos] == z["n_boxes"].tolist()
     ip, bp, sp, jp = (str(tmp_path / f) for f in ("infos.pkl", "buffer.json", "sorted.json", "jsdiv.pkl"))
