@@ -167,3 +167,16 @@ def test_cald_selector_replays_reference_golden(tmp_path):
                                buffer_path=sp, jsdiv_path=jj))
     sel2.select_samples(local_rank=0)
     assert sel2.selected_index[sel2.current_budget] == z["selected"].tolist()
+
+
+def test_every_example_config_builds_its_selector_type():
+    """examples/active/cbgs_*.py mirror the reference's config names; each names a registered selector."""
+    import glob
+    from al3d.selectors import SELECTORS
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "active")
+    files = sorted(glob.glob(os.path.join(root, "cbgs_*.py")))
+    assert len(files) == 12
+    for f in files:
+        cfg = Config.fromfile(f)
+        assert cfg.selector["type"] in SELECTORS.module_dict, f
+        assert cfg.model["type"] == "FPNVoxelNet"
