@@ -64,10 +64,21 @@ nsweeps = 10
 data_root = "data/nuScenes"
 voxel_generator = dict(range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], voxel_size=[0.1, 0.1, 0.2],
                        max_points_in_voxel=10, max_voxel_num=60000)
+assigner = dict(box_coder=box_coder, target_assigner=target_assigner, out_size_factor=8, debug=False)
+val_preprocessor = dict(mode="val", shuffle_points=False, remove_environment=False,
+                        remove_unknown_examples=False)
+test_pipeline = [
+    dict(type="LoadPointCloudFromFile", dataset=dataset_type),
+    dict(type="LoadPointCloudAnnotations", with_bbox=True),
+    dict(type="Preprocess", cfg=val_preprocessor),
+    dict(type="Voxelization", cfg=voxel_generator),
+    dict(type="AssignTarget", cfg=assigner),
+    dict(type="Reformat"),
+]
 train_anno = "data/nuScenes/infos_train_10sweeps_withvelo.pkl"
 val_anno = "data/nuScenes/infos_val_10sweeps_withvelo.pkl"
 data = dict(samples_per_gpu=4, workers_per_gpu=4,
             val=dict(type=dataset_type, root_path=data_root, info_path=val_anno, test_mode=True,
-                     nsweeps=nsweeps, class_names=class_names))
+                     nsweeps=nsweeps, class_names=class_names, pipeline=test_pipeline))
 log_level = "INFO"
 work_dir = "work_dirs/cbgs_active"

@@ -1,4 +1,8 @@
 from .anchors import create_anchors_3d_range, generate_task_anchors
 from .pool import PoolFrames, DeviceSweepLoader
+from .pipelines import (PIPELINES, Compose, LoadPointCloudFromFile, LoadPointCloudAnnotations, Preprocess,
+                        Voxelization, AssignTarget, Reformat, SweepDataset, collate_device)
 
-__all__ = ["create_anchors_3d_range", "generate_task_anchors", "PoolFrames", "DeviceSweepLoader"]
+__all__ = ["create_anchors_3d_range", "generate_task_anchors", "PoolFrames", "DeviceSweepLoader", "PIPELINES",
+           "Compose", "LoadPointCloudFromFile", "LoadPointCloudAnnotations", "Preprocess", "Voxelization",
+           "AssignTarget", "Reformat", "SweepDataset", "collate_device"]

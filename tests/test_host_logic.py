@@ -180,3 +180,18 @@ def test_every_example_config_builds_its_selector_type():
         cfg = Config.fromfile(f)
         assert cfg.selector["type"] in SELECTORS.module_dict, f
         assert cfg.model["type"] == "FPNVoxelNet"
+
+
+def test_pipeline_registry_builds_the_reference_val_pipeline():
+    """PIPELINES holds the stage names of the reference's test_pipeline; construction needs no GPU."""
+    from al3d.datasets import PIPELINES, Compose, SweepDataset
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "active")
+    cfg = Config.fromfile(os.path.join(root, "cbgs_spatial_temporal.py"))
+    names = [t["type"] for t in cfg.test_pipeline]
+    assert names == ["LoadPointCloudFromFile", "LoadPointCloudAnnotations", "Preprocess", "Voxelization",
+                     "AssignTarget", "Reformat"]
+    assert set(names) <= set(PIPELINES.module_dict)
+    ds = SweepDataset([{"lidar_path": "x", "sweeps": []}], cfg.data["val"]["pipeline"], nsweeps=cfg.nsweeps)
+    assert len(ds) == 1 and isinstance(ds.pipeline, Compose) and len(ds.pipeline.transforms) == 6
+    with pytest.raises(NotImplementedError):
+        Compose([dict(type="Preprocess", cfg=dict(mode="train"))])
