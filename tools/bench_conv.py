@@ -13,6 +13,8 @@ shapes = [  # H, Cin, Cout, k, s, p
 for (H, Cin, Cout, k, s, p) in shapes:
     x = torch.randn(B, H, H, Cin, device=dev)
     w = torch.randn(Cout, k * k, Cin, device=dev) * 0.05
+    if os.environ.get("AL3D_BENCH_ZERO") == "1":      # data-dependent power: all-zero operands toggle nothing
+        x.zero_(); w.zero_()
     if MODE == 'bf16x6':
         w = D.split_bf16x3(w)
     sc = torch.ones(Cout, device=dev); sh = torch.zeros(Cout, device=dev)
