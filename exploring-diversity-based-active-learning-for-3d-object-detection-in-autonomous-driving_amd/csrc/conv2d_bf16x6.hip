@@ -324,21 +324,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_halo_kernel(Conv6Params
             }
             if (tap == 8 && more) store_halo();                     // halo(chunk) was last read during tap 7
             {
-                // An A fragment (32 pixels x 16 channels) whose high plane is all zero is exactly zero
-                // (x1 = bf16(x) is zero only for x = 0): its twelve MFMAs add nothing and are skipped.
-                // The first neck layer reads the scattered sparse BEV map, where whole 32-pixel runs
-                // are empty; deeper layers almost never take the branch (two ballots per step).
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint4 hi = __builtin_bit_cast(uint4, fa[cs][0][i]);
-                    if (__ballot((hi.x | hi.y | hi.z | hi.w) != 0u) == 0ull) continue;   // wave-uniform
+                for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs][PA[t]][i], fb[cs][PB[t]][j], acc[i][j], 0, 0, 0);
-                }
             }
             if (has2) store_b((tap + 2) % 3);
             __syncthreads();

@@ -33,8 +33,9 @@ for name, coords, shape in levels:
         valid = (nbr >= 0)
         pad = (-n) % 32
         v = torch.nn.functional.pad(valid, (0, pad)).view(27, -1, 32).any(-1)
+        v16 = torch.nn.functional.pad(valid, (0, (-n) % 16)).view(27, -1, 16).any(-1)
         v128 = torch.nn.functional.pad(valid, (0, (-n) % 128)).view(27, -1, 128).any(-1)
-        print(f"{name} {tag:10s} n={n:7d} valid pairs {valid.float().mean():.3f}  non-empty 32-row x tap {v.float().mean():.3f}  128-row x tap {v128.float().mean():.3f}")
+        print(f"{name} {tag:10s} n={n:7d} valid pairs {valid.float().mean():.3f}  non-empty 16-row x tap {v16.float().mean():.3f}  32-row x tap {v.float().mean():.3f}  128-row x tap {v128.float().mean():.3f}")
     c = coords.contiguous()
     stats(table(c), "as-is")
     key = ((c[:, 0].long() * D + c[:, 1]) * H + c[:, 2]) * W + c[:, 3]
