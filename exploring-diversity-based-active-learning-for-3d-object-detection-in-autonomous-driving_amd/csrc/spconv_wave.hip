@@ -432,8 +432,8 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
     if (n_out == 0) return AL3D_OK;
     AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave2_bf16x6: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    SW2_DISPATCH(16, 16, 4, 4, 4) SW2_DISPATCH(16, 32, 4, 2, 2) SW2_DISPATCH(32, 32, 4, 2, 2) SW2_DISPATCH(32, 64, 4, 2, 4)
-    SW2_DISPATCH(64, 64, 4, 2, 4) SW2_DISPATCH(64, 128, 16, 2, 2) SW2_DISPATCH(128, 128, 16, 2, 2)
+    SW2_DISPATCH(16, 16, 4, 4, 4) SW2_DISPATCH(16, 32, 8, 2, 2) SW2_DISPATCH(32, 32, 8, 2, 2) SW2_DISPATCH(32, 64, 8, 4, 2)
+    SW2_DISPATCH(64, 64, 8, 4, 2) SW2_DISPATCH(64, 128, 16, 2, 2) SW2_DISPATCH(128, 128, 16, 2, 2)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_bf16x6: unsupported channel pair %d -> %d", cin, cout);
 }
 
