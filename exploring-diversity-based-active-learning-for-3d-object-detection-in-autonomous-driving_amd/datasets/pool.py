@@ -23,6 +23,20 @@ class PoolFrames:
     def __init__(self, frames, tokens=None):
         self.frames = frames
         self.tokens = tokens or [f"frame{i:06d}" for i in range(len(frames))]
+        self.flat = None            # optional: all frames back to back in one tensor (see pack())
+        self.offsets = None         # python list, len(frames) + 1
+
+    def pack(self):
+        """Store the frames back to back in one tensor (``frames`` become views of it) so that a batch
+        of consecutive frames is a slice instead of a ``torch.cat`` copy (160 MB per 32-frame batch)."""
+        if self.flat is None and len(self.frames) > 0:
+            counts = [int(f.shape[0]) for f in self.frames]
+            self.offsets = [0]
+            for c in counts:
+                self.offsets.append(self.offsets[-1] + c)
+            self.flat = torch.cat(self.frames, dim=0)
+            self.frames = [self.flat[self.offsets[i]:self.offsets[i + 1]] for i in range(len(counts))]
+        return self
 
     def __len__(self):
         return len(self.frames)
@@ -42,14 +56,14 @@ class PoolFrames:
             p[:, 0] = c * x - s * y + float(shift[i, 0])
             p[:, 1] = s * x + c * y + float(shift[i, 1])
             frames.append(p.contiguous())
-        return cls(frames)
+        return cls(frames).pack()
 
     @classmethod
     def from_files(cls, infos, device, nsweeps=10, root=None):
         """Real nuScenes frames: raw sweep files -> pinned staging -> device merge kernel (a1)."""
         from .nusc_files import load_frame_points_device
         frames = [load_frame_points_device(info, device, nsweeps=nsweeps, root=root) for info in infos]
-        return cls(frames, tokens=[str(i.get("token", f"frame{k:06d}")) for k, i in enumerate(infos)])
+        return cls(frames, tokens=[str(i.get("token", f"frame{k:06d}")) for k, i in enumerate(infos)]).pack()
 
     @classmethod
     def from_numpy(cls, arrays, device):
@@ -84,7 +98,11 @@ class DeviceSweepLoader:
             frames = [self.pool.frames[i] for i in ids]
             off = torch.tensor([0] + list(np.cumsum([f.shape[0] for f in frames])), dtype=torch.int64,
                                device=self.device)
-            pts = torch.cat(frames, dim=0) if len(frames) > 1 else frames[0]
+            consecutive = all(b == a + 1 for a, b in zip(ids[:-1], ids[1:]))
+            if self.pool.flat is not None and consecutive:
+                pts = self.pool.flat[self.pool.offsets[ids[0]]:self.pool.offsets[ids[-1] + 1]]
+            else:
+                pts = torch.cat(frames, dim=0) if len(frames) > 1 else frames[0]
             v = self.voxelizer(pts, off)
             B = len(ids)
             yield {
