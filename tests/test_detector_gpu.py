@@ -69,6 +69,26 @@ def test_sparse_conv_pipelined_kernel_is_bit_identical(cin, cout):
     assert np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("k,s,p,subm", [((1, 1, 3), (1, 1, 2), (0, 0, 0), False),     # BEVFusion-style conv_out
+                                        ((3, 3, 1), (1, 1, 1), (0, 0, 0), True),
+                                        ((1, 3, 3), (1, 2, 2), (0, 1, 1), False),
+                                        ((3, 3, 3), (1, 1, 1), (0, 0, 0), True),
+                                        ((2, 2, 2), (2, 2, 2), (0, 0, 0), False)])
+def test_sparse_conv_anisotropic_geometries(oracle, k, s, p, subm):
+    """Kernel/stride/padding combinations beyond the ones FPNSpMiddleResNetFHD uses (the rulebook and
+    the conv kernels are generic in them), 32 -> 64 channels on the default matrix-core path."""
+    from al3d import detector_ops as D
+    rng = np.random.default_rng(sum(k) * 7 + sum(s))
+    shape, batch = [7, 19, 23], 2
+    feats, coords = random_sparse(rng, batch, shape, 700, 32)
+    w = (rng.normal(size=(*k, 32, 64)) / np.sqrt(32 * np.prod(k))).astype(np.float32)
+    fo, co, oshape = oracle.spconv(feats, coords, batch, shape, w, k, s, p, subm)
+    got, gco, gshape = D.sparse_conv_layer(_t(feats), _t(coords), batch, shape, _t(w), k, s, p, subm, relu=False)
+    assert gshape == oshape and len(gco) == len(co)
+    np.testing.assert_allclose(to_dense(got.cpu().numpy(), gco.cpu().numpy(), batch, oshape),
+                               to_dense(fo, co, batch, oshape), rtol=2e-5, atol=2e-5)
+
+
 def test_sparse_conv_residual_and_empty(oracle):
     from al3d import detector_ops as D
     rng = np.random.default_rng(2)

@@ -318,3 +318,22 @@ def test_ppal_primitives(oracle):
             h = -s * torch.log(s) - (1.0 - s) * torch.log(1 - s)
             tot += float((h * torch.from_numpy(cw[labels[b, t, :counts[b, t]]])).sum())
         np.testing.assert_allclose(e[b], tot, rtol=1e-5)
+
+
+def test_l1_map_row_blocks_equal_full_map():
+    """al3d_l1_distance_rows_f32: any row range of the map, bit for bit (the N>1 path's building block)."""
+    import torch
+    from al3d import lib
+    g = torch.Generator(device="cpu").manual_seed(1)
+    n, c = 333, 70                                     # not multiples of the tile or of 4
+    feats = torch.randn(n, c, generator=g).cuda()
+    full = torch.empty((n, n), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    lib.call("al3d_l1_distance_f32", feats.data_ptr(), n, c, 2, full.data_ptr(), st)
+    for r0, nr in [(0, 64), (64, 100), (200, 133), (332, 1), (0, n), (17, 0)]:
+        blk = torch.full((max(nr, 1), n), float("nan"), dtype=torch.float32, device="cuda")
+        lib.call("al3d_l1_distance_rows_f32", feats.data_ptr(), n, c, 2, r0, nr, blk.data_ptr(), st)
+        if nr:
+            assert torch.equal(blk[:nr].view(torch.int32), full[r0:r0 + nr].view(torch.int32)), (r0, nr)
+    with pytest.raises(lib.Al3dError):
+        lib.call("al3d_l1_distance_rows_f32", feats.data_ptr(), n, c, 2, 300, 100, full.data_ptr(), st)
