@@ -36,7 +36,11 @@ def to_dense(feats, coords, batch, shape):
 @pytest.mark.parametrize("subm,k,s,p", [(True, (3, 3, 3), (1, 1, 1), (0, 0, 0)),
                                          (False, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
                                          (False, (3, 3, 3), (2, 2, 2), (0, 1, 1)),
-                                         (False, (3, 1, 1), (2, 1, 1), (0, 0, 0))])
+                                         (False, (3, 1, 1), (2, 1, 1), (0, 0, 0)),
+                                         (False, (1, 1, 3), (1, 1, 2), (0, 0, 0)),
+                                         (True, (3, 3, 1), (1, 1, 1), (0, 0, 0)),
+                                         (False, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                                         (False, (2, 2, 2), (2, 2, 2), (0, 0, 0))])
 def test_oracle_spconv_equals_dense_conv3d(oracle, subm, k, s, p):
     rng = np.random.default_rng(11)
     shape, batch, cin, cout = [11, 14, 12], 2, 5, 7
