@@ -35,20 +35,26 @@ __global__ void sp_scatter_index_kernel(const int* __restrict__ coords, int n, S
 }
 
 // Output-major rulebook for a submanifold conv: nbr[i][k] = row at coords[i] + (k - k/2).
+// One thread per (output row, kz, ky): its kw lookups are adjacent grid cells (x-1, x, x+1), i.e. one
+// memory transaction instead of kw, and the row's coordinates are read once per tap row.
 __global__ void sp_subm_table_kernel(const int* __restrict__ coords, int n, SpDims g,
                                      const int* __restrict__ grid, int kd, int kh, int kw,
                                      int* __restrict__ nbr)
 {
-    const int K = kd * kh * kw;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)n * K) return;
-    const int k = (int)(e / n), i = (int)(e % n);       // tap-major: nbr[k][i], coalesced over i
-    const int kx = k % kw, ky = (k / kw) % kh, kz = k / (kw * kh);
-    const int* c = coords + 4 * i;
-    const int z = c[1] + kz - kd / 2, y = c[2] + ky - kh / 2, x = c[3] + kx - kw / 2;
-    int v = -1;
-    if (z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) v = grid[sp_cell(g, c[0], z, y, x)];
-    nbr[e] = v;
+    if (e >= (int64_t)n * kd * kh) return;
+    const int kzy = (int)(e / n), i = (int)(e % n);     // tap-major: coalesced over i
+    const int ky = kzy % kh, kz = kzy / kh;
+    const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)i);
+    const int z = c.y + kz - kd / 2, y = c.z + ky - kh / 2, x0 = c.w - kw / 2;
+    const bool row_ok = z >= 0 && z < g.D && y >= 0 && y < g.H;
+    const int64_t base = row_ok ? sp_cell(g, c.x, z, y, 0) : 0;
+    for (int kx = 0; kx < kw; ++kx) {
+        const int x = x0 + kx;
+        int v = -1;
+        if (row_ok && x >= 0 && x < g.W) v = grid[base + x];
+        nbr[((int64_t)kzy * kw + kx) * n + i] = v;
+    }
 }
 
 struct SpConvGeom { int kd, kh, kw, sd, sh, sw, pd, ph, pw; };
@@ -173,20 +179,25 @@ __global__ void sp_count_tail_kernel(const unsigned* __restrict__ bits, const in
     if (threadIdx.x == 0 && blockIdx.x == 0) *counter = wscan[words - 1] + __popc(bits[words - 1]);
 }
 
-// Strided conv, step 2: nbr[o][k] = input row at o*stride - pad + k (grid_in lookup).
+// Strided conv, step 2: nbr[k][o] = input row at o*stride - pad + k (grid_in lookup); one thread per
+// (output row, kz, ky) -- its kw lookups are adjacent input cells.
 __global__ void sp_down_table_kernel(const int* __restrict__ coords_out, int n_out, SpConvGeom q,
                                      SpDims gi, const int* __restrict__ grid_in, int* __restrict__ nbr)
 {
-    const int K = q.kd * q.kh * q.kw;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)n_out * K) return;
-    const int k = (int)(e / n_out), o = (int)(e % n_out);   // tap-major
-    const int kx = k % q.kw, ky = (k / q.kw) % q.kh, kz = k / (q.kw * q.kh);
-    const int* c = coords_out + 4 * o;
-    const int z = c[1] * q.sd - q.pd + kz, y = c[2] * q.sh - q.ph + ky, x = c[3] * q.sw - q.pw + kx;
-    int v = -1;
-    if (z >= 0 && z < gi.D && y >= 0 && y < gi.H && x >= 0 && x < gi.W) v = grid_in[sp_cell(gi, c[0], z, y, x)];
-    nbr[e] = v;
+    if (e >= (int64_t)n_out * q.kd * q.kh) return;
+    const int kzy = (int)(e / n_out), o = (int)(e % n_out);   // tap-major
+    const int ky = kzy % q.kh, kz = kzy / q.kh;
+    const int4 c = *reinterpret_cast<const int4*>(coords_out + 4 * (int64_t)o);
+    const int z = c.y * q.sd - q.pd + kz, y = c.z * q.sh - q.ph + ky, x0 = c.w * q.sw - q.pw;
+    const bool row_ok = z >= 0 && z < gi.D && y >= 0 && y < gi.H;
+    const int64_t base = row_ok ? sp_cell(gi, c.x, z, y, 0) : 0;
+    for (int kx = 0; kx < q.kw; ++kx) {
+        const int x = x0 + kx;
+        int v = -1;
+        if (row_ok && x >= 0 && x < gi.W) v = grid_in[base + x];
+        nbr[((int64_t)kzy * q.kw + kx) * n_out + o] = v;
+    }
 }
 
 // ------------------------------------------------------------------ the conv itself
@@ -305,9 +316,10 @@ extern "C" int al3d_sp_subm_table(const int* coords, int n, int B, int D, int H,
     if (n == 0) return AL3D_OK;
     AL3D_REQUIRE(coords && grid && nbr && n > 0, "al3d_sp_subm_table: bad arguments");
     AL3D_REQUIRE(kd % 2 == 1 && kh % 2 == 1 && kw % 2 == 1, "al3d_sp_subm_table: odd kernel sizes only");
+    AL3D_REQUIRE(((uintptr_t)coords & 15) == 0, "al3d_sp_subm_table: coords must be 16-byte aligned");
     if (n == 0) return AL3D_OK;
     SpDims g = {B, D, H, W};
-    hipLaunchKernelGGL(sp_subm_table_kernel, dim3(blocks_for((int64_t)n * kd * kh * kw, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(sp_subm_table_kernel, dim3(blocks_for((int64_t)n * kd * kh, 256)), dim3(256), 0,
                        (hipStream_t)stream, coords, n, g, grid, kd, kh, kw, nbr);
     AL3D_CHECK_LAUNCH("sp_subm_table_kernel");
     return AL3D_OK;
@@ -380,9 +392,10 @@ extern "C" int al3d_sp_down_table(const int* coords_out, int n_out, const int* k
 {
     if (n_out == 0) return AL3D_OK;
     AL3D_REQUIRE(coords_out && ksize && stride && pad && grid_in && nbr, "al3d_sp_down_table: null pointer");
+    AL3D_REQUIRE(((uintptr_t)coords_out & 15) == 0, "al3d_sp_down_table: coords_out must be 16-byte aligned");
     SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
     SpDims gi = {B, ID, IH, IW};
-    hipLaunchKernelGGL(sp_down_table_kernel, dim3(blocks_for((int64_t)n_out * q.kd * q.kh * q.kw, 256)),
+    hipLaunchKernelGGL(sp_down_table_kernel, dim3(blocks_for((int64_t)n_out * q.kd * q.kh, 256)),
                        dim3(256), 0, (hipStream_t)stream, coords_out, n_out, q, gi, grid_in, nbr);
     AL3D_CHECK_LAUNCH("sp_down_table_kernel");
     return AL3D_OK;
