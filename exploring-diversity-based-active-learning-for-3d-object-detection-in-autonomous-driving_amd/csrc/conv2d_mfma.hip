@@ -232,14 +232,37 @@ __global__ __launch_bounds__(256) void gap_rows_kernel(const float* __restrict__
     }
 }
 
+// same reduction with 16-byte loads: a thread owns four consecutive channels (C % 4 == 0), so a row of
+// C = 512 channels is one 128-lane load per pixel instead of two 256-lane ones; every channel is
+// still summed left to right in its own accumulator (bit-identical to the scalar kernel).
+__global__ __launch_bounds__(256) void gap_rows_vec4_kernel(const float* __restrict__ x, int W, int C, int rows,
+                                                            float* __restrict__ rowmean)
+{
+    const int c4 = C >> 2;                                   // float4 lanes per pixel
+    const int per_block = 256 / c4 > 0 ? 256 / c4 : 1;      // image rows handled by one workgroup
+    const int sub = threadIdx.x / c4, lane = threadIdx.x % c4;
+    const int64_t by = (int64_t)blockIdx.x * per_block + sub;
+    if (sub >= per_block || by >= rows) return;
+    const float4* row = reinterpret_cast<const float4*>(x + by * W * C) + lane;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int xx = 0; xx < W; ++xx) {
+        const float4 v = row[(int64_t)xx * c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float w = (float)W;
+    reinterpret_cast<float4*>(rowmean + by * C)[lane] = make_float4(s.x / w, s.y / w, s.z / w, s.w / w);
+}
+
 // stage 2: out[b][c] = (sum_y rowmean[b][y][c]) / H, top to bottom
-__global__ __launch_bounds__(256) void gap_cols_kernel(const float* __restrict__ rowmean, int H, int C,
+__global__ __launch_bounds__(64) void gap_cols_kernel(const float* __restrict__ rowmean, int H, int C,
                                                        float* __restrict__ out)
 {
-    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;   // 64-thread blocks: more of them in flight
     if (c >= C) return;
     float s = 0.f;
-    for (int y = 0; y < H; ++y) s += rowmean[((int64_t)b * H + y) * C + c];
+#pragma unroll 16
+    for (int y = 0; y < H; ++y) s += rowmean[((int64_t)b * H + y) * C + c];   // loads run ahead, adds stay in order
     out[(int64_t)b * C + c] = s / (float)H;
 }
 
@@ -251,9 +274,15 @@ extern "C" int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, flo
     AL3D_REQUIRE(x && out && workspace, "al3d_gap_nhwc_f32: null pointer");
     AL3D_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, "al3d_gap_nhwc_f32: bad shape");
     float* rowmean = (float*)workspace;
-    hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, x, W, C,
-                       rowmean);
-    hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)al3d_cdiv(C, 256), (unsigned)B), dim3(256), 0,
+    if (C % 4 == 0 && C / 4 <= 256 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)workspace & 15) == 0) {
+        const int per_block = 256 / (C / 4);
+        hipLaunchKernelGGL(gap_rows_vec4_kernel, dim3((unsigned)al3d_cdiv((int64_t)B * H, per_block)), dim3(256), 0,
+                           (hipStream_t)stream, x, W, C, B * H, rowmean);
+    } else {
+        hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, x, W, C,
+                           rowmean);
+    }
+    hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)al3d_cdiv(C, 64), (unsigned)B), dim3(64), 0,
                        (hipStream_t)stream, rowmean, H, C, out);
     AL3D_CHECK_LAUNCH("gap_kernel");
     return AL3D_OK;
