@@ -273,9 +273,10 @@ def main():
         if roof:
             from al3d import sweep as _sweep
             roof["measured"] = ("HIP events around every neck+head region of the timed steps"
-                                + ("; the sparse half of the next batch runs concurrently on a second "
-                                   "stream (AL3D_PIPELINE=1), so these durations include that contention"
-                                   if _sweep.PIPELINE else ""))
+                                + {"split": "; the sparse half of the next batch runs concurrently on a second stream "
+                                            "(AL3D_PIPELINE=split), so these durations include that contention",
+                                   "ahead": "; the next batch's voxelization + rulebook (small latency-bound kernels) "
+                                            "run on a second stream meanwhile"}.get(_sweep.PIPELINE, ""))
             out["roofline"] = roof
         if not args.no_verify:
             out["selected_equals_oracle"] = verify_selection(infos, state["feats"], state["selected"])

@@ -175,47 +175,39 @@ class _SparseEncoderBase(nn.Module):
     def _out_shape(shape, k, s, p):
         return [(shape[d] + 2 * p[d] - (k[d] - 1) - 1) // s[d] + 1 for d in range(3)]
 
-    def _run(self, feats, coords, batch_size, spatial_shape):
-        """Returns (final SparseTensor, [SparseTensor per stage])."""
+    def build_rulebook(self, coords, batch_size, spatial_shape):
+        """All index work of one batch.  It depends on the voxel coordinates only -- level grids,
+        output sites of the strided convs (one small D2H each), every layer's tap-major table -- so
+        the sweep can run it for batch i+1 on a side stream while batch i is being convolved.
+        Returns ``dict(steps=[...])`` with one entry per item of the layer plan."""
         if self.training:
             raise RuntimeError("al3d sparse encoder implements the eval() sweep only")
-        dev = feats.device
+        dev = coords.device
         self._prepare(dev)
         st = _stream()
         coords = coords.to(torch.int32).contiguous()
-        feats = feats.float().contiguous()
         shape = [int(s) for s in spatial_shape]
-        n = feats.shape[0]
+        n = coords.shape[0]
         lv = self._level(shape, batch_size, dev)
         lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W, _ptr(lv.grid),
                  1, st)
         used = [(lv, coords, n)]
         nbr, nbr_key = None, None
-        middle = []
-        identity = None
-        def new_out(rows, m, step):
-            return torch.empty((rows, m.out_channels), dtype=torch.float32, device=dev)
-
+        steps = []
         for step in self._plan:
             if step["kind"] == "stage_end":
-                middle.append(SparseTensor(feats, coords, shape, batch_size))
+                steps.append(dict(coords=coords, shape=shape, n=n))
                 continue
             m = step["mod"]
             K = int(np.prod(m.kernel_size))
             if step["kind"] == "subm":
                 key = (id(lv), m.kernel_size)
                 if nbr_key != key:
-                    nbr = torch.empty((max(n, 1), K), dtype=torch.int32, device=dev)
+                    nbr = torch.empty((K, max(n, 1)), dtype=torch.int32, device=dev)
                     lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
                              _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
                     nbr_key = key
-                if feats.shape[-1] != self._pad_cin(m) and feats.dtype == torch.float32:
-                    feats = torch.nn.functional.pad(feats, (0, self._pad_cin(m) - feats.shape[-1]))
-                if step.get("block_start"):
-                    identity = feats
-                out = new_out(n, m, step)
-                self._conv(m, feats, nbr, K, step, identity if step["residual"] else None, out, n, st)
-                feats = out
+                steps.append(dict(nbr=nbr, n=n, K=K))
             else:
                 oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
                 olv = self._level(oshape, batch_size, dev)
@@ -230,16 +222,40 @@ class _SparseEncoderBase(nn.Module):
                 n_out = int(counter.item())      # one small D2H per stage
                 ocoords = ocoords[:n_out]
                 used.append((olv, ocoords, n_out))
-                dnbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
+                dnbr = torch.empty((K, max(n_out, 1)), dtype=torch.int32, device=dev)
                 lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
                          lv.W, _ptr(lv.grid), _ptr(dnbr), st)
-                out = new_out(n_out, m, step)
-                self._conv(m, feats, dnbr, K, step, None, out, n_out, st)
-                feats, coords, n, shape, lv = out, ocoords, n_out, oshape, olv
+                steps.append(dict(nbr=dnbr, n=n_out, K=K))
+                coords, n, shape, lv = ocoords, n_out, oshape, olv
                 nbr_key = None
         for g, c, cnt in used:      # leave every level grid clean for the next call
             lib.call("al3d_sp_scatter_index", _ptr(c), cnt, batch_size, g.D, g.H, g.W, _ptr(g.grid), 0, st)
-        return SparseTensor(feats, coords, shape, batch_size), middle
+        return dict(steps=steps, batch_size=batch_size)
+
+    def _run(self, feats, coords, batch_size, spatial_shape, book=None):
+        """Returns (final SparseTensor, [SparseTensor per stage]).  ``book``: a rulebook built earlier
+        by ``build_rulebook`` for these coordinates (else it is built here)."""
+        if book is None:
+            book = self.build_rulebook(coords, batch_size, spatial_shape)
+        dev = feats.device
+        st = _stream()
+        feats = feats.float().contiguous()
+        middle = []
+        identity = None
+        for step, b in zip(self._plan, book["steps"]):
+            if step["kind"] == "stage_end":
+                middle.append(SparseTensor(feats, b["coords"], b["shape"], batch_size))
+                continue
+            m = step["mod"]
+            if feats.shape[-1] != self._pad_cin(m):
+                feats = torch.nn.functional.pad(feats, (0, self._pad_cin(m) - feats.shape[-1]))
+            if step.get("block_start"):
+                identity = feats
+            out = torch.empty((b["n"], m.out_channels), dtype=torch.float32, device=dev)
+            self._conv(m, feats, b["nbr"], b["K"], step, identity if step.get("residual") else None, out, b["n"], st)
+            feats = out
+        last = middle[-1]
+        return SparseTensor(feats, last.indices, last.spatial_shape, batch_size), middle
 
     @staticmethod
     def dense_nhwc(sp):
@@ -274,9 +290,12 @@ class FPNSpMiddleResNetFHD(_SparseEncoderBase):
     def _stages(self):
         return [self.middle_conv0, self.middle_conv1, self.middle_conv2, self.middle_conv3]
 
-    def forward(self, voxel_features, coors, batch_size, input_shape):
+    def rulebook_for(self, coors, batch_size, input_shape):
+        return self.build_rulebook(coors, batch_size, np.array(input_shape[::-1]) + [1, 0, 0])
+
+    def forward(self, voxel_features, coors, batch_size, input_shape, book=None):
         """-> (dense NHWC [B,128,128,256], middle list of 4 SparseTensor) -- the reference
         returns NCHW (scn.py:371-392); this build keeps activations channels-last."""
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
-        final, middle = self._run(voxel_features, coors, batch_size, sparse_shape)
+        final, middle = self._run(voxel_features, coors, batch_size, sparse_shape, book=book)
         return self.dense_nhwc(final), middle

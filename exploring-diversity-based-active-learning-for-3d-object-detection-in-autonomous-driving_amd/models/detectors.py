@@ -69,7 +69,15 @@ class FPNVoxelNet(SingleStageDetector):
     # The forward pass is exposed in two halves so that the sweep can run the sparse half of batch
     # i+1 (voxel features -> sparse encoder -> dense BEV; latency-bound gathers) on one HIP stream
     # while the dense half of batch i (neck + head + decode; matrix-core bound) runs on another.
-    def sparse_stage(self, example):
+    def prepare(self, example):
+        """Index work of a batch (sparse-conv rulebook); needs ``coordinates`` only, so the sweep runs
+        it one batch ahead on a side stream.  Pass the result as ``book=`` to forward / sparse_stage."""
+        if not hasattr(self.backbone, "rulebook_for"):
+            return None
+        return self.backbone.rulebook_for(example["coordinates"], len(example["num_voxels"]),
+                                          example["shape"][0])
+
+    def sparse_stage(self, example, book=None):
         num_voxels = example["num_voxels"]
         data = dict(features=example.get("voxels"), num_voxels=example.get("num_points"),
                     mean_features=example.get("voxel_features"), coors=example["coordinates"],
@@ -78,6 +86,8 @@ class FPNVoxelNet(SingleStageDetector):
             input_features = data["mean_features"]
         else:
             input_features = self.reader(data["features"], data["num_voxels"])
+        if book is not None:
+            return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"], book=book)
         return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
 
     def dense_stage(self, example, x, middle, finetune=False, **kwargs):
@@ -95,7 +105,7 @@ class FPNVoxelNet(SingleStageDetector):
     def forward(self, example, return_loss=True, finetune=False, **kwargs):
         if return_loss:
             raise NotImplementedError("al3d implements the inference sweep, not training")
-        x, middle = self.sparse_stage(example)
+        x, middle = self.sparse_stage(example, book=kwargs.pop("book", None))
         return self.dense_stage(example, x, middle, finetune=finetune, **kwargs)
 
 

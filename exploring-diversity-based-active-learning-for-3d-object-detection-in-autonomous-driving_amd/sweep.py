@@ -64,10 +64,16 @@ def gather_in_dataset_order(local_feats, local_index, num_frames):
 
 import os as _os
 
-# Two-stream batch pipeline (sparse half of batch i+1 overlaps the dense half of batch i).  Measured
-# +4..9 % frames/s on MI355X, but every kernel then runs contended, which blurs per-kernel timings;
-# opt in with AL3D_PIPELINE=1.
-PIPELINE = _os.environ.get("AL3D_PIPELINE", "0") == "1"
+# Batch pipelining of the sweep over two HIP streams (AL3D_PIPELINE):
+#   "ahead" (default)  the index work of batch i+1 -- voxelization + sparse-conv rulebook, small
+#                      latency-bound kernels and every host synchronisation of a batch -- runs on a
+#                      side stream while batch i is convolved; the conv phase never waits for the host.
+#   "split" (or "1")   the whole sparse half of batch i+1 overlaps the dense half of batch i (+3..5 %
+#                      more, but the matrix-core kernels of both halves then contend, which blurs
+#                      per-kernel timings).
+#   "0" / "off"        one batch at a time on the caller's stream.
+_mode = _os.environ.get("AL3D_PIPELINE", "ahead").lower()
+PIPELINE = {"1": "split", "split": "split", "0": None, "off": None, "none": None}.get(_mode, "ahead")
 _SIDE = {}
 
 
@@ -128,29 +134,37 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
             index.extend(range(seen, seen + b))
         seen += b
 
-    pipelined = (PIPELINE and torch.device(device).type == "cuda" and hasattr(detector, "sparse_stage")
-                 and hasattr(detector, "dense_stage"))
+    on_gpu = torch.device(device).type == "cuda"
+    mode = PIPELINE if on_gpu else None
+    if mode == "split" and not (hasattr(detector, "sparse_stage") and hasattr(detector, "dense_stage")):
+        mode = "ahead"
+    if mode == "ahead" and not hasattr(detector, "prepare"):
+        mode = None
     with torch.no_grad():
-        if not pipelined:
+        if mode is None:
             for data_batch in dataloader:
                 example = example_to_device(data_batch, device, non_blocking=False)
                 preds, middle = detector(example, return_loss=False, estimate=True)
                 finish(example, preds, middle)
         else:
-            # Two-stage software pipeline over batches: the sparse half of batch i+1 is enqueued on a
-            # side stream while the dense half of batch i runs on the caller's stream.  The dense
-            # half is enqueued FIRST (it has no host synchronisation), so the device keeps working
-            # on it while the host waits for the sparse half's row counts.
+            # Software pipeline over batches.  The work of the batch that is due on the caller's
+            # stream is enqueued FIRST (it contains no host synchronisation), then the host turns to
+            # the side stream, whose row-count read-backs it may wait on while the device keeps
+            # working on the main stream.
             main = torch.cuda.current_stream(device)
             side = _side_stream(device)
             side.wait_stream(main)
-            pending = None                      # (example, x, middle, event) of the batch whose dense half is due
+            pending = None
             it = iter(dataloader)
             while True:
                 if pending is not None:
-                    example, x, middle, ev = pending
+                    example, ahead, ev = pending
                     main.wait_event(ev)
-                    preds, middle = detector.dense_stage(example, x, middle, estimate=True)
+                    if mode == "ahead":
+                        preds, middle = detector(example, return_loss=False, estimate=True, book=ahead)
+                    else:
+                        x, middle = ahead
+                        preds, middle = detector.dense_stage(example, x, middle, estimate=True)
                     finish(example, preds, middle)
                     pending = None
                 with torch.cuda.stream(side):
@@ -159,12 +173,12 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                     except StopIteration:
                         break
                     example = example_to_device(data_batch, device, non_blocking=False)
-                    x, middle = detector.sparse_stage(example)
-                    for t in _tensors_of((example, x, middle)):
+                    ahead = detector.prepare(example) if mode == "ahead" else detector.sparse_stage(example)
+                    for t in _tensors_of((example, ahead)):
                         t.record_stream(main)   # produced on the side stream, consumed on the main one
                     ev = torch.cuda.Event()
                     ev.record(side)
-                pending = (example, x, middle, ev)
+                pending = (example, ahead, ev)
             main.wait_stream(side)
     local = torch.cat(feats, dim=0)
     idx = torch.as_tensor(index, dtype=torch.int64, device=local.device)

@@ -331,8 +331,9 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
             D.SPCONV = mode
             assert torch.equal(run(4), ref), mode
         D.SPCONV = saved[0]
-        S.PIPELINE = True
-        assert torch.equal(run(2), ref)
+        for mode in (None, "ahead", "split"):
+            S.PIPELINE = mode
+            assert torch.equal(run(2), ref), mode
     finally:
         D.SPCONV, S.PIPELINE = saved
 
