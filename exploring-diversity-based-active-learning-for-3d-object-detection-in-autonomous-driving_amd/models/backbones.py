@@ -230,7 +230,11 @@ class _SparseEncoderBase(nn.Module):
                 nbr_key = None
         for g, c, cnt in used:      # leave every level grid clean for the next call
             lib.call("al3d_sp_scatter_index", _ptr(c), cnt, batch_size, g.D, g.H, g.W, _ptr(g.grid), 0, st)
-        return dict(steps=steps, batch_size=batch_size)
+        # the zero-filled dense BEV buffer the last stage scatters into (537 MB at batch 32): also
+        # coordinate-independent work that can be done ahead
+        last_c = [st_["mod"].out_channels for st_ in self._plan if st_["kind"] != "stage_end"][-1]
+        dense = torch.zeros((batch_size, shape[1], shape[2], last_c * shape[0]), dtype=torch.float32, device=dev)
+        return dict(steps=steps, batch_size=batch_size, dense=dense)
 
     def _run(self, feats, coords, batch_size, spatial_shape, book=None):
         """Returns (final SparseTensor, [SparseTensor per stage]).  ``book``: a rulebook built earlier
@@ -258,11 +262,13 @@ class _SparseEncoderBase(nn.Module):
         return SparseTensor(feats, last.indices, last.spatial_shape, batch_size), middle
 
     @staticmethod
-    def dense_nhwc(sp):
-        """``ret.dense()`` + ``view(N, C*D, H, W)`` in NHWC: [B, H, W, C*D], channel = c*D + z."""
+    def dense_nhwc(sp, out=None):
+        """``ret.dense()`` + ``view(N, C*D, H, W)`` in NHWC: [B, H, W, C*D], channel = c*D + z.
+        ``out``: an already zero-filled buffer of that shape (the rulebook pass prepares one)."""
         D, H, W = sp.spatial_shape
         C = sp.features.shape[1]
-        out = torch.zeros((sp.batch_size, H, W, C * D), dtype=torch.float32, device=sp.features.device)
+        if out is None or tuple(out.shape) != (sp.batch_size, H, W, C * D):
+            out = torch.zeros((sp.batch_size, H, W, C * D), dtype=torch.float32, device=sp.features.device)
         lib.call("al3d_sp_to_dense_nhwc", _ptr(sp.features), _ptr(sp.indices), sp.features.shape[0], C,
                  sp.batch_size, D, H, W, _ptr(out), _stream())
         return out
@@ -297,5 +303,7 @@ class FPNSpMiddleResNetFHD(_SparseEncoderBase):
         """-> (dense NHWC [B,128,128,256], middle list of 4 SparseTensor) -- the reference
         returns NCHW (scn.py:371-392); this build keeps activations channels-last."""
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        if book is None:
+            book = self.build_rulebook(coors, batch_size, sparse_shape)
         final, middle = self._run(voxel_features, coors, batch_size, sparse_shape, book=book)
-        return self.dense_nhwc(final), middle
+        return self.dense_nhwc(final, out=book.pop("dense", None)), middle
