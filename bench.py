@@ -239,6 +239,9 @@ def main():
         step()
         sweep_s += state["sweep_s"]
         select_s += state["select_s"]
+        if os.environ.get("AL3D_BENCH_MEM") == "1" and rank == 0:      # dev aid: allocator growth per step
+            print(f"[mem] reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, allocated "
+                  f"{torch.cuda.memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -155,6 +155,7 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
             side = _side_stream(device)
             side.wait_stream(main)
             pending = None
+            done = []                           # completion events of the batches enqueued on the main stream
             it = iter(dataloader)
             while True:
                 if pending is not None:
@@ -167,6 +168,13 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                         preds, middle = detector.dense_stage(example, x, middle, estimate=True)
                     finish(example, preds, middle)
                     pending = None
+                    e = torch.cuda.Event()
+                    e.record(main)
+                    done.append(e)
+                # bound the run-ahead: the side stream is ~10x faster than the main one and would
+                # otherwise prepare (and keep alive) every remaining batch of the pool at once
+                while len(done) > 1:
+                    done.pop(0).synchronize()
                 with torch.cuda.stream(side):
                     try:
                         data_batch = next(it)

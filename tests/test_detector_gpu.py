@@ -338,6 +338,39 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
         D.SPCONV, S.PIPELINE = saved
 
 
+def test_pipelined_sweep_keeps_a_bounded_number_of_batches_alive():
+    """The side stream is ~10x faster than the main one; without a bound on its run-ahead it prepares
+    (and keeps alive) every remaining batch of the pool.  Peak memory of a 16-batch sweep must stay
+    within a small factor of the serial sweep's."""
+    from al3d import sweep as S, synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    pool = PoolFrames.from_numpy([synthetic.make_point_cloud(200 + i, nsweeps=2) for i in range(32)], DEV)
+    saved = S.PIPELINE
+    peaks = {}
+    try:
+        for mode in (None, "ahead", "split"):
+            S.PIPELINE = mode
+            loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 2, device=DEV)
+            S.sweep_embeddings(model, loader, DEV, len(pool))           # warm caches / level grids
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            torch.cuda.reset_peak_memory_stats()
+            S.sweep_embeddings(model, loader, DEV, len(pool))
+            torch.cuda.synchronize()
+            peaks[mode] = torch.cuda.max_memory_allocated() - base
+    finally:
+        S.PIPELINE = saved
+    assert peaks["ahead"] < 3.0 * peaks[None] and peaks["split"] < 3.0 * peaks[None], peaks
+
+
 def test_uncertainty_sweeps_compose(oracle, tmp_path):
     """pred=True paths of Entropy / Badge / UWE: the swept quantities must equal what the
     reference expressions give on the detector's own outputs (entropy from the post-NMS scores,
