@@ -97,7 +97,19 @@ class ConvTimer:
         out = dict(bound="mfma", achieved=round(tf, 2), unit="TFLOP/s", traffic=None,
                    launches=self.launches, avg_launch_us=round(ms * 1e3 / max(self.launches, 1), 2),
                    gflop_per_frame=DENSE_GFLOP_PER_FRAME)
-        if D.MATH == "bf16x6":
+        if D.MATH == "f16x3":
+            # fp32-class arithmetic on the f16 matrix cores: every algorithmic MAC executes as three
+            # f16 MFMA products (the f16 and bf16 dense peaks are equal), so peak/3 bounds it.
+            out.update(kernel="conv3x3_f16x3_frag_kernel",
+                       kernel_family="conv3x3_f16x3_frag_kernel (11 of 15 launches) + conv2d_f16x3_kernel "
+                                     "(stride-2, 1x1, deconv, fused head)",
+                       peak=round(MFMA_BF16_PEAK_TFLOPS / 3, 1),
+                       peak_basis="2500 TFLOP/s dense f16 MFMA / 3 f16 products per fp32-class MAC",
+                       frac=round(3 * tf / MFMA_BF16_PEAK_TFLOPS, 4), mfma_products_per_mac=3,
+                       executed_tflops=round(3 * tf, 1), f16_mfma_peak=MFMA_BF16_PEAK_TFLOPS,
+                       fp32_mfma_peak=MFMA_F32_PEAK_TFLOPS,
+                       vs_fp32_mfma_peak=round(tf / MFMA_F32_PEAK_TFLOPS, 3))
+        elif D.MATH == "bf16x6":
             # fp32-faithful arithmetic on the bf16 matrix cores: every algorithmic MAC executes as
             # six bf16 MFMA products, so the bf16 peak bounds the *executed* rate.
             out.update(kernel="conv3x3_bf16x6_halo_kernel",
@@ -261,7 +273,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if _math() == "f32" else "f32 (exact 3-way bf16 split, 6 MFMA products per MAC, f32 accumulate)",
+            "dtype": _DTYPE[_math()],
             "data": "synthetic",
             "config": {"workload": f"{args.scenes * world}-scene nuScenes-shaped pool ({n_total} frames, "
                                    f"10-sweep ~250k-point clouds resident in HBM), FPNVoxelNet sweep + "
@@ -292,6 +304,14 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_DTYPE = {
+    "f32": "f32",
+    "bf16x6": "f32 (exact 3-way bf16 split, 6 MFMA products per MAC, f32 accumulate)",
+    "f16x3": "f32 (dense neck+head: 2-way f16 split, 3 MFMA products per MAC; sparse encoder: 3-way bf16 "
+             "split, 6 products; f32 accumulate)",
+}
 
 
 def _math():

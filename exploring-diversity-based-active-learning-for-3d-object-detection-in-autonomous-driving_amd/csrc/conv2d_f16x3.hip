@@ -1,0 +1,751 @@
+// Dense 2-D convolution in fp32-class arithmetic with THREE f16 matrix-core products per MAC.
+//
+// f16 carries 11 significand bits, so two pieces hold 22-23 of an fp32 value's 24 (bf16 needs
+// three pieces and six products for the same, conv2d_bf16x6.hip).  What f16 lacks is exponent
+// range; the split is arranged to spend as little of it as possible:
+//
+//   activation x (any |x| < 65504):  xh = f16(x)                A0
+//                                    xl = f16((x - xh) * 2^11)  A1   (residual lifted by 2^11)
+//   weight w, pre-scaled once per layer by a power of two so that max|ws| <= 2^14:
+//                                    wh = f16(ws)               B0
+//                                    wl = f16(ws - wh)          B1
+//                                    wd = wh * 2^-11            B2   (derived in registers from the B0
+//                                         fragment with v_pk_mul_f16; exact: wh >= 2^-3 for every
+//                                         weight above 2^-17 max|w|, f16 subnormal rounding below)
+//   x*ws = A0*B0 + A0*B1 + A1*B2 + (dropped xl*wl term <= 2^-24 |x ws|)
+//
+// All three products go into ONE fp32 accumulator (v_mfma_f32_32x32x16_f16, products exact);
+// the weight scale 2^-s is folded into the per-channel BN scale on the host (exact).
+// Per-product relative error <= ~3 * 2^-24, i.e. the size of one fp32 rounding, for |x| >= 2^-14.
+// Below that xh is an f16 subnormal (v_cvt_f16_f32 and the gfx950 matrix core both keep them --
+// measured, tools/probe_f16x3.py) with absolute error 2^-25, of which the lifted residual recovers
+// eleven more bits: absolute representation error <= 2^-36 everywhere.  Measured against fp64
+// (max error as a fraction of sum|a*b|, lognormal activations of typical magnitude m):
+//      m = 1 .. 1e-5: 2.6e-7 .. 3.2e-7  (fp32-input MFMA kernel: 4.2e-7 .. 5.3e-7, bf16x6: 3.1e-7 .. 4.4e-7)
+//      m = 1e-6: 1.4e-6 (and short K=32 sums already at m = 1e-5) -- the envelope: tensors whose
+// typical magnitude is within [1e-4, 6e4].
+// An activation >= 65504 turns into inf/NaN in the output, never a plausible number -- the sweep
+// checks its embeddings for finiteness and names AL3D_MATH=bf16x6 (full fp32 range) as the way out.
+//
+// Same role, layouts and tiling as conv2d_bf16x6.hip: NHWC f32 activations in HBM, split while
+// they are staged; weights pre-split into [2][Cout][taps][Cin] f16.  Half the MFMAs, 4 instead
+// of 6 fragment reads per step, 2/3 of the LDS.
+#include "al3d_common.h"
+#include <type_traits>
+
+#define F3_BM 128
+#define F3_BN 128
+#define F3_BK 16
+#define F3_LDB 48          // bytes per LDS row: 16 f16 (32 B) + 16 B pad (conflict-free b128 reads)
+#define F3_TH 8
+#define F3_TW 16
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct ConvF3Params {
+    const float* in;        // [B, H, W, Cin] f32
+    const _Float16* wgt;    // [2][Cout][taps][Cin] f16 planes (wh, wl)
+    const float* scale;     // BN scale * 2^-s
+    const float* shift;
+    float* out;
+    int B, H, W, Cin, Cout, OH, OW, ldc, coff;
+    int ksize, stride, pad, relu;
+    int tiles_x, tiles_y;
+    int64_t plane;          // elements per weight plane = Cout * taps * Cin
+};
+
+__device__ __forceinline__ void split_act(float x, _Float16& h, _Float16& l)
+{
+    h = (_Float16)x;                                  // subnormal below 2^-14 (kept: see the header)
+    l = (_Float16)((x - (float)h) * 2048.0f);
+}
+
+__device__ __forceinline__ void split_act4(const float4& v, f16x4& h, f16x4& l)
+{
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { _Float16 a, b; split_act(e[i], a, b); h[i] = a; l[i] = b; }
+}
+
+// wd fragment = wh fragment * 2^-11 (packed f16 multiplies; the compiler emits v_pk_mul_f16)
+__device__ __forceinline__ f16x8 lift_down(const f16x8& wh)
+{
+    return wh * (_Float16)0.00048828125f;
+}
+
+#define F3_IC(v) std::integral_constant<int, v>{}
+#define F3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv2d_f16x3_kernel(ConvF3Params p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][2][F3_BM * F3_LDB];   // [buf][plane]
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][2][F3_BN * F3_LDB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    int tile = blockIdx.x;
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = blockIdx.y * F3_BN;
+    const int MH = MODE == 0 ? p.OH : p.H, MW = MODE == 0 ? p.OW : p.W;
+    const int taps = MODE == 0 ? p.ksize * p.ksize : 1;
+    const int tap0 = MODE == 0 ? 0 : blockIdx.z;
+    const int wtaps = MODE == 0 ? taps : 4;
+
+    const int aq = tid & 3, ar = tid >> 2;            // piece, row (0..63), +64 on pass 1
+    int py[2], px[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = ar + 64 * i;
+        py[i] = ty_ * F3_TH + m / F3_TW;
+        px[i] = tx_ * F3_TW + m % F3_TW;
+    }
+    const int bq = tid & 1, br = tid >> 1;
+    const int kchunks = p.Cin / F3_BK;
+    const int nsteps = taps * kchunks;
+
+    float4 ra[2];
+    uint4 rb[2];
+    auto load_step = [&](int step) {
+        const int tap = step / kchunks, c0 = (step - tap * kchunks) * F3_BK;
+        const int ky = MODE == 0 ? tap / p.ksize : 0, kx = MODE == 0 ? tap % p.ksize : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int iy, ix;
+            if (MODE == 0) { iy = py[i] * p.stride - p.pad + ky; ix = px[i] * p.stride - p.pad + kx; }
+            else { iy = py[i]; ix = px[i]; }
+            const bool ok = py[i] < MH && px[i] < MW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            ra[i] = ok ? *reinterpret_cast<const float4*>(
+                             p.in + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + c0 + 4 * aq)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int n = n0 + br;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            rb[pl] = n < p.Cout ? *reinterpret_cast<const uint4*>(
+                                      p.wgt + pl * p.plane + ((int64_t)n * wtaps + tap0 + tap) * p.Cin + c0 + 8 * bq)
+                                : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f16x4 h, l;
+            split_act4(ra[i], h, l);
+            const int off = (ar + 64 * i) * F3_LDB + 8 * aq;
+            *reinterpret_cast<f16x4*>(&As[buf][0][off]) = h;
+            *reinterpret_cast<f16x4*>(&As[buf][1][off]) = l;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            *reinterpret_cast<uint4*>(&Bs[buf][pl][br * F3_LDB + 16 * bq]) = rb[pl];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) load_step(step + 1);
+        f16x8 a[2][2], bb[3][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a[pl][t] = *reinterpret_cast<const f16x8*>(&As[buf][pl][(wm * 64 + t * 32 + fr) * F3_LDB + 16 * fh]);
+                bb[pl][t] = *reinterpret_cast<const f16x8*>(&Bs[buf][pl][(wn * 64 + t * 32 + fr) * F3_LDB + 16 * fh]);
+            }
+            bb[2][t] = lift_down(bb[0][t]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = F3_MFMA(a[1][i], bb[2][j], acc[i][j]);      // xl * wh   (smallest first)
+                acc[i][j] = F3_MFMA(a[0][i], bb[1][j], acc[i][j]);      // xh * wl
+                acc[i][j] = F3_MFMA(a[0][i], bb[0][j], acc[i][j]);      // xh * wh
+            }
+        if (step + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale[n];
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                if (y >= MH || x >= MW) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                int oy = y, ox = x;
+                if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
+                p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 3x3 / stride 1 / pad 1
+// Halo-staged kernel: the 6x34-pixel input halo of a 4x32 output tile is split and staged once
+// per 16-channel chunk, the nine taps read their A fragments from it at shifted rows; only the
+// weight tile changes per tap.  Output tile = 4 rows x 32 columns: lane r of an M-tile is column
+// r, so the 32 lanes of a fragment read 32 consecutive halo rows (conflict-free ds_read_b128 at
+// a 48-byte pitch).
+//
+// With three MFMAs per tile pair a step holds only 12 x 32 matrix-core cycles per wave, far less
+// than an L2 round trip, so -- unlike the bf16x6 kernel this grew from -- nothing may wait inside
+// a step.  Global step s = chunk * 9 + tap; everything below is software-pipelined over s:
+//   * weights: global load of B(s+3) is issued at the top of step s into register set (s+1)&1;
+//     the set loaded one step earlier, B(s+2), is written to LDS buffer (s+2)%3 at the end of
+//     step s -- two full steps between issue and use;
+//   * three weight buffers (two planes each; the third operand is derived) in LDS (32-byte rows, 16-byte halves XOR-swizzled by bit 3 of the
+//     row: conflict-free b128 reads and writes without padding): B(s+1) is read by the fragment
+//     prefetch of step s, B(s) was read during step s-1, B(s+2) is being written;
+//   * fragments of step s+1 are read into the second register set while the MFMAs of step s run;
+//   * the halo is double-buffered by chunk parity: loads for chunk c+1 are issued at taps 0 and 3
+//     of chunk c (two halves, to halve the staging registers), split and stored at taps 2 and 5,
+//     published by those taps' barriers, first read at tap 8;
+//   * one barrier per step; 9 is odd, so two chunks are unrolled to keep every register-set
+//     and buffer index a compile-time constant;
+//   * every global load is unconditional (out-of-image pixels, rows beyond Cout and the steps
+//     past the end read a zero word / a clamped address): a branch around a VMEM op would make
+//     hipcc wait for vmcnt(0) at the next use and serialise the pipeline.
+#define G3_TH 4
+#define G3_TW 32
+#define G3_HH (G3_TH + 2)
+#define G3_HW (G3_TW + 2)
+#define G3_HP (G3_HH * G3_HW)          // 204 halo pixels
+#define G3_BROW 32                     // bytes per weight row in LDS (16 f16, swizzled halves)
+
+__device__ uint4 g_f3_zero16;          // 16 zero bytes (device globals are zero-initialised)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(ConvF3Params p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][2][G3_HP * F3_LDB];      // [chunk parity][plane] 39.2 KB
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][2][F3_BN * G3_BROW];     // [step % 3][plane]     24.6 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile = blockIdx.x;
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = blockIdx.y * F3_BN;
+    const int y0 = ty_ * G3_TH - 1, x0 = tx_ * G3_TW - 1;       // image coords of halo (0,0)
+    const int nchunks = p.Cin / F3_BK;
+    const int bq = tid & 1, br = tid >> 1;
+    const float* zero = reinterpret_cast<const float*>(&g_f3_zero16);
+
+    // ---- halo: 204 pixels x 4 float4 pieces = 816 pieces over 4 passes of 256 threads
+    float4 rh[2];                                    // the halo travels in two halves (8 VGPRs, not 16)
+    auto load_halo = [&](int chunk, int half) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = 2 * half + k;
+            const int piece = tid + 256 * i;
+            const int hp = piece >> 2, q = piece & 3;
+            const int iy = y0 + hp / G3_HW, ix = x0 + hp % G3_HW;
+            const bool ok = hp < G3_HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float* src = p.in + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + chunk * F3_BK + 4 * q;
+            rh[k] = *reinterpret_cast<const float4*>(ok ? src : zero);
+        }
+    };
+    auto store_halo = [&](int buf, int half) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = tid + 256 * (2 * half + k);
+            const int hp = piece >> 2, q = piece & 3;
+            if (hp >= G3_HP) continue;
+            f16x4 h, l;
+            split_act4(rh[k], h, l);
+            const int off = hp * F3_LDB + 8 * q;
+            *reinterpret_cast<f16x4*>(&Ah[buf][0][off]) = h;
+            *reinterpret_cast<f16x4*>(&Ah[buf][1][off]) = l;
+        }
+    };
+    // ---- weights: this thread's 16-byte piece of row n0+br, three planes
+    const int nb = n0 + br;
+    const bool nb_ok = nb < p.Cout;
+    const _Float16* wrow = nb_ok ? p.wgt + (int64_t)nb * 9 * p.Cin + 8 * bq
+                                 : reinterpret_cast<const _Float16*>(zero);
+    const int64_t wplane = nb_ok ? p.plane : 0;
+    const int wtap = nb_ok ? p.Cin : 0, wchunk = nb_ok ? F3_BK : 0;
+    uint4 rb0[2], rb1[2];                            // two register sets (named: an [2][2] array went to scratch)
+    auto load_b = [&](auto set_, int chunk, int tap) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const uint4 v = *reinterpret_cast<const uint4*>(wrow + pl * wplane + tap * wtap + chunk * wchunk);
+            if constexpr (decltype(set_)::value == 0) rb0[pl] = v; else rb1[pl] = v;
+        }
+    };
+    const int bw_off = br * G3_BROW + 16 * (bq ^ ((br >> 3) & 1));
+    auto store_b = [&](auto set_, int buf) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            if constexpr (decltype(set_)::value == 0) *reinterpret_cast<uint4*>(&Bs[buf][pl][bw_off]) = rb0[pl];
+            else *reinterpret_cast<uint4*>(&Bs[buf][pl][bw_off]) = rb1[pl];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_off = ((2 * wm) * G3_HW + fr) * F3_LDB + 16 * fh;
+    const int b_off = (wn * 64 + fr) * G3_BROW + 16 * (fh ^ ((fr >> 3) & 1));   // +32 rows keeps bit 3
+    f16x8 fa[2][2][2], fb[2][2][2];                   // [set][plane][tile]
+    // fragment reads are issued plane by plane, each right after the MFMA group that last used the
+    // registers of the same plane in the current set (keeps ~1.5 fragment sets live, not 2)
+    auto read_a = [&](int set, int pl, int hbuf, int tap) {
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            fa[set][pl][t] = *reinterpret_cast<const f16x8*>(
+                &Ah[hbuf][pl][a_off + ((t + ky) * G3_HW + kx) * F3_LDB]);
+    };
+    auto read_b = [&](int set, int pl, int bbuf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            fb[set][pl][t] = *reinterpret_cast<const f16x8*>(&Bs[bbuf][pl][b_off + t * 32 * G3_BROW]);
+    };
+    auto read_frags = [&](int set, int hbuf, int tap, int bbuf) {
+        read_a(set, 1, hbuf, tap); read_b(set, 0, bbuf);
+        read_b(set, 1, bbuf);
+        read_a(set, 0, hbuf, tap);
+    };
+    auto mfma_group = [&](int set, int pa, int pb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = F3_MFMA(fa[set][pa][i], fb[set][pb][j], acc[i][j]);
+    };
+    auto mfma_lifted = [&](int set) {                 // xl' * (wh * 2^-11)
+        f16x8 wd[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wd[j] = lift_down(fb[set][0][j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = F3_MFMA(fa[set][1][i], wd[j], acc[i][j]);
+    };
+
+    // ---- prologue: halo(0), B(0), B(1) in LDS; B(2) in flight in register set 0
+    const int last = nchunks - 1;
+    load_halo(0, 0);
+    load_b(F3_IC(0), 0, 0);
+    store_halo(0, 0);
+    load_halo(0, 1);
+    store_halo(0, 1);
+    store_b(F3_IC(0), 0);
+    load_b(F3_IC(0), 0, 1);
+    store_b(F3_IC(0), 1);
+    load_b(F3_IC(0), 0, 2);
+    __syncthreads();
+    read_frags(0, 0, 0, 0);
+
+    // cp (chunk parity) and tap are template-level constants so that every register-set and LDS
+    // buffer index is constant from the start (a loop variable, even fully unrolled, left the
+    // staging arrays in scratch memory).
+    auto step = [&](auto cp_, auto tap_, int chunk, int cn) {
+        constexpr int cp = decltype(cp_)::value, tap = decltype(tap_)::value;
+        constexpr int q = (cp + tap) & 1;             // register-set parity of this step
+        // B(s+3) -> the other register set (in flight for two steps)
+        if (tap < 6) load_b(F3_IC(q ^ 1), chunk, tap + 3);
+        else load_b(F3_IC(q ^ 1), cn, tap - 6);
+        if (tap == 0) load_halo(cn, 0);               // next chunk's halo, first half: stored at tap 2
+        if (tap == 3) load_halo(cn, 1);               // second half: stored at tap 5, first read at tap 8
+        __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top of the step (hipcc sinks them to the stores)
+        // MFMAs of step s (smallest products first: xl*wd, xh*wl, xh*wh), interleaved with the
+        // fragment reads of step s+1 (halo of the next chunk after tap 8)
+        constexpr int nh = tap < 8 ? cp : cp ^ 1, nt = tap < 8 ? tap + 1 : 0, nbuf = (tap + 1) % 3;
+        mfma_lifted(q);
+        read_a(q ^ 1, 1, nh, nt);
+        mfma_group(q, 0, 1);
+        read_b(q ^ 1, 1, nbuf);
+        mfma_group(q, 0, 0);
+        read_a(q ^ 1, 0, nh, nt); read_b(q ^ 1, 0, nbuf);
+        store_b(F3_IC(q), (tap + 2) % 3);             // B(s+2), loaded during step s-1
+        if (tap == 2) store_halo(cp ^ 1, 0);
+        if (tap == 5) store_halo(cp ^ 1, 1);
+        __syncthreads();
+    };
+    auto chunk_body = [&](auto cp_, int chunk) {
+        const int cn = chunk < last ? chunk + 1 : chunk;         // clamped: the last chunk re-reads itself
+        step(cp_, F3_IC(0), chunk, cn); step(cp_, F3_IC(1), chunk, cn); step(cp_, F3_IC(2), chunk, cn);
+        step(cp_, F3_IC(3), chunk, cn); step(cp_, F3_IC(4), chunk, cn); step(cp_, F3_IC(5), chunk, cn);
+        step(cp_, F3_IC(6), chunk, cn); step(cp_, F3_IC(7), chunk, cn); step(cp_, F3_IC(8), chunk, cn);
+    };
+    for (int chunk0 = 0; chunk0 < nchunks; chunk0 += 2) {       // nchunks is even (checked by the launcher)
+        chunk_body(F3_IC(0), chunk0);
+        chunk_body(F3_IC(1), chunk0 + 1);
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale[n];
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int y = ty_ * G3_TH + 2 * wm + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = tx_ * G3_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (y >= p.OH || x >= p.OW) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                p.out[(((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 3x3 / stride 1 / pad 1, weights from L2
+// The kernel above is bound by LDS bandwidth, not by the matrix cores: per step a CU moves 64 KB
+// of fragment reads + 16 KB of weight writes through LDS for 24 x 4 MFMAs (ablation on MI355X,
+// B=32 128x128x128->128: full 537 us; without the weight staging 440; without any staging 398;
+// without the barrier 536).  Here the weights never touch LDS: they are pre-arranged in HBM in
+// FRAGMENT order -- [plane][Cout/32][chunk][tap][lane][8] f16, i.e. the 1 KiB a wave needs for one
+// B operand is contiguous and lane-ordered -- and every wave loads its own B fragments straight
+// into registers with one coalesced global_load_dwordx4 per fragment, two steps ahead (register
+// ring of three sets; the steps of a wave walk its weight stream linearly).  What is left in LDS
+// is the double-buffered activation halo, so a block needs only TWO barriers per chunk of nine
+// taps (one before the next halo's first store -- its buffer was last read at tap 7 of the
+// previous chunk -- and one after its last store), and the four waves drift freely in between.
+// LDS traffic per step and CU: 83 KB -> 35 KB; L2 -> CU traffic doubles (both M-waves of a block
+// load the same weights: 32 KB per step and CU, ~40 % of the vector L1's 64 B/clk).
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][2][G3_HP * F3_LDB];      // [chunk parity][plane] 39.2 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile = blockIdx.x;
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = blockIdx.y * F3_BN;
+    const int y0 = ty_ * G3_TH - 1, x0 = tx_ * G3_TW - 1;       // image coords of halo (0,0)
+    const int nchunks = p.Cin / F3_BK;
+    const int total = 9 * nchunks;
+    const float* zero = reinterpret_cast<const float*>(&g_f3_zero16);
+
+    float4 rh[2];                                    // the halo travels in two halves (8 VGPRs, not 16)
+    auto load_halo = [&](int chunk, int half) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = tid + 256 * (2 * half + k);
+            const int hp = piece >> 2, q = piece & 3;
+            const int iy = y0 + hp / G3_HW, ix = x0 + hp % G3_HW;
+            const bool ok = hp < G3_HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float* src = p.in + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + chunk * F3_BK + 4 * q;
+            rh[k] = *reinterpret_cast<const float4*>(ok ? src : zero);
+        }
+    };
+    auto store_halo = [&](int buf, int half) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = tid + 256 * (2 * half + k);
+            const int hp = piece >> 2, q = piece & 3;
+            if (hp >= G3_HP) continue;
+            f16x4 h, l;
+            split_act4(rh[k], h, l);
+            const int off = hp * F3_LDB + 8 * q;
+            *reinterpret_cast<f16x4*>(&Ah[buf][0][off]) = h;
+            *reinterpret_cast<f16x4*>(&Ah[buf][1][off]) = l;
+        }
+    };
+
+    // ---- this wave's weight stream: [plane][ntile][step][lane][8]; ntile = 32 output channels
+    const int NT = p.Cout >> 5;
+    const int nt0 = (n0 >> 5) + wn * 2;
+    const _Float16* bsrc[2][2];                       // [plane][tile]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bsrc[pl][j] = p.wgt + ((int64_t)(pl * NT + nt0 + j) * total) * 512 + lane * 8;
+    f16x8 fb0[2][2], fb1[2][2], fb2[2][2];            // ring of three register sets [plane][tile]
+    auto load_b = [&](auto ring_, int sidx) {
+        constexpr int ring = decltype(ring_)::value;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(bsrc[pl][j] + (int64_t)sidx * 512);
+                if constexpr (ring == 0) fb0[pl][j] = v;
+                else if constexpr (ring == 1) fb1[pl][j] = v;
+                else fb2[pl][j] = v;
+            }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_off = ((2 * wm) * G3_HW + fr) * F3_LDB + 16 * fh;
+    f16x8 fa[2][2][2];                                // [set][plane][tile]
+    auto read_a = [&](int set, int pl, int hbuf, int tap) {
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            fa[set][pl][t] = *reinterpret_cast<const f16x8*>(
+                &Ah[hbuf][pl][a_off + ((t + ky) * G3_HW + kx) * F3_LDB]);
+    };
+    auto mfma_step = [&](int set, const f16x8 (&fb)[2][2], auto&& between0, auto&& between1) {
+        f16x8 wd[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wd[j] = lift_down(fb[0][j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = F3_MFMA(fa[set][1][i], wd[j], acc[i][j]);        // xl' * wd
+        between0();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = F3_MFMA(fa[set][0][i], fb[1][j], acc[i][j]);     // xh * wl
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = F3_MFMA(fa[set][0][i], fb[0][j], acc[i][j]);     // xh * wh
+        between1();
+    };
+
+    // ---- prologue: halo(0) in LDS, B(0), B(1) in flight
+    const int last = nchunks - 1;
+    load_halo(0, 0);
+    load_b(F3_IC(0), 0);
+    load_b(F3_IC(1), 1);
+    store_halo(0, 0);
+    load_halo(0, 1);
+    store_halo(0, 1);
+    __syncthreads();
+    read_a(0, 1, 0, 0);
+    read_a(0, 0, 0, 0);
+
+    auto step = [&](auto cp_, auto tap_, int chunk, int cn) {
+        constexpr int cp = decltype(cp_)::value, tap = decltype(tap_)::value;
+        constexpr int q = (cp + tap) & 1;             // A fragment set of this step
+        constexpr int ring = (cp * 9 + tap) % 3;      // B register set of this step (18 % 3 == 0)
+        const int s2 = chunk * 9 + tap + 2;           // B(s+2) -> the set used at step s-1
+        load_b(F3_IC((ring + 2) % 3), s2 < total ? s2 : total - 1);
+        if (tap == 0) load_halo(cn, 0);               // next chunk's halo, first half: stored at tap 2
+        if (tap == 3) load_halo(cn, 1);               // second half: stored at tap 5, first read at tap 8
+        __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top of the step
+        constexpr int nh = tap < 8 ? cp : cp ^ 1, nt = tap < 8 ? tap + 1 : 0;
+        auto b0 = [&]() { read_a(q ^ 1, 1, nh, nt); };
+        auto b1 = [&]() { read_a(q ^ 1, 0, nh, nt); };
+        if constexpr (ring == 0) mfma_step(q, fb0, b0, b1);
+        else if constexpr (ring == 1) mfma_step(q, fb1, b0, b1);
+        else mfma_step(q, fb2, b0, b1);
+        if (tap == 2) store_halo(cp ^ 1, 0);
+        if (tap == 5) store_halo(cp ^ 1, 1);
+        // tap 1: every wave is past the previous chunk's tap 7, the last reader of halo buffer cp^1,
+        // before anyone overwrites it at tap 2; tap 6: both halves stored before the reads of tap 8
+        if (tap == 1 || tap == 6) __syncthreads();
+    };
+    auto chunk_body = [&](auto cp_, int chunk) {
+        const int cn = chunk < last ? chunk + 1 : chunk;         // clamped: the last chunk re-reads itself
+        step(cp_, F3_IC(0), chunk, cn); step(cp_, F3_IC(1), chunk, cn); step(cp_, F3_IC(2), chunk, cn);
+        step(cp_, F3_IC(3), chunk, cn); step(cp_, F3_IC(4), chunk, cn); step(cp_, F3_IC(5), chunk, cn);
+        step(cp_, F3_IC(6), chunk, cn); step(cp_, F3_IC(7), chunk, cn); step(cp_, F3_IC(8), chunk, cn);
+    };
+    for (int chunk0 = 0; chunk0 < nchunks; chunk0 += 2) {       // nchunks is even (checked by the launcher)
+        chunk_body(F3_IC(0), chunk0);
+        chunk_body(F3_IC(1), chunk0 + 1);
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        const float sc = p.scale[n];
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int y = ty_ * G3_TH + 2 * wm + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = tx_ * G3_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (y >= p.OH || x >= p.OW) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                p.out[(((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n] = v;
+            }
+        }
+    }
+}
+
+// planes [2][Cout][9][Cin] (al3d_split_f16x3) -> fragment order [2][Cout/32][Cin/16][9][64][8]
+__global__ void pack_frag_kernel(const _Float16* __restrict__ planes, int Cout, int Cin, _Float16* __restrict__ out)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_plane = (int64_t)Cout * 9 * Cin;
+    if (o >= 2 * per_plane) return;
+    const int nchunks = Cin / 16;
+    int64_t r = o;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int tap = r % 9; r /= 9;
+    const int chunk = r % nchunks; r /= nchunks;
+    const int nt = r % (Cout / 32); r /= (Cout / 32);
+    const int pl = (int)r;
+    const int n = nt * 32 + (lane & 31), k = chunk * 16 + 8 * (lane >> 5) + e;
+    out[o] = planes[pl * per_plane + ((int64_t)n * 9 + tap) * Cin + k];
+}
+
+extern "C" int al3d_pack_f16x3_frag(const void* planes_f16x2, int Cout, int Cin, void* out_frag, void* stream)
+{
+    AL3D_REQUIRE(planes_f16x2 && out_frag, "al3d_pack_f16x3_frag: null pointer");
+    AL3D_REQUIRE(Cout >= 128 && Cout % 128 == 0 && Cin >= 32 && Cin % 32 == 0,
+                 "al3d_pack_f16x3_frag: needs Cout %% 128 == 0 and Cin %% 32 == 0 (got %d, %d)", Cout, Cin);
+    const int64_t count = 2 * (int64_t)Cout * 9 * Cin;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)planes_f16x2, Cout, Cin, (_Float16*)out_frag);
+    AL3D_CHECK_LAUNCH("pack_frag_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_frag, const float* scale,
+                                            const float* shift, float* out, int B, int H, int W, int Cin,
+                                            int Cout, int ldc, int coff, int relu, void* stream)
+{
+    ConvF3Params p;
+    p.in = in; p.wgt = (const _Float16*)wgt_frag; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = 3; p.stride = 1; p.pad = 1; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    p.OH = H; p.OW = W;
+    p.plane = (int64_t)Cout * 9 * Cin;
+    AL3D_REQUIRE(in && wgt_frag && out && scale, "al3d_conv3x3_nhwc_f16x3_frag: null pointer");
+    AL3D_REQUIRE(B >= 1 && H >= 1 && W >= 1, "al3d_conv3x3_nhwc_f16x3_frag: bad shape");
+    AL3D_REQUIRE(Cout % 128 == 0 && Cin % 32 == 0 && Cout >= 128 && Cin >= 32,
+                 "al3d_conv3x3_nhwc_f16x3_frag: needs Cout %% 128 == 0 and Cin %% 32 == 0 (got %d, %d)", Cout, Cin);
+    AL3D_REQUIRE(coff >= 0 && coff + Cout <= ldc, "al3d_conv3x3_nhwc_f16x3_frag: channel window exceeds ldc=%d", ldc);
+    AL3D_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)wgt_frag & 15) == 0,
+                 "al3d_conv3x3_nhwc_f16x3_frag: in/wgt must be 16-byte aligned");
+    p.tiles_x = (int)al3d_cdiv(p.OW, G3_TW);
+    p.tiles_y = (int)al3d_cdiv(p.OH, G3_TH);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)(Cout / F3_BN), 1);
+    hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv3x3_f16x3_frag_kernel");
+    return AL3D_OK;
+}
+
+// one-off weight split: f32 [count] * 2^sexp -> f16 [2][count] (wh, wl)
+__global__ void split_weights_f16_kernel(const float* __restrict__ w, int64_t count, float mul,
+                                         _Float16* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float ws = w[i] * mul;                      // power of two: exact
+    const _Float16 wh = (_Float16)ws;
+    out[i] = wh;
+    out[count + i] = (_Float16)(ws - (float)wh);
+}
+
+extern "C" int al3d_split_f16x3(const float* w, int64_t count, int scale_exp, void* out_f16x3, void* stream)
+{
+    AL3D_REQUIRE(w && out_f16x3 && count >= 0, "al3d_split_f16x3: bad arguments");
+    AL3D_REQUIRE(scale_exp >= -100 && scale_exp <= 100, "al3d_split_f16x3: scale exponent %d out of range", scale_exp);
+    if (count == 0) return AL3D_OK;
+    hipLaunchKernelGGL(split_weights_f16_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, count, ldexpf(1.0f, scale_exp), (_Float16*)out_f16x3);
+    AL3D_CHECK_LAUNCH("split_weights_f16_kernel");
+    return AL3D_OK;
+}
+
+static int convf3_check(const ConvF3Params& p, const char* name)
+{
+    AL3D_REQUIRE(p.in && p.wgt && p.out && p.scale, "%s: null pointer (scale carries the weight exponent and is required)", name);
+    AL3D_REQUIRE(p.B >= 1 && p.H >= 1 && p.W >= 1 && p.Cin >= 1 && p.Cout >= 1, "%s: bad shape", name);
+    AL3D_REQUIRE(p.Cin % F3_BK == 0, "%s: Cin=%d must be a multiple of %d", name, p.Cin, F3_BK);
+    AL3D_REQUIRE(p.coff >= 0 && p.coff + p.Cout <= p.ldc, "%s: channel window [%d,%d) exceeds ldc=%d",
+                 name, p.coff, p.coff + p.Cout, p.ldc);
+    AL3D_REQUIRE(((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.wgt & 15) == 0,
+                 "%s: in/wgt must be 16-byte aligned", name);
+    return AL3D_OK;
+}
+
+extern "C" int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x3, const float* scale,
+                                      const float* shift, float* out, int B, int H, int W, int Cin,
+                                      int Cout, int ksize, int stride, int pad, int ldc, int coff,
+                                      int relu, void* stream)
+{
+    ConvF3Params p;
+    p.in = in; p.wgt = (const _Float16*)wgt_f16x3; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    AL3D_REQUIRE(ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0, "al3d_conv2d_nhwc_f16x3: bad geometry");
+    p.OH = (H + 2 * pad - ksize) / stride + 1;
+    p.OW = (W + 2 * pad - ksize) / stride + 1;
+    AL3D_REQUIRE(p.OH >= 1 && p.OW >= 1, "al3d_conv2d_nhwc_f16x3: empty output");
+    p.plane = (int64_t)Cout * ksize * ksize * Cin;
+    int rc = convf3_check(p, "al3d_conv2d_nhwc_f16x3");
+    if (rc) return rc;
+    if (ksize == 3 && stride == 1 && pad == 1 && Cin % (2 * F3_BK) == 0) {     // halo-staged fast path (chunk pairs)
+        p.tiles_x = (int)al3d_cdiv(p.OW, G3_TW);
+        p.tiles_y = (int)al3d_cdiv(p.OH, G3_TH);
+        dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)al3d_cdiv(Cout, F3_BN), 1);
+        hipLaunchKernelGGL(conv3x3_f16x3_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        AL3D_CHECK_LAUNCH("conv3x3_f16x3_halo_kernel");
+        return AL3D_OK;
+    }
+    p.tiles_x = (int)al3d_cdiv(p.OW, F3_TW);
+    p.tiles_y = (int)al3d_cdiv(p.OH, F3_TH);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)al3d_cdiv(Cout, F3_BN), 1);
+    hipLaunchKernelGGL(conv2d_f16x3_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv2d_f16x3_kernel<conv>");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_deconv2x2_nhwc_f16x3(const float* in, const void* wgt_f16x3, const float* scale,
+                                         const float* shift, float* out, int B, int H, int W, int Cin,
+                                         int Cout, int ldc, int coff, int relu, void* stream)
+{
+    ConvF3Params p;
+    p.in = in; p.wgt = (const _Float16*)wgt_f16x3; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = 2; p.stride = 2; p.pad = 0; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    p.OH = 2 * H; p.OW = 2 * W;
+    p.plane = (int64_t)Cout * 4 * Cin;
+    int rc = convf3_check(p, "al3d_deconv2x2_nhwc_f16x3");
+    if (rc) return rc;
+    p.tiles_x = (int)al3d_cdiv(W, F3_TW);
+    p.tiles_y = (int)al3d_cdiv(H, F3_TH);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)al3d_cdiv(Cout, F3_BN), 4);
+    hipLaunchKernelGGL(conv2d_f16x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv2d_f16x3_kernel<deconv>");
+    return AL3D_OK;
+}

@@ -42,25 +42,99 @@ def split_bf16x3(w_packed):
     return out
 
 
-# Arithmetic of the MFMA conv kernels: "bf16x6" = fp32-faithful six-product split on the bf16
-# matrix cores (default), "f32" = fp32-input MFMA (bitwise an fp32 FMA chain).
+def split_f16x3(w_packed, scale=None):
+    """f32 packed weights (device) -> (f16 [2, *shape] planes (wh, wl), scale * 2^-s).
+
+    ``s`` is the power of two that brings max|w| just under 2^14 (f16's exponent range is spent
+    on the weights once, here, so the kernel never depends on it); it is folded back into the
+    per-channel scale the kernel multiplies its accumulator with -- exact."""
+    import math
+    w = _dev(w_packed, torch.float32, "w")
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    if not math.isfinite(amax):
+        raise lib.Al3dError("split_f16x3: non-finite weight")
+    s = 14 - math.frexp(amax)[1] if amax > 0.0 else 0          # amax <= 2^e  ->  amax * 2^s <= 2^14
+    s = max(-100, min(100, s))
+    out = torch.empty((2,) + tuple(w.shape), dtype=torch.float16, device=w.device)
+    lib.call("al3d_split_f16x3", _ptr(w), w.numel(), s, _ptr(out), _stream())
+    cout = w.shape[0]
+    base = torch.ones(cout, dtype=torch.float32, device=w.device) if scale is None else \
+        _dev(scale, torch.float32, "scale")
+    return out, (base.double() * 2.0 ** (-s)).float().contiguous()
+
+
+# Arithmetic of the MFMA conv kernels (AL3D_MATH):
+#   "f16x3"  (default) dense neck + head: three f16 products per MAC (fp32-class, activations
+#            < 65504); sparse encoder: bf16x6
+#   "bf16x6" fp32-faithful six-product split on the bf16 matrix cores everywhere (full fp32 range)
+#   "f32"    fp32-input MFMA (bitwise an fp32 FMA chain)
 import os as _os
-MATH = _os.environ.get("AL3D_MATH", "bf16x6")
+MATH = _os.environ.get("AL3D_MATH", "f16x3")
+if MATH not in ("f16x3", "bf16x6", "f32"):
+    raise lib.Al3dError(f"AL3D_MATH={MATH!r}: expected f16x3, bf16x6 or f32")
+
+
+def sparse_math():
+    """Arithmetic of the sparse encoder under the current MATH."""
+    return "f32" if MATH == "f32" else "bf16x6"
+
+
+def pack_frag_f16x3(planes):
+    """f16 planes [2,Cout,9,Cin] -> MFMA fragment order [2,Cout/32,Cin/16,9,64,8] (3x3/s1/p1 layers:
+    every wave streams its B operands from L2, no LDS staging)."""
+    planes = _dev(planes, torch.float16, "planes")
+    _, cout, taps, cin = planes.shape
+    assert taps == 9
+    out = torch.empty((2, cout // 32, cin // 16, 9, 64, 8), dtype=torch.float16, device=planes.device)
+    lib.call("al3d_pack_f16x3_frag", _ptr(planes), cout, cin, _ptr(out), _stream())
+    return out
+
+
+def frag_ok(cout, cin, ksize, stride, pad):
+    return ksize == 3 and stride == 1 and pad == 1 and cout % 128 == 0 and cin % 32 == 0
+
+
+def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
+    """Packed f32 weights + folded-BN scale -> (weights in the dense kernels' format for MATH,
+    the scale to hand them).  With the layer geometry given, 3x3/s1/p1 layers get the
+    fragment-ordered f16x3 layout."""
+    if MATH == "f16x3":
+        planes, scale = split_f16x3(w_packed, scale)
+        if ksize is not None and frag_ok(planes.shape[1], planes.shape[3], ksize, stride, pad):
+            return pack_frag_f16x3(planes), scale
+        return planes, scale
+    if MATH == "bf16x6":
+        return split_bf16x3(w_packed), scale
+    return w_packed, scale
 # sparse-conv structure for the bf16x6 arithmetic: "auto" = the software-pipelined wave kernel;
 # "wave" (unpipelined wave kernel) and "tile" (LDS-staged 128-row tile) give the same bits, for A/B
 SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
 
 
 # ------------------------------------------------------------------ kernels
+_DENSE_KIND = {torch.float32: "f32", torch.bfloat16: "bf16x6", torch.float16: "f16x3"}
+
+
 def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, coff=0):
     x = _dev(x, torch.float32, "x")
-    split = w_packed.dtype == torch.bfloat16          # [3, Cout, taps, Cin] from split_bf16x3
-    if split:
-        w_packed = _dev(w_packed, torch.bfloat16, "w")
-        wshape = w_packed.shape[1:]
-    else:
-        w_packed = _dev(w_packed, torch.float32, "w")
-        wshape = w_packed.shape
+    # the weight format selects the arithmetic: bf16 [3,Cout,taps,Cin] (split_bf16x3),
+    # f16 [2,Cout,taps,Cin] (split_f16x3, scale required) or plain f32 [Cout,taps,Cin]
+    kind = _DENSE_KIND[w_packed.dtype]
+    w_packed = _dev(w_packed, w_packed.dtype, "w")
+    if kind == "f16x3" and scale is None:
+        raise lib.Al3dError("conv2d_nhwc: f16x3 weights need the scale returned by split_f16x3")
+    if w_packed.dim() == 6:                           # fragment-ordered f16x3 (pack_frag_f16x3)
+        B, H, W, Cin = x.shape
+        Cout = w_packed.shape[1] * 32
+        if not (ksize == 3 and stride == 1 and pad == 1 and w_packed.shape[2] * 16 == Cin):
+            raise lib.Al3dError("conv2d_nhwc: fragment-ordered weights are for 3x3/s1/p1 layers of matching Cin")
+        if out is None:
+            out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+        assert out.shape[:3] == (B, H, W) and out.is_contiguous()
+        lib.call("al3d_conv3x3_nhwc_f16x3_frag", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
+                 B, H, W, Cin, Cout, out.shape[3], coff, 1 if relu else 0, _stream())
+        return out
+    wshape = w_packed.shape[1:] if kind != "f32" else w_packed.shape
     B, H, W, Cin = x.shape
     Cout = wshape[0]
     assert wshape[1] == ksize * ksize and wshape[2] == Cin
@@ -69,8 +143,7 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
     if out is None:
         out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, OH, OW) and out.is_contiguous()
-    lib.call("al3d_conv2d_nhwc_bf16x6" if split else "al3d_conv2d_nhwc_f32", _ptr(x), _ptr(w_packed),
-             _ptr(scale), _ptr(shift), _ptr(out),
+    lib.call("al3d_conv2d_nhwc_" + kind, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
              B, H, W, Cin, Cout, ksize, stride, pad, out.shape[3], coff, 1 if relu else 0, _stream())
     return out
 
@@ -78,12 +151,14 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
 def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0):
     x = _dev(x, torch.float32, "x")
     B, H, W, Cin = x.shape
-    split = w_packed.dtype == torch.bfloat16
-    Cout = w_packed.shape[1] if split else w_packed.shape[0]
+    kind = _DENSE_KIND[w_packed.dtype]
+    Cout = w_packed.shape[1] if kind != "f32" else w_packed.shape[0]
+    if kind == "f16x3" and scale is None:
+        raise lib.Al3dError("deconv2x2_nhwc: f16x3 weights need the scale returned by split_f16x3")
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, 2 * H, 2 * W) and out.is_contiguous()
-    lib.call("al3d_deconv2x2_nhwc_bf16x6" if split else "al3d_deconv2x2_nhwc_f32", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
+    lib.call("al3d_deconv2x2_nhwc_" + kind, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
              B, H, W, Cin, Cout, out.shape[3], coff, 1 if relu else 0, _stream())
     return out
 
@@ -201,7 +276,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
                  _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     if mfma is None:
-        mfma = (cin, cout) in MFMA_PAIRS and ("wave2" if MATH == "bf16x6" else True)
+        mfma = (cin, cout) in MFMA_PAIRS and ("wave2" if sparse_math() == "bf16x6" else True)
     if mfma in ("bf16x6", "wave", "wave2"):
         w6 = split_bf16x3(w.permute(2, 0, 1).contiguous())
         fn = {"bf16x6": "al3d_sp_conv_bf16x6", "wave": "al3d_sp_conv_wave_bf16x6",

@@ -130,7 +130,7 @@ class _SparseEncoderBase(nn.Module):
     def _pad_cin(m):
         """Input channels the layer is run with: a narrow first layer (5 -> 16) is zero-padded to
         16 input channels so it runs on the matrix cores like every other layer (bf16x6 only)."""
-        if D.MATH == "bf16x6" and m.in_channels < 16 and (16, m.out_channels) in MFMA_PAIRS:
+        if D.sparse_math() == "bf16x6" and m.in_channels < 16 and (16, m.out_channels) in MFMA_PAIRS:
             return 16
         return m.in_channels
 
@@ -143,7 +143,7 @@ class _SparseEncoderBase(nn.Module):
             w = torch.nn.functional.pad(w, (0, 0, 0, cin - m.in_channels))
         if (cin, m.out_channels) in MFMA_PAIRS:
             w = w.permute(2, 0, 1).contiguous().to(device)
-            return D.split_bf16x3(w) if D.MATH == "bf16x6" else w
+            return D.split_bf16x3(w) if D.sparse_math() == "bf16x6" else w
         return w.contiguous().to(device)
 
     @staticmethod

@@ -133,9 +133,7 @@ class MultiGroupHead(nn.Module):
             bs.append(t.conv_cls.bias)
             off += t.conv_cls.out_channels
         self._ch = off
-        self._w = D.pack_conv_weight(torch.cat([w.detach() for w in ws], dim=0)).to(device)
-        if D.MATH == "bf16x6":
-            self._w = D.split_bf16x3(self._w)
+        self._w, self._wscale = D.pack_dense(D.pack_conv_weight(torch.cat([w.detach() for w in ws], dim=0)).to(device))
         self._b = torch.cat([b.detach() for b in bs]).float().contiguous().to(device)
         self._packed_dev = (device, D.MATH)
 
@@ -144,7 +142,7 @@ class MultiGroupHead(nn.Module):
         (``box_preds [B,H,W,na*10]``, ``cls_preds [B,H,W,na*nc]``) like Head.forward
         (mg_head.py:222-231), plus the fused buffer under ``_fused``."""
         self._prepare(x.device)
-        fused = D.conv2d_nhwc(x, self._w, None, self._b, 1, 1, 0, False)
+        fused = D.conv2d_nhwc(x, self._w, self._wscale, self._b, 1, 1, 0, False)
         rets = []
         for t, task in enumerate(self.tasks):
             b0, c0 = self._box_off[t], self._cls_off[t]

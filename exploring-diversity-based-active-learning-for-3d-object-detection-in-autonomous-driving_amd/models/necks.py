@@ -69,10 +69,6 @@ class RPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.xavier_uniform_(m.weight)
 
-    @staticmethod
-    def _w(w):
-        return D.split_bf16x3(w) if D.MATH == "bf16x6" else w
-
     def _prepare(self, device):
         if getattr(self, "_packed_dev", None) == (device, D.MATH):
             return
@@ -84,19 +80,21 @@ class RPN(nn.Module):
                 if isinstance(m, nn.Conv2d):
                     scale, shift = D.fold_bn(mods[j + 1])
                     pad = 1 if (j > 0 and isinstance(mods[j - 1], nn.ZeroPad2d)) else m.padding[0]
-                    convs.append(dict(w=self._w(D.pack_conv_weight(m.weight).to(device)), scale=scale.to(device),
-                                      shift=shift.to(device), k=m.kernel_size[0], s=m.stride[0], p=pad))
+                    w, scale = D.pack_dense(D.pack_conv_weight(m.weight).to(device), scale.to(device),
+                                            m.kernel_size[0], m.stride[0], pad)
+                    convs.append(dict(w=w, scale=scale, shift=shift.to(device), k=m.kernel_size[0],
+                                      s=m.stride[0], p=pad))
             self._blocks_p.append(convs)
         for de in self.deblocks:
             up, bn = de[0], de[1]
             scale, shift = D.fold_bn(bn)
             if isinstance(up, nn.ConvTranspose2d):
                 assert up.kernel_size == (2, 2) and up.stride == (2, 2), "only 2x2/s2 deconv is built"
-                self._deblocks_p.append(dict(deconv=True, w=self._w(D.pack_deconv_weight(up.weight).to(device)),
-                                             scale=scale.to(device), shift=shift.to(device)))
+                w, scale = D.pack_dense(D.pack_deconv_weight(up.weight).to(device), scale.to(device))
+                self._deblocks_p.append(dict(deconv=True, w=w, scale=scale, shift=shift.to(device)))
             else:
-                self._deblocks_p.append(dict(deconv=False, w=self._w(D.pack_conv_weight(up.weight).to(device)),
-                                             scale=scale.to(device), shift=shift.to(device),
+                w, scale = D.pack_dense(D.pack_conv_weight(up.weight).to(device), scale.to(device))
+                self._deblocks_p.append(dict(deconv=False, w=w, scale=scale, shift=shift.to(device),
                                              k=up.kernel_size[0], s=up.stride[0]))
         self._packed_dev = (device, D.MATH)
 

@@ -323,6 +323,31 @@ int al3d_deconv2x2_nhwc_bf16x6(const float* in, const void* wgt_bf16x3, const fl
                                const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
                                int ldc, int coff, int relu, void* stream);
 
+/* fp32-class variants on the f16 matrix cores ("f16x3", the default of the dense neck + head):
+ * activations are split while staged into xh = f16(x), xl = f16((x - xh) * 2^11); weights are
+ * pre-split once with al3d_split_f16x3() -- f32 [count], multiplied by 2^scale_exp chosen by the
+ * caller so that max|w * 2^scale_exp| <= 2^14 -- into f16 [2][count] planes
+ * (wh, wl = ws - wh); x*ws = xh*wh + xh*wl + xl*(wh * 2^-11) in ONE fp32 accumulator, dropped term
+ * <= 2^-24 relative.  `scale` is REQUIRED and must already carry the factor
+ * 2^-scale_exp (exact).  Valid for |activation| < 65504 (larger values give inf/NaN outputs --
+ * use the bf16x6 entries for the full fp32 range).  Otherwise the contract of
+ * al3d_conv2d_nhwc_f32 / al3d_deconv2x2_nhwc_f32 (same reference lines), Cin % 16 == 0. */
+int al3d_split_f16x3(const float* w, int64_t count, int scale_exp, void* out_f16x2, void* stream);
+int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x2, const float* scale,
+                           const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                           int ksize, int stride, int pad, int ldc, int coff, int relu, void* stream);
+int al3d_deconv2x2_nhwc_f16x3(const float* in, const void* wgt_f16x2, const float* scale,
+                              const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                              int ldc, int coff, int relu, void* stream);
+/* 3x3 / stride 1 / pad 1 layers (11 of the neck's 15 launches, rpn.py:66-113): same arithmetic,
+ * weights re-arranged once by al3d_pack_f16x3_frag() from the [2][Cout][9][Cin] planes into MFMA
+ * fragment order [2][Cout/32][Cin/16][9][64 lanes][8] so that every wave streams its B operands
+ * straight from L2 into registers (no LDS staging of weights).  Cout % 128 == 0, Cin % 32 == 0. */
+int al3d_pack_f16x3_frag(const void* planes_f16x2, int Cout, int Cin, void* out_frag, void* stream);
+int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_frag, const float* scale,
+                                 const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                                 int ldc, int coff, int relu, void* stream);
+
 /* BEV embedding: mean over W then over H of an NHWC map, [B,H,W,C] -> [B,C].
  * Replaces `fpn_feats[-1].mean(-1).mean(-1)` (det3d/selectors/feature_selector.py:68-71). */
 int64_t al3d_gap_workspace_bytes(int B, int H, int C);

@@ -119,3 +119,113 @@ def test_deconv_bf16x6_matches_f32_kernel():
     a = D.deconv2x2_nhwc(_nhwc(x).to(DEV), wp, None, None, False)
     b = D.deconv2x2_nhwc(_nhwc(x).to(DEV), D.split_bf16x3(wp), None, None, False)
     torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-6)
+
+
+# ---------------------------------------------------------------- f16x3 (fp32-class) kernels
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(1, 16, 16, 32, 128, 3, 1, 1), (2, 24, 40, 64, 128, 3, 1, 1),
+                                                  (1, 32, 32, 128, 256, 3, 2, 1), (2, 13, 19, 32, 40, 1, 1, 0),
+                                                  (1, 64, 64, 256, 128, 3, 1, 1)])
+@pytest.mark.parametrize("xmag", [1.0, 1e-4, 300.0])
+def test_conv2d_f16x3_is_fp32_class(B, H, W, Cin, Cout, k, s, p, xmag):
+    """Three f16 products per MAC: error against the exact (fp64) convolution, as a fraction of
+    sum|a*b|, must stay at the fp32-input kernel's level -- at O(1) activations, at activations
+    below f16's normal range (1e-4 * lognormal: the high piece of many values is an f16 subnormal, the lifted residual piece
+    carries the rest) and at large ones (300 * lognormal, still < 65504).  Tolerance: 1.5e-6 of sum|a*b| like the bf16x6
+    test, and at most 3x the fp32-input kernel's error (measured ~1x)."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(H * 7 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, H, W, generator=g)) * xmag
+    x = x.clamp(-6.0e4, 6.0e4)                       # the lognormal tail may not leave f16's range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    ref = _nhwc(F.conv2d(x.double(), w.double(), stride=s, padding=p))
+    wp = D.pack_conv_weight(w).to(DEV)
+    got32 = D.conv2d_nhwc(_nhwc(x).to(DEV), wp, None, None, k, s, p, False).cpu().double()
+    w3, sc3 = D.split_f16x3(wp)
+    got3 = D.conv2d_nhwc(_nhwc(x).to(DEV), w3, sc3, None, k, s, p, False)
+    if D.frag_ok(Cout, Cin, k, s, p):
+        # same arithmetic with the weights streamed in fragment order: the same bits
+        gotf = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_frag_f16x3(w3), sc3, None, k, s, p, False)
+        assert torch.equal(gotf, got3)
+    got3 = got3.cpu().double()
+    scale = _nhwc(F.conv2d(x.abs().double(), w.abs().double(), stride=s, padding=p))
+    e32 = ((got32 - ref).abs() / scale).max().item()
+    e3 = ((got3 - ref).abs() / scale).max().item()
+    assert e32 < 1.5e-6 and e3 < 1.5e-6 and e3 < 3.0 * e32 + 1e-8, (e32, e3)
+
+
+def test_split_f16x3_planes():
+    """wh + wl reproduces w * 2^s to 2^-22 relative, max|w 2^s| in (2^13, 2^14]."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(1)
+    w = (torch.randn(64, 64, generator=g) * 0.03).to(DEV)
+    pl, sc = D.split_f16x3(w)
+    mul = 1.0 / float(sc[0])
+    assert mul == 2.0 ** round(np.log2(mul))
+    ws = w.double() * mul
+    assert 2.0 ** 13 < float(ws.abs().max()) <= 2.0 ** 14
+    p = pl.double()
+    big = ws.abs() > 0.25                                   # lo piece in f16's normal range
+    assert float(((p[0] + p[1] - ws).abs() / ws.abs())[big].max()) < 2.0 ** -22
+    assert float((p[0] + p[1] - ws).abs().max()) < 2.0 ** -9    # absolute, in units of 2^-s
+    assert pl.shape == (2, 64, 64)
+
+
+def test_conv2d_f16x3_scale_shift_relu_and_window():
+    """BN scale (with the folded weight exponent), shift, ReLU and the concat window."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 24, 40, generator=g)
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24.0
+    scale = torch.rand(96, generator=g) + 0.5
+    shift = torch.randn(96, generator=g) * 0.1
+    ref = (F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).relu()
+    w3, sc3 = D.split_f16x3(D.pack_conv_weight(w).to(DEV), scale.to(DEV))
+    out = torch.full((2, 24, 40, 160), -7.0, device=DEV)
+    D.conv2d_nhwc(_nhwc(x).to(DEV), w3, sc3, shift.to(DEV), 3, 1, 1, True, out=out, coff=64)
+    o = out.cpu()
+    torch.testing.assert_close(o[..., 64:], _nhwc(ref), rtol=RTOL, atol=ATOL)
+    assert torch.all(o[..., :64] == -7.0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 128, 128, 256, 128), (2, 24, 40, 64, 128), (3, 9, 70, 128, 256),
+                                            (1, 64, 64, 256, 256)])
+def test_conv3x3_f16x3_fragment_stream_equals_lds_staged_kernel(B, H, W, Cin, Cout):
+    """Both 3x3 kernels run the same products in the same order: bit-identical outputs, including
+    ragged tiles (H, W not multiples of 4 x 32), scale/shift/ReLU and a concat window."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, 9, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    w3, sc3 = D.split_f16x3(w, scale)
+    a = torch.full((B, H, W, Cout + 32), -3.0, device=DEV)
+    b = torch.full((B, H, W, Cout + 32), -3.0, device=DEV)
+    D.conv2d_nhwc(x, w3, sc3, shift, 3, 1, 1, True, out=a, coff=32)
+    D.conv2d_nhwc(x, D.pack_frag_f16x3(w3), sc3, shift, 3, 1, 1, True, out=b, coff=32)
+    assert torch.equal(a, b)
+    assert torch.all(b[..., :32] == -3.0)
+
+
+def test_deconv_f16x3_matches_f32_kernel():
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    w = torch.randn(64, 96, 2, 2, generator=g) / 8.0
+    wp = D.pack_deconv_weight(w).to(DEV)
+    a = D.deconv2x2_nhwc(_nhwc(x).to(DEV), wp, None, None, False)
+    w3, sc3 = D.split_f16x3(wp)
+    b = D.deconv2x2_nhwc(_nhwc(x).to(DEV), w3, sc3, None, False)
+    torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-6)
+
+
+def test_conv2d_f16x3_out_of_range_activation_is_not_silent():
+    """|x| >= 65504 cannot be carried by the f16 pieces: the output must be non-finite, never a
+    plausible wrong number (the sweep checks its embeddings for finiteness)."""
+    from al3d import detector_ops as D
+    x = torch.ones(1, 8, 8, 32)
+    x[0, 3, 3, 5] = 7.0e4
+    w3, sc3 = D.split_f16x3(torch.full((128, 9, 32), 0.01).to(DEV))
+    out = D.conv2d_nhwc(x.to(DEV), w3, sc3, None, 3, 1, 1, False).cpu()
+    assert not torch.isfinite(out[0, 3, 3]).any()
+    assert torch.isfinite(out[0, 7, 7]).all()

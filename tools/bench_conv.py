@@ -15,9 +15,15 @@ for (H, Cin, Cout, k, s, p) in shapes:
     w = torch.randn(Cout, k * k, Cin, device=dev) * 0.05
     if os.environ.get("AL3D_BENCH_ZERO") == "1":      # data-dependent power: all-zero operands toggle nothing
         x.zero_(); w.zero_()
-    if MODE == 'bf16x6':
+    if MODE == "bf16x6":
         w = D.split_bf16x3(w)
     sc = torch.ones(Cout, device=dev); sh = torch.zeros(Cout, device=dev)
+    if MODE == 'f16x3':
+        w, sc = D.split_f16x3(w, sc)
+    if MODE == 'f16x3frag':
+        w, sc = D.split_f16x3(w, sc)
+        if D.frag_ok(Cout, Cin, k, s, p):
+            w = D.pack_frag_f16x3(w)
     OH = (H + 2 * p - k) // s + 1
     out = torch.empty(B, OH, OH, Cout, device=dev)
     for _ in range(3):
