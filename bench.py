@@ -309,8 +309,8 @@ def main():
 _DTYPE = {
     "f32": "f32",
     "bf16x6": "f32 (exact 3-way bf16 split, 6 MFMA products per MAC, f32 accumulate)",
-    "f16x3": "f32 (dense neck+head: 2-way f16 split, 3 MFMA products per MAC; sparse encoder: 3-way bf16 "
-             "split, 6 products; f32 accumulate)",
+    "f16x3": "f32 (2-way f16 split of every operand, 3 MFMA products per MAC, f32 accumulate; sparse "
+             "encoder, dense neck and head)",
 }
 
 

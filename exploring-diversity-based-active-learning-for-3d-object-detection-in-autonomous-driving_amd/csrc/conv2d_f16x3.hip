@@ -59,7 +59,7 @@ struct ConvF3Params {
 __device__ __forceinline__ void split_act(float x, _Float16& h, _Float16& l)
 {
     h = (_Float16)x;                                  // subnormal below 2^-14 (kept: see the header)
-    l = (_Float16)((x - (float)h) * 2048.0f);
+    l = (_Float16)__builtin_fmaf((float)h, -2048.0f, x * 2048.0f);   // == (x - h) * 2^11 exactly; one v_fma_mix
 }
 
 __device__ __forceinline__ void split_act4(const float4& v, f16x4& h, f16x4& l)

@@ -209,10 +209,36 @@ __global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restri
 __device__ __attribute__((aligned(256))) float g_sw_zero[128];   // stays zero: target of masked gathers
 __device__ int g_sw_neg1 = -1;                                    // "no neighbour" for masked index loads
 
-template <int CIN, int COUT, int NW, int UPS, int P>
+// ---- f16x3 arithmetic (see conv2d_f16x3.hip): x = xh + xl' * 2^-11 with xh = f16(x),
+// xl' = f16((x - xh) * 2^11); x*w = xh*wh + xh*wl + xl'*(wh * 2^-11), three f16 MFMAs per tile.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sw_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sw_split8_f16(const float4& lo, const float4& hi, f16x8& ph, f16x8& pl)
+{
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const sw_f32x2 x = {v[2 * e], v[2 * e + 1]};
+        const sw_f16x2 xh = __builtin_convertvector(x, sw_f16x2);
+        // (x - xh) * 2^11 == fma(xh, -2^11, x * 2^11) exactly (power-of-two scalings, exact residual)
+        const sw_f32x2 r = {__builtin_fmaf((float)xh[0], -2048.0f, x[0] * 2048.0f),
+                            __builtin_fmaf((float)xh[1], -2048.0f, x[1] * 2048.0f)};
+        h[e] = __builtin_bit_cast(unsigned, xh);
+        l[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sw_f16x2));
+    }
+    ph = __builtin_bit_cast(f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    pl = __builtin_bit_cast(f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+__device__ __forceinline__ uint4 sw_lift_down(const uint4& wh)       // 8 f16 * 2^-11 (packed multiplies)
+{
+    return __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, wh) * (_Float16)0.00048828125f);
+}
+
+template <int CIN, int COUT, int NW, int UPS, int P, int NPL>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8))) void sp_conv_wave2_kernel(const float* __restrict__ fin,
                                                             const int* __restrict__ nbr, int K,
-                                                            const __bf16* __restrict__ wgt,   // [3][COUT][K][CIN]
+                                                            const unsigned short* __restrict__ wgt,   // [NPL][COUT][K][CIN]: 3 bf16 planes (bf16x6) or 2 f16 planes (f16x3)
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ residual, int relu,
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     constexpr int NT = 64 * NW;                          // threads; the workgroup owns 32*NW output rows
     constexpr int G = P > UPS ? P / UPS : 1;             // slabs per unrolled group (ring slots stay compile-time)
     static_assert(P % UPS == 0 || UPS % P == 0, "ring depth and slab size must divide one another");
-    constexpr int SLAB_PIECES = UPS * 3 * NROWS * 2;
+    constexpr int SLAB_PIECES = UPS * NPL * NROWS * 2;   // 16-byte pieces fetched per slab (LDS always holds 3 planes)
     constexpr int PASSES = (SLAB_PIECES + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) unsigned char Ws[2][UPS * UNIT_BYTES + 64];
     __shared__ __attribute__((aligned(16))) unsigned char zrow[64];
@@ -295,8 +321,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     auto slab_src = [&](int slab, int q) -> const uint4* {
         int piece = tid + NT * q;
         piece = piece < SLAB_PIECES ? piece : SLAB_PIECES - 1;
-        const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
-        const int uu = (piece >> 1) / (NROWS * 3);
+        const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % NPL;
+        const int uu = (piece >> 1) / (NROWS * NPL);
         int unit = slab * UPS + uu;
         unit = unit < nunits ? unit : nunits - 1;
         const int tap = s_taps[unit / KG], g = unit % KG;
@@ -310,9 +336,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     auto store_piece = [&](int buf, int q, const uint4& v) {
         const int piece = tid + NT * q;
         if (piece >= SLAB_PIECES) return;
-        const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % 3;
-        const int uu = (piece >> 1) / (NROWS * 3);
+        const int half = piece & 1, n = (piece >> 1) % NROWS, pl = ((piece >> 1) / NROWS) % NPL;
+        const int uu = (piece >> 1) / (NROWS * NPL);
         *reinterpret_cast<uint4*>(&Ws[buf][uu * UNIT_BYTES + (pl * NROWS + n) * SW_PITCH + 16 * half]) = v;
+        if (NPL == 2 && pl == 0)                        // f16x3: third LDS plane = wh * 2^-11, derived once per slab
+            *reinterpret_cast<uint4*>(&Ws[buf][uu * UNIT_BYTES + (2 * NROWS + n) * SW_PITCH + 16 * half]) = sw_lift_down(v);
     };
     auto store_slab = [&](int buf) {
         store_piece(buf, 0, rw0);
@@ -366,22 +394,38 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
             for (int i = 0; i < UPS; ++i) {
                 const int slot = (gi * UPS + i) % P;                    // compile-time after unrolling
                 if (cur_tap(cc) >= 0) {
-                    bf16x8 a0, a1, a2;
-                    sw_split8(dlo[slot], dhi[slot], a0, a1, a2);
                     const unsigned char* ub = &Ws[buf][i * UNIT_BYTES];
+                    if constexpr (NPL == 3) {
+                        bf16x8 a0, a1, a2;
+                        sw_split8(dlo[slot], dhi[slot], a0, a1, a2);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = j * 32 + fr;
-                        const bool live = n < COUT;
-                        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(live ? ub + (0 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
-                        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(live ? ub + (1 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
-                        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(live ? ub + (2 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = j * 32 + fr;
+                            const bool live = n < COUT;
+                            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(live ? ub + (0 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(live ? ub + (1 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                            const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(live ? ub + (2 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+                        }
+                    } else {
+                        f16x8 ah, al;
+                        sw_split8_f16(dlo[slot], dhi[slot], ah, al);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = j * 32 + fr;
+                            const bool live = n < COUT;
+                            const f16x8 wh = *reinterpret_cast<const f16x8*>(live ? ub + (0 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                            const f16x8 wl = *reinterpret_cast<const f16x8*>(live ? ub + (1 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                            const f16x8 wd = *reinterpret_cast<const f16x8*>(live ? ub + (2 * NROWS + n) * SW_PITCH + 16 * fh : zrow);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wd, acc[j], 0, 0, 0);     // smallest first
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[j], 0, 0, 0);
+                        }
                     }
                 }
                 advance(cc);
@@ -414,11 +458,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     }
 }
 
-#define SW2_DISPATCH(CI, CO, NW, UPS, P)                                                              \
+#define SW2_DISPATCH(CI, CO, NW, UPS, P, NPL)                                                         \
     if (cin == CI && cout == CO) {                                                                    \
-        hipLaunchKernelGGL((sp_conv_wave2_kernel<CI, CO, NW, UPS, P>),                                \
+        hipLaunchKernelGGL((sp_conv_wave2_kernel<CI, CO, NW, UPS, P, NPL>),                           \
                            dim3((unsigned)al3d_cdiv(n_out, 32 * NW)), dim3(64 * NW), 0, s, fin, nbr, K, \
-                           (const __bf16*)wgt_bf16x3, scale, shift, residual, relu, fout, n_out);     \
+                           (const unsigned short*)wgt, scale, shift, residual, relu, fout, n_out);    \
         AL3D_CHECK_LAUNCH("sp_conv_wave2_kernel");                                                    \
         return AL3D_OK;                                                                               \
     }
@@ -432,9 +476,26 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
     if (n_out == 0) return AL3D_OK;
     AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave2_bf16x6: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    SW2_DISPATCH(16, 16, 4, 4, 4) SW2_DISPATCH(16, 32, 8, 2, 2) SW2_DISPATCH(32, 32, 8, 2, 2) SW2_DISPATCH(32, 64, 8, 4, 2)
-    SW2_DISPATCH(64, 64, 8, 4, 2) SW2_DISPATCH(64, 128, 16, 2, 2) SW2_DISPATCH(128, 128, 16, 2, 2)
+    const void* wgt = wgt_bf16x3;
+    SW2_DISPATCH(16, 16, 4, 4, 4, 3) SW2_DISPATCH(16, 32, 8, 2, 2, 3) SW2_DISPATCH(32, 32, 8, 2, 2, 3) SW2_DISPATCH(32, 64, 8, 4, 2, 3)
+    SW2_DISPATCH(64, 64, 8, 4, 2, 3) SW2_DISPATCH(64, 128, 16, 2, 2, 3) SW2_DISPATCH(128, 128, 16, 2, 2, 3)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_bf16x6: unsupported channel pair %d -> %d", cin, cout);
+}
+
+extern "C" int al3d_sp_conv_wave2_f16x3(const float* fin, const int* nbr, int K, const void* wgt_f16x2,
+                                        int cin, int cout, const float* scale, const float* shift,
+                                        const float* residual, int relu, float* fout, int n_out,
+                                        void* stream)
+{
+    AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_wave2_f16x3: bad sizes");
+    if (n_out == 0) return AL3D_OK;
+    AL3D_REQUIRE(fin && nbr && wgt_f16x2 && fout, "al3d_sp_conv_wave2_f16x3: null pointer");
+    AL3D_REQUIRE(scale, "al3d_sp_conv_wave2_f16x3: scale carries the weight exponent and is required");
+    hipStream_t s = (hipStream_t)stream;
+    const void* wgt = wgt_f16x2;
+    SW2_DISPATCH(16, 16, 4, 4, 4, 2) SW2_DISPATCH(16, 32, 8, 2, 2, 2) SW2_DISPATCH(32, 32, 8, 2, 2, 2) SW2_DISPATCH(32, 64, 8, 4, 2, 2)
+    SW2_DISPATCH(64, 64, 8, 4, 2, 2) SW2_DISPATCH(64, 128, 16, 2, 2, 2) SW2_DISPATCH(128, 128, 16, 2, 2, 2)
+    return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_f16x3: unsupported channel pair %d -> %d", cin, cout);
 }
 
 #define SW_DISPATCH(CI, CO)                                                                           \

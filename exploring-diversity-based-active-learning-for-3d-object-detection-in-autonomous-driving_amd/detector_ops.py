@@ -64,8 +64,8 @@ def split_f16x3(w_packed, scale=None):
 
 
 # Arithmetic of the MFMA conv kernels (AL3D_MATH):
-#   "f16x3"  (default) dense neck + head: three f16 products per MAC (fp32-class, activations
-#            < 65504); sparse encoder: bf16x6
+#   "f16x3"  (default) three f16 products per MAC (fp32-class, activations < 65504) in the dense
+#            neck + head and in the sparse encoder
 #   "bf16x6" fp32-faithful six-product split on the bf16 matrix cores everywhere (full fp32 range)
 #   "f32"    fp32-input MFMA (bitwise an fp32 FMA chain)
 import os as _os
@@ -76,7 +76,7 @@ if MATH not in ("f16x3", "bf16x6", "f32"):
 
 def sparse_math():
     """Arithmetic of the sparse encoder under the current MATH."""
-    return "f32" if MATH == "f32" else "bf16x6"
+    return MATH
 
 
 def pack_frag_f16x3(planes):
@@ -276,8 +276,12 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
                  _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     if mfma is None:
-        mfma = (cin, cout) in MFMA_PAIRS and ("wave2" if sparse_math() == "bf16x6" else True)
-    if mfma in ("bf16x6", "wave", "wave2"):
+        mfma = (cin, cout) in MFMA_PAIRS and ({"bf16x6": "wave2", "f16x3": "wave2_f16x3"}.get(sparse_math(), True))
+    if mfma == "wave2_f16x3":
+        w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
+        lib.call("al3d_sp_conv_wave2_f16x3", _ptr(feats), _ptr(nbr), K, _ptr(w3), cin, cout, _ptr(sc3),
+                 _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+    elif mfma in ("bf16x6", "wave", "wave2"):
         w6 = split_bf16x3(w.permute(2, 0, 1).contiguous())
         fn = {"bf16x6": "al3d_sp_conv_bf16x6", "wave": "al3d_sp_conv_wave_bf16x6",
               "wave2": "al3d_sp_conv_wave2_bf16x6"}[mfma]

@@ -76,6 +76,8 @@ SIGNATURES = {
                                                 c_int, c_p]),
     "al3d_sp_conv_wave2_bf16x6": (c_int, [c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int, c_p,
                                                  c_int, c_p]),
+    "al3d_sp_conv_wave2_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int, c_p,
+                                                 c_int, c_p]),
     "al3d_merge_bf16x3": (c_int, [c_p, c_i64, c_p, c_p]),
     "al3d_sp_to_dense_nhwc": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_head_decode_nms": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p,

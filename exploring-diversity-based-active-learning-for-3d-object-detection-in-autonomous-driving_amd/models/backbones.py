@@ -104,9 +104,9 @@ class _SparseEncoderBase(nn.Module):
                 if isinstance(m, _SpConvParams):
                     bn = mods[i + 1]
                     scale, shift = fold_bn(bn)
-                    plan.append(dict(kind="subm" if m.subm else "down", mod=m,
-                                     w=self._pack(m, device),
-                                     scale=scale.to(device), shift=shift.to(device), relu=True,
+                    w, scale = self._pack(m, device, scale.to(device))
+                    plan.append(dict(kind="subm" if m.subm else "down", mod=m, w=w,
+                                     scale=scale, shift=shift.to(device), relu=True,
                                      residual=False))
                     i += 3  # conv, bn, relu
                 elif isinstance(m, SparseBasicBlock):
@@ -114,9 +114,9 @@ class _SparseEncoderBase(nn.Module):
                         scale, shift = fold_bn(bn)
                         if conv.bias is not None:   # (x + b) * s + t
                             shift = shift + conv.bias.detach().float().to(scale.device) * scale
-                        plan.append(dict(kind="subm", mod=conv,
-                                         w=self._pack(conv, device),
-                                         scale=scale.to(device), shift=shift.to(device), relu=True,
+                        w, scale = self._pack(conv, device, scale.to(device))
+                        plan.append(dict(kind="subm", mod=conv, w=w,
+                                         scale=scale, shift=shift.to(device), relu=True,
                                          residual=last, block_start=not last))
                     i += 1
                 else:
@@ -130,21 +130,25 @@ class _SparseEncoderBase(nn.Module):
     def _pad_cin(m):
         """Input channels the layer is run with: a narrow first layer (5 -> 16) is zero-padded to
         16 input channels so it runs on the matrix cores like every other layer (bf16x6 only)."""
-        if D.sparse_math() == "bf16x6" and m.in_channels < 16 and (16, m.out_channels) in MFMA_PAIRS:
+        if D.sparse_math() in ("bf16x6", "f16x3") and m.in_channels < 16 and (16, m.out_channels) in MFMA_PAIRS:
             return 16
         return m.in_channels
 
     @staticmethod
-    def _pack(m, device):
-        """[kz,ky,kx,Cin,Cout] -> [K,Cin,Cout] (VALU kernel) or [Cout,K,Cin] (MFMA kernel)."""
+    def _pack(m, device, scale):
+        """[kz,ky,kx,Cin,Cout] -> [K,Cin,Cout] (VALU kernel) or [Cout,K,Cin] (MFMA kernels, split into
+        bf16 / f16 planes for the split arithmetics).  Returns (weights, scale): the f16x3 split folds
+        its weight exponent into the layer's BN scale."""
         w = m.weight.detach().reshape(-1, m.in_channels, m.out_channels).float()
         cin = _SparseEncoderBase._pad_cin(m)
         if cin != m.in_channels:
             w = torch.nn.functional.pad(w, (0, 0, 0, cin - m.in_channels))
         if (cin, m.out_channels) in MFMA_PAIRS:
             w = w.permute(2, 0, 1).contiguous().to(device)
-            return D.split_bf16x3(w) if D.sparse_math() == "bf16x6" else w
-        return w.contiguous().to(device)
+            if D.sparse_math() == "f16x3":
+                return D.split_f16x3(w, scale)
+            return (D.split_bf16x3(w) if D.sparse_math() == "bf16x6" else w), scale
+        return w.contiguous().to(device), scale
 
     @staticmethod
     def _conv(m, feats, nbr, K, step, residual, out, n, st):
@@ -152,7 +156,9 @@ class _SparseEncoderBase(nn.Module):
         res_ptr = None if residual is None else _ptr(residual)
         cin = feats.shape[-1]                    # == m.in_channels, or 16 for a zero-padded narrow first layer
         mfma_pair = (cin, m.out_channels) in MFMA_PAIRS
-        if mfma_pair and step["w"].dtype == torch.bfloat16:
+        if mfma_pair and step["w"].dtype == torch.float16:
+            fn = "al3d_sp_conv_wave2_f16x3"           # f16x3 arithmetic, software-pipelined wave kernel
+        elif mfma_pair and step["w"].dtype == torch.bfloat16:
             # bf16x6 arithmetic.  Measured per channel pair on the real rulebooks
             # (tools/bench_splayers.py): the software-pipelined wave kernel wins everywhere;
             # AL3D_SPCONV=wave|tile selects the older structures (same results bit for bit).

@@ -284,6 +284,12 @@ int al3d_sp_conv_wave_bf16x6(const float* fin, const int* nbr, int K, const void
 int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K, const void* wgt_bf16x3, int cin,
                               int cout, const float* scale, const float* shift, const float* residual,
                               int relu, float* fout, int n_out, void* stream);
+/* the software-pipelined wave kernel in f16x3 arithmetic (see al3d_conv2d_nhwc_f16x3): weights =
+ * al3d_split_f16x3 of [Cout][K][Cin] (two f16 planes), `scale` REQUIRED and carrying 2^-scale_exp;
+ * gathered activations must stay below 65504.  Default of the sparse encoder. */
+int al3d_sp_conv_wave2_f16x3(const float* fin, const int* nbr, int K, const void* wgt_f16x2, int cin,
+                             int cout, const float* scale, const float* shift, const float* residual,
+                             int relu, float* fout, int n_out, void* stream);
 /* planes [3][count] bf16 -> f32 [count], exact (inverse of al3d_split_bf16x3) */
 int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));

@@ -25,7 +25,7 @@ def _t(a):
                                          (False, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
                                          (False, (3, 3, 3), (2, 2, 2), (0, 1, 1)),
                                          (False, (3, 1, 1), (2, 1, 1), (0, 0, 0))])
-@pytest.mark.parametrize("mfma", [False, True, "bf16x6", "wave", "wave2"])
+@pytest.mark.parametrize("mfma", [False, True, "bf16x6", "wave", "wave2", "wave2_f16x3"])
 def test_sparse_conv_layer_vs_oracle(oracle, cin, cout, subm, k, s, p, mfma):
     from al3d import detector_ops as D
     from al3d.detector_ops import MFMA_PAIRS
