@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x6_kernel(Conv6Params p)
                 const int y = ty_ * C6_TH + m / C6_TW, x = tx_ * C6_TW + m % C6_TW;
                 if (y >= MH || x >= MW) continue;
                 float v = acc[i][j][r] * sc + sh;
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 int oy = y, ox = x;
                 if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
                 p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_halo_kernel(Conv6Params
                 const int x = tx_ * H3_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (y >= p.OH || x >= p.OW) continue;
                 float v = acc[i][j][r] * sc + sh;
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 p.out[(((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n] = v;
             }
         }

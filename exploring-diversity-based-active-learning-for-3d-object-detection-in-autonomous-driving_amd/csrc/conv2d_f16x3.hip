@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_kernel(ConvF3Params p)
                 const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
                 if (y >= MH || x >= MW) continue;
                 float v = acc[i][j][r] * sc + sh;
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 int oy = y, ox = x;
                 if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
                 p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(ConvF3Params
                 const int x = tx_ * G3_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (y >= p.OH || x >= p.OW) continue;
                 float v = acc[i][j][r] * sc + sh;
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 p.out[(((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n] = v;
             }
         }
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
                 const int x = tx_ * G3_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (y >= p.OH || x >= p.OW) continue;
                 float v = acc[i][j][r] * sc + sh;
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 p.out[(((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n] = v;
             }
         }

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvParams p)
                 const int y = ty_ * CV_TH + m / CV_TW, x = tx_ * CV_TW + m % CV_TW;
                 if (y >= MH || x >= MW) continue;
                 float v = acc[i][j][r] * sc + sh;
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 int oy = y, ox = x;
                 if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
                 p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const float* __restrict__ 
         if (row >= n_out) continue;
         float v = acc[r] * sc + sh;
         if (residual) v += residual[(int64_t)row * COUT + co];
-        if (relu) v = v > 0.f ? v : 0.f;
+        if (relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
         fout[(int64_t)row * COUT + co] = v;
     }
 }

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_bf16x6_kernel(const float* __r
                 float v = acc[i][j][r] * sc + sh;
                 const int64_t o = (int64_t)row * COUT + n;
                 if (residual) v += residual[o];
-                if (relu) v = v > 0.f ? v : 0.f;
+                if (relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 fout[o] = v;
             }
         }

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_mfma_kernel(const float* __res
                 if (row >= n_out) continue;
                 float v = acc[i][j][r] * sc + sh;
                 if (residual) v += residual[(int64_t)row * COUT + n];
-                if (relu) v = v > 0.f ? v : 0.f;
+                if (relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
                 fout[(int64_t)row * COUT + n] = v;
             }
         }

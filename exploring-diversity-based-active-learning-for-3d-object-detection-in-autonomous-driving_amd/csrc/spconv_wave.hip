@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void sp_conv_wave_kernel(const float* __restri
             float v = acc[j][r] * sc + sh;
             const int64_t o = (int64_t)row * COUT + n;
             if (residual) v += residual[o];
-            if (relu) v = v > 0.f ? v : 0.f;
+            if (relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
             fout[o] = v;
         }
     }
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
             float v = acc[j][r] * sc + sh;
             const int64_t o = (int64_t)row * COUT + n;
             if (residual) v += residual[o];
-            if (relu) v = v > 0.f ? v : 0.f;
+            if (relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
             fout[o] = v;
         }
     }

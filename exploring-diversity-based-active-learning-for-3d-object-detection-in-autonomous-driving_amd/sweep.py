@@ -189,6 +189,7 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                 pending = (example, ahead, ev)
             main.wait_stream(side)
     local = torch.cat(feats, dim=0)
+    _check_range(local)
     idx = torch.as_tensor(index, dtype=torch.int64, device=local.device)
     n = num_frames if num_frames is not None else int(idx.max().item()) + 1
     out = gather_in_dataset_order(local, idx, n)
@@ -196,6 +197,17 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
         e = gather_in_dataset_order(torch.cat(ents).unsqueeze(1), idx, n).squeeze(1)
         return out, e
     return out
+
+
+def _check_range(local):
+    """f16x3 arithmetic carries activations below 65504 only; anything larger turns into inf/NaN in
+    the layer's output and from there into the frame's embedding.  One reduction per sweep."""
+    from . import detector_ops as D
+    from .lib import Al3dError
+    if D.MATH == "f16x3" and local.numel() and not bool(torch.isfinite(local).all()):
+        bad = int((~torch.isfinite(local).all(dim=1)).sum())
+        raise Al3dError(f"{bad} frame embedding(s) are not finite: an activation left the f16x3 range "
+                        "(|x| < 65504); rerun with AL3D_MATH=bf16x6 (full fp32 range)")
 
 
 def _entropy_of(scores):

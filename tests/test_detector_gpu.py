@@ -371,6 +371,30 @@ def test_pipelined_sweep_keeps_a_bounded_number_of_batches_alive():
     assert peaks["ahead"] < 3.0 * peaks[None] and peaks["split"] < 3.0 * peaks[None], peaks
 
 
+def test_sweep_rejects_activations_beyond_the_f16x3_range():
+    """f16x3 carries |activation| < 65504.  A model whose first neck BN multiplies by 1e7 must make the
+    sweep fail loudly (non-finite embeddings -> Al3dError naming AL3D_MATH=bf16x6), not return numbers."""
+    from al3d import detector_ops as D, sweep as S, synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.lib import Al3dError
+    from al3d.models import build_detector
+    from al3d.utils import Config
+    if D.MATH != "f16x3":
+        pytest.skip("range check applies to the f16x3 arithmetic")
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    with torch.no_grad():
+        model.neck.blocks[0][2].weight.mul_(1.0e7)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    pool = PoolFrames.from_numpy([synthetic.make_point_cloud(300 + i, nsweeps=1) for i in range(2)], DEV)
+    loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 2, device=DEV)
+    with pytest.raises(Al3dError, match="AL3D_MATH=bf16x6"):
+        S.sweep_embeddings(model, loader, DEV, len(pool))
+
+
 def test_uncertainty_sweeps_compose(oracle, tmp_path):
     """pred=True paths of Entropy / Badge / UWE: the swept quantities must equal what the
     reference expressions give on the detector's own outputs (entropy from the post-NMS scores,
