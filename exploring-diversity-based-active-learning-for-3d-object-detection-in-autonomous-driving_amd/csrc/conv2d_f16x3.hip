@@ -53,8 +53,26 @@ struct ConvF3Params {
     int B, H, W, Cin, Cout, OH, OW, ldc, coff;
     int ksize, stride, pad, relu;
     int tiles_x, tiles_y;
+    int nblocks, ntiles;    // 128-channel column blocks; pixel tiles (tiles_x * tiles_y * B)
     int64_t plane;          // elements per weight plane = Cout * taps * Cin
 };
+
+// 1-D grid -> (pixel tile, column block).  Blocks with equal blockIdx % 8 share an XCD and its L2,
+// so the column blocks of one pixel tile get ids that differ by 8: they run on the same XCD at
+// about the same time and the second one finds the tile's activations in L2 instead of HBM (the
+// 1x1 layers are bandwidth-bound: 42 flop per byte).  Grid = ceil(ntiles / 8) * 8 * nblocks.
+__device__ __forceinline__ bool f3_tile_of_block(const ConvF3Params& p, int& tile, int& nblk)
+{
+    const int id = blockIdx.x, span = 8 * p.nblocks;
+    const int grp = id / span, rem = id - grp * span;
+    nblk = rem >> 3;
+    tile = grp * 8 + (rem & 7);
+    return tile < p.ntiles;
+}
+static inline unsigned f3_grid(const ConvF3Params& p)
+{
+    return (unsigned)(al3d_cdiv(p.ntiles, 8) * 8 * p.nblocks);
+}
 
 __device__ __forceinline__ void split_act(float x, _Float16& h, _Float16& l)
 {
@@ -86,11 +104,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_kernel(ConvF3Params p)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    int tile = blockIdx.x;
+    int tile, nblk;
+    if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
     const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
     const int b = tile;
-    const int n0 = blockIdx.y * F3_BN;
+    const int n0 = nblk * F3_BN;
     const int MH = MODE == 0 ? p.OH : p.H, MW = MODE == 0 ? p.OW : p.W;
     const int taps = MODE == 0 ? p.ksize * p.ksize : 1;
     const int tap0 = MODE == 0 ? 0 : blockIdx.z;
@@ -246,11 +265,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(ConvF3Params
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 31, fh = lane >> 5;
-    int tile = blockIdx.x;
+    int tile, nblk;
+    if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
     const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
     const int b = tile;
-    const int n0 = blockIdx.y * F3_BN;
+    const int n0 = nblk * F3_BN;
     const int y0 = ty_ * G3_TH - 1, x0 = tx_ * G3_TW - 1;       // image coords of halo (0,0)
     const int nchunks = p.Cin / F3_BK;
     const int bq = tid & 1, br = tid >> 1;
@@ -448,11 +468,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 31, fh = lane >> 5;
-    int tile = blockIdx.x;
+    int tile, nblk;
+    if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
     const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
     const int b = tile;
-    const int n0 = blockIdx.y * F3_BN;
+    const int n0 = nblk * F3_BN;
     const int y0 = ty_ * G3_TH - 1, x0 = tx_ * G3_TW - 1;       // image coords of halo (0,0)
     const int nchunks = p.Cin / F3_BK;
     const int total = 9 * nchunks;
@@ -657,8 +678,8 @@ extern "C" int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_fra
                  "al3d_conv3x3_nhwc_f16x3_frag: in/wgt must be 16-byte aligned");
     p.tiles_x = (int)al3d_cdiv(p.OW, G3_TW);
     p.tiles_y = (int)al3d_cdiv(p.OH, G3_TH);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)(Cout / F3_BN), 1);
-    hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = Cout / F3_BN;
+    hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("conv3x3_f16x3_frag_kernel");
     return AL3D_OK;
 }
@@ -717,15 +738,15 @@ extern "C" int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x3, co
     if (ksize == 3 && stride == 1 && pad == 1 && Cin % (2 * F3_BK) == 0) {     // halo-staged fast path (chunk pairs)
         p.tiles_x = (int)al3d_cdiv(p.OW, G3_TW);
         p.tiles_y = (int)al3d_cdiv(p.OH, G3_TH);
-        dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)al3d_cdiv(Cout, F3_BN), 1);
-        hipLaunchKernelGGL(conv3x3_f16x3_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+        hipLaunchKernelGGL(conv3x3_f16x3_halo_kernel, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
         AL3D_CHECK_LAUNCH("conv3x3_f16x3_halo_kernel");
         return AL3D_OK;
     }
     p.tiles_x = (int)al3d_cdiv(p.OW, F3_TW);
     p.tiles_y = (int)al3d_cdiv(p.OH, F3_TH);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)al3d_cdiv(Cout, F3_BN), 1);
-    hipLaunchKernelGGL(conv2d_f16x3_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+    hipLaunchKernelGGL(conv2d_f16x3_kernel<0>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("conv2d_f16x3_kernel<conv>");
     return AL3D_OK;
 }
@@ -744,8 +765,8 @@ extern "C" int al3d_deconv2x2_nhwc_f16x3(const float* in, const void* wgt_f16x3,
     if (rc) return rc;
     p.tiles_x = (int)al3d_cdiv(W, F3_TW);
     p.tiles_y = (int)al3d_cdiv(H, F3_TH);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * B), (unsigned)al3d_cdiv(Cout, F3_BN), 4);
-    hipLaunchKernelGGL(conv2d_f16x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+    hipLaunchKernelGGL(conv2d_f16x3_kernel<1>, dim3(f3_grid(p), 1, 4), dim3(256), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("conv2d_f16x3_kernel<deconv>");
     return AL3D_OK;
 }

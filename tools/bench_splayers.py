@@ -2,7 +2,8 @@
 
   python tools/bench_splayers.py [batch] [fnA,fnB,...]
 
-Runs the sparse encoder once with the layer calls recorded, then replays every bf16x6 layer with
+Runs the sparse encoder once with the layer calls recorded (AL3D_MATH selects the weight format:
+bf16x6 entries need AL3D_MATH=bf16x6), then replays every matrix-core layer with
 each of the named C-ABI entry points (same arguments), checks the outputs agree bit for bit with
 the first one, and prints the time per layer and the total."""
 import sys, os
@@ -21,7 +22,7 @@ model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
 synthetic.seeded_init_(model, seed=0); model = model.to(dev).eval()
 anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-fns = (sys.argv[2] if len(sys.argv) > 2 else "al3d_sp_conv_wave_bf16x6,al3d_sp_conv_wave2_bf16x6,al3d_sp_conv_bf16x6").split(",")
+fns = (sys.argv[2] if len(sys.argv) > 2 else "al3d_sp_conv_wave2_f16x3").split(",")
 pool = PoolFrames.from_synthetic(bs, dev, num_base=8)
 ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=bs, device=dev)))
 calls = []
@@ -35,7 +36,7 @@ with torch.no_grad():
 torch.cuda.synchronize()
 tot = {f: 0.0 for f in fns}
 for (m, feats, nbr, K, step, residual, n) in calls:
-    if step["w"].dtype != torch.bfloat16:
+    if step["w"].dtype not in (torch.bfloat16, torch.float16):
         continue
     ci, co = m.in_channels, m.out_channels
     valid = float((nbr[:, :n] >= 0).float().mean()) if nbr.dim() == 2 else -1
