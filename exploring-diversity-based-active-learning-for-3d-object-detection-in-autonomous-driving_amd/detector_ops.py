@@ -79,6 +79,11 @@ def sparse_math():
     return MATH
 
 
+# structure of the f16x3 3x3 layers: "auto" = weights streamed in fragment order (no LDS staging),
+# "lds" = the LDS-staged halo kernel (same bits), for A/B
+DENSE = _os.environ.get("AL3D_DENSE", "auto")
+
+
 def pack_frag_f16x3(planes):
     """f16 planes [2,Cout,9,Cin] -> MFMA fragment order [2,Cout/32,Cin/16,9,64,8] (3x3/s1/p1 layers:
     every wave streams its B operands from L2, no LDS staging)."""
@@ -100,7 +105,7 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
     fragment-ordered f16x3 layout."""
     if MATH == "f16x3":
         planes, scale = split_f16x3(w_packed, scale)
-        if ksize is not None and frag_ok(planes.shape[1], planes.shape[3], ksize, stride, pad):
+        if ksize is not None and DENSE != "lds" and frag_ok(planes.shape[1], planes.shape[3], ksize, stride, pad):
             return pack_frag_f16x3(planes), scale
         return planes, scale
     if MATH == "bf16x6":

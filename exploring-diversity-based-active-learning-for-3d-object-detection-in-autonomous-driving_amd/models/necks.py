@@ -70,7 +70,7 @@ class RPN(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
 
     def _prepare(self, device):
-        if getattr(self, "_packed_dev", None) == (device, D.MATH):
+        if getattr(self, "_packed_dev", None) == (device, D.MATH, D.DENSE):
             return
         self._blocks_p, self._deblocks_p = [], []
         for blk in self.blocks:
@@ -96,7 +96,7 @@ class RPN(nn.Module):
                 w, scale = D.pack_dense(D.pack_conv_weight(up.weight).to(device), scale.to(device))
                 self._deblocks_p.append(dict(deconv=False, w=w, scale=scale, shift=shift.to(device),
                                              k=up.kernel_size[0], s=up.stride[0]))
-        self._packed_dev = (device, D.MATH)
+        self._packed_dev = (device, D.MATH, D.DENSE)
 
     def forward(self, x):
         """x NHWC [B,H,W,Cin] -> NHWC [B,H',W',sum(us_num_filters)]."""

@@ -323,19 +323,24 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
         return S.sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch, device=DEV),
                                   DEV, len(pool))
     saved = (D.SPCONV, S.PIPELINE)
+    saved_dense = D.DENSE
     try:
         ref = run(4)
         assert ref.shape == (6, 512) and torch.isfinite(ref).all()
         assert torch.equal(run(3), ref)
-        for mode in ("wave", "tile"):
+        for mode in ("wave", "tile"):               # bf16x6 arithmetic only; f16x3 has the one structure
             D.SPCONV = mode
             assert torch.equal(run(4), ref), mode
         D.SPCONV = saved[0]
+        D.DENSE = "lds"                             # f16x3: LDS-staged 3x3 kernel instead of the streamed one
+        assert torch.equal(run(4), ref), "dense lds"
+        D.DENSE = saved_dense
         for mode in (None, "ahead", "split"):
             S.PIPELINE = mode
             assert torch.equal(run(2), ref), mode
     finally:
         D.SPCONV, S.PIPELINE = saved
+        D.DENSE = saved_dense
 
 
 def test_pipelined_sweep_keeps_a_bounded_number_of_batches_alive():
