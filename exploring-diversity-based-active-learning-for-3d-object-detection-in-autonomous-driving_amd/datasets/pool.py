@@ -84,7 +84,8 @@ class DeviceSweepLoader:
         self.voxelizer = Voxelizer(voxel_cfg["range"], voxel_cfg["voxel_size"],
                                    voxel_cfg["max_points_in_voxel"], voxel_cfg["max_voxel_num"],
                                    max_batch=self.batch_size, device=self.device)
-        self.anchors = [torch.as_tensor(a, dtype=torch.float32, device=self.device) for a in anchors]
+        # anchors=None: embedding-only models (no detection head)
+        self.anchors = [torch.as_tensor(a, dtype=torch.float32, device=self.device) for a in (anchors or [])]
         self.dataset = pool          # len(loader.dataset) like a torch DataLoader
         self.sampler = self.indices
 

@@ -44,7 +44,8 @@ class SingleStageDetector(nn.Module):
         self.backbone = builder.build_backbone(backbone)
         if neck is not None:
             self.neck = builder.build_neck(neck)
-        self.bbox_head = builder.build_head(bbox_head)
+        # bbox_head=None: embedding-only graph (BEVFusion lidar branch, models/bevfusion_compat.py)
+        self.bbox_head = builder.build_head(bbox_head) if bbox_head is not None else None
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
 
@@ -94,6 +95,11 @@ class FPNVoxelNet(SingleStageDetector):
         if self.with_neck:
             x = self.neck(x)
             middle.append(NHWCFeature(x))
+        if self.bbox_head is None:
+            if not kwargs.get("estimate", False):
+                raise RuntimeError("this detector was built without a bbox_head: only the estimate=True "
+                                   "embedding sweep is available")
+            return [dict(metadata=m) for m in example.get("metadata", [None] * x.shape[0])], middle
         preds = self.bbox_head(x, finetune=finetune)
         if kwargs.get("get_preds", False):
             return preds
