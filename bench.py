@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scenes", type=int, default=SCENES_PER_RANK, help="scenes per rank")
-    ap.add_argument("--batch", type=int, default=32, help="frames per detector launch")
+    ap.add_argument("--batch", type=int, default=64, help="frames per detector launch")
     ap.add_argument("--budget", type=int, default=None,
                     help="cost budget (default 600; scaled down for pools under 64 scenes, whose "
                          "total labelling cost is below 600)")

@@ -343,6 +343,31 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
         D.DENSE = saved_dense
 
 
+def test_batch_64_equals_batch_8_at_full_size():
+    """The bench's default batch (64 frames per launch) puts 2.7e9 cells into the level-0 index grid
+    and the voxelizer's first-index grid -- beyond int32.  Embeddings must be the same bits as with
+    8 frames per launch (64-bit cell indexing everywhere)."""
+    from al3d import sweep as S, synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    pool = PoolFrames.from_synthetic(64, DEV, num_base=4, seed=3)
+
+    def run(batch):
+        return S.sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch, device=DEV),
+                                  DEV, len(pool))
+    big = run(64)
+    assert big.shape == (64, 512) and torch.isfinite(big).all()
+    assert torch.equal(big, run(8))
+    assert not torch.equal(big[0], big[1])          # frames differ (the last frame is not a copy of the first)
+
+
 def test_pipelined_sweep_keeps_a_bounded_number_of_batches_alive():
     """The side stream is ~10x faster than the main one; without a bound on its run-ahead it prepares
     (and keeps alive) every remaining batch of the pool.  Peak memory of a 16-batch sweep must stay
