@@ -96,6 +96,18 @@ __device__ __forceinline__ f16x8 lift_down(const f16x8& wh)
 #define F3_IC(v) std::integral_constant<int, v>{}
 #define F3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
+static int convf3_check(const ConvF3Params& p, const char* name)
+{
+    AL3D_REQUIRE(p.in && p.wgt && p.out && p.scale, "%s: null pointer (scale carries the weight exponent and is required)", name);
+    AL3D_REQUIRE(p.B >= 1 && p.H >= 1 && p.W >= 1 && p.Cin >= 1 && p.Cout >= 1, "%s: bad shape", name);
+    AL3D_REQUIRE(p.Cin % F3_BK == 0, "%s: Cin=%d must be a multiple of %d", name, p.Cin, F3_BK);
+    AL3D_REQUIRE(p.coff >= 0 && p.coff + p.Cout <= p.ldc, "%s: channel window [%d,%d) exceeds ldc=%d",
+                 name, p.coff, p.coff + p.Cout, p.ldc);
+    AL3D_REQUIRE(((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.wgt & 15) == 0,
+                 "%s: in/wgt must be 16-byte aligned", name);
+    return AL3D_OK;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv2d_f16x3_kernel(ConvF3Params p)
 {
@@ -629,6 +641,249 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
     }
 }
 
+// ------------------------------------------------------------------ any geometry, weights from L2
+// The generic kernel with the weight half of its staging removed, like the 3x3 kernel above: the
+// activation tile (128 pixels x 16 channels per step; no tap reuse to keep a halo for) is still
+// split once per workgroup and double-buffered in LDS, but every wave streams its B fragments from
+// fragment-ordered weights -- [plane][Cout/32 (zero-padded to 128s)][tap][chunk][lane][8] -- into a
+// register ring two steps ahead.  Halves the LDS traffic and the staging work of the stride-2 /
+// 1x1 / deconvolution / fused-head launches.  Steps are unrolled by six (LDS buffer parity x ring
+// of three) so every buffer and register-set index is a constant; all global loads unconditional.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv2d_f16x3_bstream_kernel(ConvF3Params p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][2][F3_BM * F3_LDB];   // [buf][plane] 24 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    int tile, nblk;
+    if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = nblk * F3_BN;
+    const int MH = MODE == 0 ? p.OH : p.H, MW = MODE == 0 ? p.OW : p.W;
+    const int taps = MODE == 0 ? p.ksize * p.ksize : 1;
+    const int tap0 = MODE == 0 ? 0 : blockIdx.z;
+    const int wtaps = MODE == 0 ? taps : 4;
+    const int kchunks = p.Cin / F3_BK;
+    const int total = taps * kchunks;
+    const float* zero = reinterpret_cast<const float*>(&g_f3_zero16);
+
+    // A staging: 128 rows x 16 ch f32 = 512 float4, 2 per thread (row ar and ar + 64)
+    const int aq = tid & 3, ar = tid >> 2;
+    int py[2], px[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = ar + 64 * i;
+        py[i] = ty_ * F3_TH + m / F3_TW;
+        px[i] = tx_ * F3_TW + m % F3_TW;
+    }
+    float4 ra[2];
+    int ltap = 0, lchunk = 0;                         // cursor of the next A load
+    auto load_a = [&]() {
+        const int ky = MODE == 0 ? ltap / p.ksize : 0, kx = MODE == 0 ? ltap - ky * p.ksize : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int iy, ix;
+            if (MODE == 0) { iy = py[i] * p.stride - p.pad + ky; ix = px[i] * p.stride - p.pad + kx; }
+            else { iy = py[i]; ix = px[i]; }
+            const bool ok = py[i] < MH && px[i] < MW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float* src = p.in + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + lchunk * F3_BK + 4 * aq;
+            ra[i] = *reinterpret_cast<const float4*>(ok ? src : zero);
+        }
+        if (ltap * kchunks + lchunk + 1 < total) { if (++lchunk == kchunks) { lchunk = 0; ++ltap; } }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f16x4 h, l;
+            split_act4(ra[i], h, l);
+            const int off = (ar + 64 * i) * F3_LDB + 8 * aq;
+            *reinterpret_cast<f16x4*>(&As[buf][0][off]) = h;
+            *reinterpret_cast<f16x4*>(&As[buf][1][off]) = l;
+        }
+    };
+    // B stream of this wave: [plane][ntile][tap][chunk][lane][8]
+    const int NTl = (p.Cout + 127) / 128 * 4;
+    const int nt0 = (n0 >> 5) + wn * 2;
+    const _Float16* bsrc[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bsrc[pl][j] = p.wgt + (((int64_t)(pl * NTl + nt0 + j) * wtaps + tap0) * kchunks) * 512 + lane * 8;
+    f16x8 fb0[2][2], fb1[2][2], fb2[2][2];
+    auto load_b = [&](auto ring_, int sidx) {
+        constexpr int ring = decltype(ring_)::value;
+        const int sc = sidx < total ? sidx : total - 1;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(bsrc[pl][j] + (int64_t)sc * 512);
+                if constexpr (ring == 0) fb0[pl][j] = v;
+                else if constexpr (ring == 1) fb1[pl][j] = v;
+                else fb2[pl][j] = v;
+            }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_off = (wm * 64 + fr) * F3_LDB + 16 * fh;
+    auto mfma_step = [&](int buf, const f16x8 (&fb)[2][2]) {
+        f16x8 a[2][2], wd[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                a[pl][t] = *reinterpret_cast<const f16x8*>(&As[buf][pl][a_off + t * 32 * F3_LDB]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wd[j] = lift_down(fb[0][j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = F3_MFMA(a[1][i], wd[j], acc[i][j]);          // xl' * wd   (smallest first)
+                acc[i][j] = F3_MFMA(a[0][i], fb[1][j], acc[i][j]);       // xh * wl
+                acc[i][j] = F3_MFMA(a[0][i], fb[0][j], acc[i][j]);       // xh * wh
+            }
+    };
+    // step s: B(s+2) requested, A(s+1) requested, MFMAs of step s, A(s+1) split + stored, barrier
+    auto step = [&](auto k_, int s) {
+        constexpr int k = decltype(k_)::value;        // s % 6
+        load_b(F3_IC((k + 2) % 3), s + 2);
+        load_a();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < total) {
+            if constexpr (k % 3 == 0) mfma_step(k & 1, fb0);
+            else if constexpr (k % 3 == 1) mfma_step(k & 1, fb1);
+            else mfma_step(k & 1, fb2);
+        }
+        store_a((k & 1) ^ 1);
+        __syncthreads();
+    };
+
+    load_a();                                         // A(0)
+    load_b(F3_IC(0), 0);
+    load_b(F3_IC(1), 1);
+    store_a(0);
+    __syncthreads();
+    for (int s0 = 0; s0 < total; s0 += 6) {
+        step(F3_IC(0), s0); step(F3_IC(1), s0 + 1); step(F3_IC(2), s0 + 2);
+        step(F3_IC(3), s0 + 3); step(F3_IC(4), s0 + 4); step(F3_IC(5), s0 + 5);
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale[n];
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                if (y >= MH || x >= MW) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
+                int oy = y, ox = x;
+                if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
+                p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;
+            }
+        }
+    }
+}
+
+// planes [2][Cout][taps][Cin] -> [2][ceil(Cout/128)*4][taps][Cin/16][64][8], zero rows beyond Cout
+__global__ void pack_bstream_kernel(const _Float16* __restrict__ planes, int Cout, int taps, int Cin,
+                                    _Float16* __restrict__ out, int64_t count)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= count) return;
+    const int nchunks = Cin / 16, NTl = (Cout + 127) / 128 * 4;
+    int64_t r = o;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int chunk = r % nchunks; r /= nchunks;
+    const int tap = r % taps; r /= taps;
+    const int nt = r % NTl; r /= NTl;
+    const int pl = (int)r;
+    const int n = nt * 32 + (lane & 31), k = chunk * 16 + 8 * (lane >> 5) + e;
+    out[o] = n < Cout ? planes[(int64_t)pl * Cout * taps * Cin + ((int64_t)n * taps + tap) * Cin + k] : (_Float16)0.0f;
+}
+
+extern "C" int64_t al3d_pack_f16x3_bstream_elems(int Cout, int taps, int Cin)
+{
+    if (Cout < 1 || taps < 1 || Cin < 16 || Cin % 16) return -1;
+    return 2 * (int64_t)((Cout + 127) / 128 * 128) * taps * Cin;
+}
+
+extern "C" int al3d_pack_f16x3_bstream(const void* planes_f16x2, int Cout, int taps, int Cin, void* out_frag,
+                                       void* stream)
+{
+    AL3D_REQUIRE(planes_f16x2 && out_frag, "al3d_pack_f16x3_bstream: null pointer");
+    const int64_t count = al3d_pack_f16x3_bstream_elems(Cout, taps, Cin);
+    AL3D_REQUIRE(count > 0, "al3d_pack_f16x3_bstream: needs Cin %% 16 == 0 (got Cout %d, taps %d, Cin %d)", Cout, taps, Cin);
+    hipLaunchKernelGGL(pack_bstream_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)planes_f16x2, Cout, taps, Cin, (_Float16*)out_frag, count);
+    AL3D_CHECK_LAUNCH("pack_bstream_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_conv2d_nhwc_f16x3_bstream(const float* in, const void* wgt_frag, const float* scale,
+                                              const float* shift, float* out, int B, int H, int W, int Cin,
+                                              int Cout, int ksize, int stride, int pad, int ldc, int coff,
+                                              int relu, void* stream)
+{
+    ConvF3Params p;
+    p.in = in; p.wgt = (const _Float16*)wgt_frag; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    AL3D_REQUIRE(ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0, "al3d_conv2d_nhwc_f16x3_bstream: bad geometry");
+    p.OH = (H + 2 * pad - ksize) / stride + 1;
+    p.OW = (W + 2 * pad - ksize) / stride + 1;
+    AL3D_REQUIRE(p.OH >= 1 && p.OW >= 1, "al3d_conv2d_nhwc_f16x3_bstream: empty output");
+    p.plane = 0;
+    int rc = convf3_check(p, "al3d_conv2d_nhwc_f16x3_bstream");
+    if (rc) return rc;
+    p.tiles_x = (int)al3d_cdiv(p.OW, F3_TW);
+    p.tiles_y = (int)al3d_cdiv(p.OH, F3_TH);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+    hipLaunchKernelGGL(conv2d_f16x3_bstream_kernel<0>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv2d_f16x3_bstream_kernel<conv>");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_deconv2x2_nhwc_f16x3_bstream(const float* in, const void* wgt_frag, const float* scale,
+                                                 const float* shift, float* out, int B, int H, int W, int Cin,
+                                                 int Cout, int ldc, int coff, int relu, void* stream)
+{
+    ConvF3Params p;
+    p.in = in; p.wgt = (const _Float16*)wgt_frag; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = 2; p.stride = 2; p.pad = 0; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    p.OH = 2 * H; p.OW = 2 * W;
+    p.plane = 0;
+    int rc = convf3_check(p, "al3d_deconv2x2_nhwc_f16x3_bstream");
+    if (rc) return rc;
+    p.tiles_x = (int)al3d_cdiv(W, F3_TW);
+    p.tiles_y = (int)al3d_cdiv(H, F3_TH);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+    hipLaunchKernelGGL(conv2d_f16x3_bstream_kernel<1>, dim3(f3_grid(p), 1, 4), dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv2d_f16x3_bstream_kernel<deconv>");
+    return AL3D_OK;
+}
+
 // planes [2][Cout][9][Cin] (al3d_split_f16x3) -> fragment order [2][Cout/32][Cin/16][9][64][8]
 __global__ void pack_frag_kernel(const _Float16* __restrict__ planes, int Cout, int Cin, _Float16* __restrict__ out)
 {
@@ -707,17 +962,6 @@ extern "C" int al3d_split_f16x3(const float* w, int64_t count, int scale_exp, vo
     return AL3D_OK;
 }
 
-static int convf3_check(const ConvF3Params& p, const char* name)
-{
-    AL3D_REQUIRE(p.in && p.wgt && p.out && p.scale, "%s: null pointer (scale carries the weight exponent and is required)", name);
-    AL3D_REQUIRE(p.B >= 1 && p.H >= 1 && p.W >= 1 && p.Cin >= 1 && p.Cout >= 1, "%s: bad shape", name);
-    AL3D_REQUIRE(p.Cin % F3_BK == 0, "%s: Cin=%d must be a multiple of %d", name, p.Cin, F3_BK);
-    AL3D_REQUIRE(p.coff >= 0 && p.coff + p.Cout <= p.ldc, "%s: channel window [%d,%d) exceeds ldc=%d",
-                 name, p.coff, p.coff + p.Cout, p.ldc);
-    AL3D_REQUIRE(((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.wgt & 15) == 0,
-                 "%s: in/wgt must be 16-byte aligned", name);
-    return AL3D_OK;
-}
 
 extern "C" int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x3, const float* scale,
                                       const float* shift, float* out, int B, int H, int W, int Cin,

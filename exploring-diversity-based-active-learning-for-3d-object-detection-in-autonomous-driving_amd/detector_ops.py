@@ -79,20 +79,45 @@ def sparse_math():
     return MATH
 
 
-# structure of the f16x3 3x3 layers: "auto" = weights streamed in fragment order (no LDS staging),
-# "lds" = the LDS-staged halo kernel (same bits), for A/B
+# structure of the f16x3 dense kernels: "auto" = weights streamed in fragment order (no LDS staging of
+# weights) where it pays, "bstream" = everywhere, "frag" = only the 3x3 layers, "lds" = the LDS-staged
+# kernels everywhere (same bits in all four), for A/B
 DENSE = _os.environ.get("AL3D_DENSE", "auto")
 
 
+class F16x3Packed:
+    """f16x3 weights in MFMA fragment order for the kernels that stream them from L2.
+    kind "frag3x3": [2,Cout/32,Cin/16,9,64,8] (3x3/s1/p1); kind "bstream": [2,ceil(Cout/128)*4,taps,
+    Cin/16,64,8] (any other geometry, zero rows beyond Cout)."""
+    dtype = torch.float16
+
+    def __init__(self, kind, data, cout, taps, cin):
+        self.kind, self.data, self.cout, self.taps, self.cin = kind, data, cout, taps, cin
+
+
 def pack_frag_f16x3(planes):
-    """f16 planes [2,Cout,9,Cin] -> MFMA fragment order [2,Cout/32,Cin/16,9,64,8] (3x3/s1/p1 layers:
-    every wave streams its B operands from L2, no LDS staging)."""
+    """f16 planes [2,Cout,9,Cin] -> fragment order for the 3x3/s1/p1 kernel (every wave streams its B
+    operands from L2, no LDS staging of weights)."""
     planes = _dev(planes, torch.float16, "planes")
     _, cout, taps, cin = planes.shape
     assert taps == 9
     out = torch.empty((2, cout // 32, cin // 16, 9, 64, 8), dtype=torch.float16, device=planes.device)
     lib.call("al3d_pack_f16x3_frag", _ptr(planes), cout, cin, _ptr(out), _stream())
-    return out
+    return F16x3Packed("frag3x3", out, cout, 9, cin)
+
+
+def pack_bstream_f16x3(planes):
+    """f16 planes [2,Cout,taps,Cin] -> fragment order for the streamed-weight kernel of the other geometries."""
+    planes = _dev(planes, torch.float16, "planes")
+    _, cout, taps, cin = planes.shape
+    n = lib.load().al3d_pack_f16x3_bstream_elems(cout, taps, cin)
+    if n <= 0:
+        raise lib.Al3dError(f"pack_bstream_f16x3: unsupported shape Cout={cout} taps={taps} Cin={cin}")
+    out = torch.empty((2, (cout + 127) // 128 * 4, taps, cin // 16, 64, 8), dtype=torch.float16,
+                      device=planes.device)
+    assert out.numel() == n
+    lib.call("al3d_pack_f16x3_bstream", _ptr(planes), cout, taps, cin, _ptr(out), _stream())
+    return F16x3Packed("bstream", out, cout, taps, cin)
 
 
 def frag_ok(cout, cin, ksize, stride, pad):
@@ -101,16 +126,24 @@ def frag_ok(cout, cin, ksize, stride, pad):
 
 def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
     """Packed f32 weights + folded-BN scale -> (weights in the dense kernels' format for MATH,
-    the scale to hand them).  With the layer geometry given, 3x3/s1/p1 layers get the
-    fragment-ordered f16x3 layout."""
+    the scale to hand them).  With the layer geometry given (``ksize="deconv"`` for the 2x2
+    transposed conv), f16x3 weights are put in fragment order for the streamed-weight kernels."""
     if MATH == "f16x3":
         planes, scale = split_f16x3(w_packed, scale)
-        if ksize is not None and DENSE != "lds" and frag_ok(planes.shape[1], planes.shape[3], ksize, stride, pad):
-            return pack_frag_f16x3(planes), scale
+        if ksize is not None and DENSE != "lds":
+            if ksize != "deconv" and frag_ok(planes.shape[1], planes.shape[3], ksize, stride, pad):
+                return pack_frag_f16x3(planes), scale
+            # streamed weights pay off once a launch has enough steps to amortise the deeper prologue:
+            # stride-2 3x3 (72 steps) -12 %, fused head (32) -5 %, 1x1 deblock (8) +8 % -> LDS-staged
+            steps = planes.shape[2] * planes.shape[3] // 16
+            if DENSE == "bstream" or (DENSE == "auto" and ksize != "deconv" and steps >= 24):
+                return pack_bstream_f16x3(planes), scale
         return planes, scale
     if MATH == "bf16x6":
         return split_bf16x3(w_packed), scale
     return w_packed, scale
+
+
 # sparse-conv structure for the bf16x6 arithmetic: "auto" = the software-pipelined wave kernel;
 # "wave" (unpipelined wave kernel) and "tile" (LDS-staged 128-row tile) give the same bits, for A/B
 SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
@@ -125,20 +158,27 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
     # the weight format selects the arithmetic: bf16 [3,Cout,taps,Cin] (split_bf16x3),
     # f16 [2,Cout,taps,Cin] (split_f16x3, scale required) or plain f32 [Cout,taps,Cin]
     kind = _DENSE_KIND[w_packed.dtype]
-    w_packed = _dev(w_packed, w_packed.dtype, "w")
     if kind == "f16x3" and scale is None:
         raise lib.Al3dError("conv2d_nhwc: f16x3 weights need the scale returned by split_f16x3")
-    if w_packed.dim() == 6:                           # fragment-ordered f16x3 (pack_frag_f16x3)
+    if isinstance(w_packed, F16x3Packed):             # fragment-ordered f16x3
+        pk = w_packed
         B, H, W, Cin = x.shape
-        Cout = w_packed.shape[1] * 32
-        if not (ksize == 3 and stride == 1 and pad == 1 and w_packed.shape[2] * 16 == Cin):
-            raise lib.Al3dError("conv2d_nhwc: fragment-ordered weights are for 3x3/s1/p1 layers of matching Cin")
+        if pk.cin != Cin or pk.taps != ksize * ksize or (pk.kind == "frag3x3" and (stride, pad) != (1, 1)):
+            raise lib.Al3dError("conv2d_nhwc: fragment-ordered weights do not match this layer's geometry")
+        OH = (H + 2 * pad - ksize) // stride + 1
+        OW = (W + 2 * pad - ksize) // stride + 1
         if out is None:
-            out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-        assert out.shape[:3] == (B, H, W) and out.is_contiguous()
-        lib.call("al3d_conv3x3_nhwc_f16x3_frag", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
-                 B, H, W, Cin, Cout, out.shape[3], coff, 1 if relu else 0, _stream())
+            out = torch.empty((B, OH, OW, pk.cout), dtype=torch.float32, device=x.device)
+        assert out.shape[:3] == (B, OH, OW) and out.is_contiguous()
+        if pk.kind == "frag3x3":
+            lib.call("al3d_conv3x3_nhwc_f16x3_frag", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
+                     B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
+        else:
+            lib.call("al3d_conv2d_nhwc_f16x3_bstream", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift),
+                     _ptr(out), B, H, W, Cin, pk.cout, ksize, stride, pad, out.shape[3], coff,
+                     1 if relu else 0, _stream())
         return out
+    w_packed = _dev(w_packed, w_packed.dtype, "w")
     wshape = w_packed.shape[1:] if kind != "f32" else w_packed.shape
     B, H, W, Cin = x.shape
     Cout = wshape[0]
@@ -157,9 +197,19 @@ def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0):
     x = _dev(x, torch.float32, "x")
     B, H, W, Cin = x.shape
     kind = _DENSE_KIND[w_packed.dtype]
-    Cout = w_packed.shape[1] if kind != "f32" else w_packed.shape[0]
     if kind == "f16x3" and scale is None:
         raise lib.Al3dError("deconv2x2_nhwc: f16x3 weights need the scale returned by split_f16x3")
+    if isinstance(w_packed, F16x3Packed):
+        pk = w_packed
+        if pk.kind != "bstream" or pk.taps != 4 or pk.cin != Cin:
+            raise lib.Al3dError("deconv2x2_nhwc: fragment-ordered weights do not match this layer")
+        if out is None:
+            out = torch.empty((B, 2 * H, 2 * W, pk.cout), dtype=torch.float32, device=x.device)
+        assert out.shape[:3] == (B, 2 * H, 2 * W) and out.is_contiguous()
+        lib.call("al3d_deconv2x2_nhwc_f16x3_bstream", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift),
+                 _ptr(out), B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
+        return out
+    Cout = w_packed.shape[1] if kind != "f32" else w_packed.shape[0]
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, 2 * H, 2 * W) and out.is_contiguous()

@@ -119,7 +119,7 @@ class MultiGroupHead(nn.Module):
 
     # ------------------------------------------------------------ fused 1x1 convs
     def _prepare(self, device):
-        if getattr(self, "_packed_dev", None) == (device, D.MATH):
+        if getattr(self, "_packed_dev", None) == (device, D.MATH, D.DENSE):
             return
         ws, bs, self._box_off, self._cls_off = [], [], [], []
         off = 0
@@ -133,9 +133,10 @@ class MultiGroupHead(nn.Module):
             bs.append(t.conv_cls.bias)
             off += t.conv_cls.out_channels
         self._ch = off
-        self._w, self._wscale = D.pack_dense(D.pack_conv_weight(torch.cat([w.detach() for w in ws], dim=0)).to(device))
+        self._w, self._wscale = D.pack_dense(
+            D.pack_conv_weight(torch.cat([w.detach() for w in ws], dim=0)).to(device), None, 1, 1, 0)
         self._b = torch.cat([b.detach() for b in bs]).float().contiguous().to(device)
-        self._packed_dev = (device, D.MATH)
+        self._packed_dev = (device, D.MATH, D.DENSE)
 
     def forward(self, x, finetune=False):
         """x NHWC [B,H,W,512] -> list of per-task dicts with NHWC views

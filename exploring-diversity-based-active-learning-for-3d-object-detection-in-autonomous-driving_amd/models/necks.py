@@ -90,10 +90,11 @@ class RPN(nn.Module):
             scale, shift = D.fold_bn(bn)
             if isinstance(up, nn.ConvTranspose2d):
                 assert up.kernel_size == (2, 2) and up.stride == (2, 2), "only 2x2/s2 deconv is built"
-                w, scale = D.pack_dense(D.pack_deconv_weight(up.weight).to(device), scale.to(device))
+                w, scale = D.pack_dense(D.pack_deconv_weight(up.weight).to(device), scale.to(device), "deconv")
                 self._deblocks_p.append(dict(deconv=True, w=w, scale=scale, shift=shift.to(device)))
             else:
-                w, scale = D.pack_dense(D.pack_conv_weight(up.weight).to(device), scale.to(device))
+                w, scale = D.pack_dense(D.pack_conv_weight(up.weight).to(device), scale.to(device),
+                                        up.kernel_size[0], up.stride[0], 0)
                 self._deblocks_p.append(dict(deconv=False, w=w, scale=scale, shift=shift.to(device),
                                              k=up.kernel_size[0], s=up.stride[0]))
         self._packed_dev = (device, D.MATH, D.DENSE)

@@ -353,6 +353,21 @@ int al3d_pack_f16x3_frag(const void* planes_f16x2, int Cout, int Cin, void* out_
 int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_frag, const float* scale,
                                  const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
                                  int ldc, int coff, int relu, void* stream);
+/* Every other geometry (stride-2 block entry, 1x1 deblock, 2x2 deconvolution, fused 1x1 head:
+ * rpn.py:66-113, mg_head.py:215-231) with the weights streamed the same way: activations staged
+ * through LDS per (tap, 16-channel chunk), B fragments from al3d_pack_f16x3_bstream(): planes
+ * [2][Cout][taps][Cin] -> [2][ceil(Cout/128)*4][taps][Cin/16][64][8] (zero rows beyond Cout;
+ * al3d_pack_f16x3_bstream_elems() f16 elements).  Cin % 16 == 0; deconv: taps = 4, tap = dy*2+dx.
+ * Bit-identical to al3d_conv2d_nhwc_f16x3 / al3d_deconv2x2_nhwc_f16x3 on the plane layout. */
+int64_t al3d_pack_f16x3_bstream_elems(int Cout, int taps, int Cin);
+int al3d_pack_f16x3_bstream(const void* planes_f16x2, int Cout, int taps, int Cin, void* out_frag,
+                            void* stream);
+int al3d_conv2d_nhwc_f16x3_bstream(const float* in, const void* wgt_frag, const float* scale,
+                                   const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                                   int ksize, int stride, int pad, int ldc, int coff, int relu, void* stream);
+int al3d_deconv2x2_nhwc_f16x3_bstream(const float* in, const void* wgt_frag, const float* scale,
+                                      const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                                      int ldc, int coff, int relu, void* stream);
 
 /* BEV embedding: mean over W then over H of an NHWC map, [B,H,W,C] -> [B,C].
  * Replaces `fpn_feats[-1].mean(-1).mean(-1)` (det3d/selectors/feature_selector.py:68-71). */

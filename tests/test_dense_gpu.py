@@ -146,6 +146,9 @@ def test_conv2d_f16x3_is_fp32_class(B, H, W, Cin, Cout, k, s, p, xmag):
         # same arithmetic with the weights streamed in fragment order: the same bits
         gotf = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_frag_f16x3(w3), sc3, None, k, s, p, False)
         assert torch.equal(gotf, got3)
+    if (k, s, p) != (3, 1, 1) or Cin % 32:            # the geometries the generic kernels serve
+        gotb = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_bstream_f16x3(w3), sc3, None, k, s, p, False)
+        assert torch.equal(gotb, got3)                # streamed weights: same products, same order
     got3 = got3.cpu().double()
     scale = _nhwc(F.conv2d(x.abs().double(), w.abs().double(), stride=s, padding=p))
     e32 = ((got32 - ref).abs() / scale).max().item()
@@ -205,6 +208,48 @@ def test_conv3x3_f16x3_fragment_stream_equals_lds_staged_kernel(B, H, W, Cin, Co
     D.conv2d_nhwc(x, D.pack_frag_f16x3(w3), sc3, shift, 3, 1, 1, True, out=b, coff=32)
     assert torch.equal(a, b)
     assert torch.all(b[..., :32] == -3.0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(2, 128, 128, 128, 256, 1, 1, 0),    # deblock 0
+                                                  (1, 128, 128, 128, 256, 3, 2, 1),    # block 1 entry
+                                                  (2, 37, 21, 512, 236, 1, 1, 0),      # fused head, ragged
+                                                  (1, 19, 50, 64, 40, 3, 1, 0),        # 3x3 without padding
+                                                  (1, 9, 11, 48, 16, 1, 1, 0),         # 3 steps: not a multiple of the 6-step unroll
+                                                  (3, 10, 9, 32, 300, 5, 2, 2)])       # 25 taps, 3 column blocks
+def test_conv2d_f16x3_streamed_weights_equal_lds_staged_kernel(B, H, W, Cin, Cout, k, s, p):
+    """The streamed-weight generic kernel walks the same (tap, chunk) steps with the same three
+    products per step: outputs are bit-identical to the LDS-staged generic kernel (incl. Cout
+    padding, ragged tiles, padding taps, scale/shift/ReLU and the concat window)."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(Cin + H + k)
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, k * k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    w3, sc3 = D.split_f16x3(w, scale)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    a = torch.full((B, OH, OW, Cout + 20), -3.0, device=DEV)
+    b = torch.full((B, OH, OW, Cout + 20), -3.0, device=DEV)
+    D.conv2d_nhwc(x, w3, sc3, shift, k, s, p, True, out=a, coff=20)
+    D.conv2d_nhwc(x, D.pack_bstream_f16x3(w3), sc3, shift, k, s, p, True, out=b, coff=20)
+    assert torch.equal(a, b)
+    assert torch.all(b[..., :20] == -3.0)
+
+
+def test_deconv_f16x3_streamed_weights_equal_lds_staged_kernel():
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 33, 20, 256, generator=g).to(DEV)
+    w = (torch.randn(200, 4, 256, generator=g) / 32.0).to(DEV)
+    scale = (torch.rand(200, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(200, generator=g) * 0.1).to(DEV)
+    w3, sc3 = D.split_f16x3(w, scale)
+    a = torch.full((2, 66, 40, 264), -3.0, device=DEV)
+    b = torch.full((2, 66, 40, 264), -3.0, device=DEV)
+    D.deconv2x2_nhwc(x, w3, sc3, shift, True, out=a, coff=64)
+    D.deconv2x2_nhwc(x, D.pack_bstream_f16x3(w3), sc3, shift, True, out=b, coff=64)
+    assert torch.equal(a, b)
+    assert torch.all(b[..., :64] == -3.0)
 
 
 def test_deconv_f16x3_matches_f32_kernel():

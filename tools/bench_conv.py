@@ -22,8 +22,7 @@ for (H, Cin, Cout, k, s, p) in shapes:
         w, sc = D.split_f16x3(w, sc)
     if MODE == 'f16x3frag':
         w, sc = D.split_f16x3(w, sc)
-        if D.frag_ok(Cout, Cin, k, s, p):
-            w = D.pack_frag_f16x3(w)
+        w = D.pack_frag_f16x3(w) if D.frag_ok(Cout, Cin, k, s, p) else D.pack_bstream_f16x3(w)
     OH = (H + 2 * p - k) // s + 1
     out = torch.empty(B, OH, OH, Cout, device=dev)
     for _ in range(3):
