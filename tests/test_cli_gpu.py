@@ -32,3 +32,16 @@ def test_cli_bootstrap_then_select(tmp_path):
     pool = pickle.load(open(tmp_path / "data" / "nuScenes" / "infos_train_10sweeps_withvelo.pkl", "rb"))
     cost = sum(0.12 + 0.04 * len(pool[i]["gt_names"]) for i in out["20"])
     assert cost <= 20
+
+
+def test_cli_with_the_bevfusion_lidar_config(tmp_path):
+    """Same flow on the head-less BEVFusion lidar-branch config (0.075 m grid, embeddings only)."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "active_select.py"), "--config",
+           os.path.join(ROOT, "examples", "active", "bevfusion_lidar_spatial_temporal_feature.py"), "--budget", "20",
+           "--pred", "--synthetic-scenes", "1", "--batch", "4"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for _ in range(2):
+        r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    out = json.load(open(tmp_path / "data" / "buffers" / "bevfusion_lidar_stf.json"))
+    assert list(out) == ["0", "20"] and len(out["20"]) >= 5 and all(0 <= i < 40 for i in out["20"])

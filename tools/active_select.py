@@ -110,7 +110,9 @@ def main():
         else:
             pool = PoolFrames.from_files([infos[i] for i in mine], dev, nsweeps=cfg.nsweeps,
                                          root=cfg.data_root)
-        anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+        # embedding-only models (bbox_head=None, e.g. the BEVFusion lidar branch) need no anchors
+        anchors = None if cfg.model.get("bbox_head") is None else \
+            generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
         loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
         loader.sampler = mine
 
