@@ -253,7 +253,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     static_assert(P % UPS == 0 || UPS % P == 0, "ring depth and slab size must divide one another");
     constexpr int SLAB_PIECES = UPS * NPL * NROWS * 2;   // 16-byte pieces fetched per slab (LDS always holds 3 planes)
     constexpr int PASSES = (SLAB_PIECES + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) unsigned char Ws[2][UPS * UNIT_BYTES + 64];
+    // weight slabs (main loop) and the epilogue's transposition scratch (one 32 x 32 f32 tile per wave,
+    // 40-float pitch) share the same LDS: the loop's last barrier separates the two uses
+    constexpr int EP_PITCH = 40;                         // floats: 4 * 40 % 64 == 32 -> the two row halves of a
+                                                         // C fragment hit disjoint banks
+    constexpr int WS_BYTES = 2 * (UPS * UNIT_BYTES + 64), EP_WAVE_BYTES = 32 * EP_PITCH * 4;
+    // all waves transpose at once if that fits the slab storage (or 48 KB); otherwise in two rounds
+    constexpr int EP_WAVES = NW * EP_WAVE_BYTES <= (WS_BYTES > 49152 ? WS_BYTES : 49152) ? NW : NW / 2;
+    constexpr int EP_BYTES = EP_WAVES * EP_WAVE_BYTES;
+    static_assert(EP_WAVES * EP_WAVE_BYTES <= 81920, "epilogue scratch too large");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES > EP_BYTES ? WS_BYTES : EP_BYTES];
+    unsigned char (*Ws)[UPS * UNIT_BYTES + 64] = reinterpret_cast<unsigned char (*)[UPS * UNIT_BYTES + 64]>(smem);
     __shared__ __attribute__((aligned(16))) unsigned char zrow[64];
     __shared__ unsigned s_mask;
     __shared__ int s_taps[32];
@@ -439,21 +449,51 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
         }
     }
 
+    // ---- epilogue.  The C fragment holds one column per lane and 16 scattered rows per register, so
+    // storing it directly costs 16 dword stores (and 16 dword residual loads) per 32-column tile,
+    // each touching two 64..128-byte pieces.  Instead every wave transposes the tile through its LDS
+    // scratch and then moves float4s: the wave's 32 rows x COUT block is contiguous in fout (rows are
+    // consecutive), so loads and stores are full lines.  BN, residual and ReLU are applied on the
+    // float4s.
+    float* scr = reinterpret_cast<float*>(smem) + (wave % EP_WAVES) * 32 * EP_PITCH;
+    const int wrow0 = row0 + wave * 32;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = j * 32 + fr;
-        if (n >= COUT) continue;
-        const float sc = scale ? scale[n] : 1.0f;
-        const float sh = shift ? shift[n] : 0.0f;
+    for (int round = 0; round < NW / EP_WAVES; ++round) {
+        if (round > 0) __syncthreads();                               // the other half of the waves is done with the scratch
+        if (wave / EP_WAVES != round) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (row >= n_out) continue;
-            float v = acc[j][r] * sc + sh;
-            const int64_t o = (int64_t)row * COUT + n;
-            if (residual) v += residual[o];
-            if (relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
-            fout[o] = v;
+        for (int j = 0; j < TN; ++j) {
+            const int live = COUT - j * 32 < 32 ? COUT - j * 32 : 32;    // live columns of this tile (compile-time)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                scr[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP_PITCH + fr] = acc[j][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the tile is in LDS (wave-private)
+            __builtin_amdgcn_wave_barrier();
+            const int q = live / 4;                                   // float4s per row
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx >= 32 * q) continue;
+                const int rl = idx / q, c4 = (idx - rl * q) * 4;
+                const int row = wrow0 + rl;
+                if (row >= n_out) continue;
+                const int n = j * 32 + c4;
+                float4 v = *reinterpret_cast<const float4*>(scr + rl * EP_PITCH + c4);
+                const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                const int64_t o = (int64_t)row * COUT + n;
+                if (residual) {
+                    const float4 rs = *reinterpret_cast<const float4*>(residual + o);
+                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                }
+                if (relu) {                                           // NaN propagates, like torch.relu
+                    v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
+                    v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
+                }
+                *reinterpret_cast<float4*>(fout + o) = v;
+            }
+            __builtin_amdgcn_wave_barrier();                          // scratch is rewritten by the next tile
         }
     }
 }
