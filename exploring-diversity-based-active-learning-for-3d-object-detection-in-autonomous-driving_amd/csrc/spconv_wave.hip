@@ -533,7 +533,9 @@ extern "C" int al3d_sp_conv_wave2_f16x3(const float* fin, const int* nbr, int K,
     AL3D_REQUIRE(scale, "al3d_sp_conv_wave2_f16x3: scale carries the weight exponent and is required");
     hipStream_t s = (hipStream_t)stream;
     const void* wgt = wgt_f16x2;
-    SW2_DISPATCH(16, 16, 4, 4, 4, 2) SW2_DISPATCH(16, 32, 8, 2, 2, 2) SW2_DISPATCH(32, 32, 8, 2, 2, 2) SW2_DISPATCH(32, 64, 8, 4, 2, 2)
+    // f16x3 halves the MFMA time of a unit, so the 32-channel layers take four units per slab (one barrier
+    // per 12 MFMAs instead of 6: -3 %); the LDS this needs is below the epilogue scratch anyway
+    SW2_DISPATCH(16, 16, 4, 4, 4, 2) SW2_DISPATCH(16, 32, 8, 4, 2, 2) SW2_DISPATCH(32, 32, 8, 4, 2, 2) SW2_DISPATCH(32, 64, 8, 4, 2, 2)
     SW2_DISPATCH(64, 64, 8, 4, 2, 2) SW2_DISPATCH(64, 128, 16, 2, 2, 2) SW2_DISPATCH(128, 128, 16, 2, 2, 2)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_f16x3: unsupported channel pair %d -> %d", cin, cout);
 }
