@@ -30,6 +30,12 @@
 // Same role, layouts and tiling as conv2d_bf16x6.hip: NHWC f32 activations in HBM, split while
 // they are staged; weights pre-split into [2][Cout][taps][Cin] f16.  Half the MFMAs, 4 instead
 // of 6 fragment reads per step, 2/3 of the LDS.
+//
+// Kernels in this file (all bit-identical to one another on the same layer):
+//   conv3x3_f16x3_frag_kernel     3x3/s1/p1, halo in LDS, weights streamed in fragment order   (default)
+//   conv3x3_f16x3_halo_kernel     3x3/s1/p1, halo and weights through LDS                      (AL3D_DENSE=lds)
+//   conv2d_f16x3_bstream_kernel   any geometry, activation tile in LDS, weights streamed       (>= 24 steps)
+//   conv2d_f16x3_kernel           any geometry, both tiles through LDS                         (short launches, deconv)
 #include "al3d_common.h"
 #include <type_traits>
 
