@@ -368,6 +368,38 @@ def test_batch_64_equals_batch_8_at_full_size():
     assert not torch.equal(big[0], big[1])          # frames differ (the last frame is not a copy of the first)
 
 
+def test_sweep_with_an_empty_frame_in_the_batch():
+    """A frame without a single point in range (ragged batch: 0 voxels for one sample) must not disturb
+    its neighbours: their embeddings are the bits they have without it, the empty frame's embedding is
+    that of an all-zero BEV map (finite, the same for any position in the batch), and its detections
+    are whatever the head makes of the biases -- no crash, no NaN."""
+    from al3d import sweep as S, synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active",
+                                       "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    clouds = [synthetic.make_point_cloud(500 + i, nsweeps=1) for i in range(3)]
+    far = np.array([[500.0, 500.0, 0.0, 1.0, 0.0]], dtype=np.float32)          # one point, outside the range
+    none = np.zeros((0, 5), dtype=np.float32)
+
+    def run(frames, batch):
+        pool = PoolFrames.from_numpy(frames, DEV)
+        return S.sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch, device=DEV),
+                                  DEV, len(pool))
+    ref = run(clouds, 3)
+    a = run([clouds[0], far, clouds[1], clouds[2]], 4)
+    b = run([none, clouds[0], clouds[1], clouds[2], far], 5)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert torch.equal(a[[0, 2, 3]], ref) and torch.equal(b[[1, 2, 3]], ref)
+    assert torch.equal(a[1], b[0]) and torch.equal(a[1], b[4])
+    assert torch.equal(run([far], 1)[0], a[1])                                 # a batch that is empty altogether
+
+
 def test_pipelined_sweep_keeps_a_bounded_number_of_batches_alive():
     """The side stream is ~10x faster than the main one; without a bound on its run-ahead it prepares
     (and keeps alive) every remaining batch of the pool.  Peak memory of a 16-batch sweep must stay
