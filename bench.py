@@ -7,10 +7,11 @@ run through the FPNVoxelNet detector (sparse encoder, MFMA neck/head, decode + r
 and reduced to its 512-d BEV embedding; embeddings are all-gathered (RCCL) when N > 1; then
 SpatialTemporalFeatureSelector builds the spatial (kNN geodesic), temporal and feature (L1)
 maps and runs the greedy k-center under the cost budget.  Workload at N=1 = BASELINE.json
-configs[1]: the 64-scene pool (2,560 frames), budget 600.  Point clouds are synthetic and
-resident in HBM before the timed region; weights are seeded random-init (no checkpoints
-offline).  With N ranks every rank sweeps its own 2,560 frames (weak scaling), the pool seen
-by the selector is N x 2,560 frames.
+configs[1]: the 64-scene pool (2,560 frames), budget 600.  With N > 1 ranks the workload is
+BASELINE.json configs[2]'s shape: every rank sweeps 88 scenes = 3,520 frames (weak scaling) and the
+selector sees N x 3,520 frames with budget 1200 -- at N = 8 that is the full nuScenes pool
+(704 scenes, 28,160 frames).  Point clouds are synthetic and resident in HBM before the timed
+region; weights are seeded random-init (no checkpoints offline).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W]   (N > 1 under torch.distributed.run)
 """
@@ -30,9 +31,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-SCENES_PER_RANK = 64
+SCENES_PER_RANK = 64              # N = 1: BASELINE configs[1]
+SCENES_PER_RANK_MULTI = 88        # N > 1: BASELINE configs[2] (8 x 88 scenes = the full 28,160-frame pool)
 FRAMES_PER_SCENE = 40
 BUDGET = 600
+BUDGET_MULTI = 1200
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 DENSE_GFLOP_PER_FRAME = 67.6      # neck 63.7 + heads 3.96 (2*MAC, fp32)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
@@ -43,13 +47,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenes", type=int, default=SCENES_PER_RANK, help="scenes per rank")
+    ap.add_argument("--scenes", type=int, default=None,
+                    help="scenes per rank (default 64 at N=1 = configs[1]; 88 at N>1 = configs[2] per rank)")
     ap.add_argument("--batch", type=int, default=64, help="frames per detector launch")
     ap.add_argument("--budget", type=int, default=None,
                     help="cost budget (default 600; scaled down for pools under 64 scenes, whose "
                          "total labelling cost is below 600)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extra-math", action="store_true",
+                    help="skip the one extra step (outside the timed region) under AL3D_MATH=bf16x6 (value_bf16x6)")
     return ap.parse_args()
 
 
@@ -136,6 +143,101 @@ class ConvTimer:
         return out
 
 
+class SparseTimer:
+    """HIP-event timing of every sparse-conv launch (the 21 layers of FPNSpMiddleResNetFHD,
+    det3d/models/backbones/scn.py:331-369) on the stream it is launched on, plus the algorithmic
+    work of each layer from the measured rulebook: pairs = valid (output row, tap)
+    entries, flops = 2 * pairs * Cin * Cout, bytes = pairs * (Cin + Cout) * 4 + n_out * Cout * 4 +
+    K * Cin * Cout * 4."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = []            # (layer index within the batch, e0, e1)
+        self.layers = None          # per layer: dict(cin, cout, K, n_out, pairs) of ONE batch
+        self._i = 0
+
+    def wrap(self, model):
+        bb = model.backbone
+        conv = bb._conv
+        timer = self
+
+        def timed(m, feats, nbr, K, step, residual, out, n, st):
+            if not timer.enabled:
+                return conv(m, feats, nbr, K, step, residual, out, n, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            conv(m, feats, nbr, K, step, residual, out, n, st)
+            e1.record()
+            timer.events.append((timer._i, e0, e1))
+            timer._i += 1
+
+        bb._conv = timed
+        run = bb._run
+
+        def run_wrapped(*a, **k):
+            timer._i = 0
+            return run(*a, **k)
+
+        bb._run = run_wrapped
+
+    def measure_rulebook(self, model, example):
+        """Pairs per layer of one batch (outside the timed region)."""
+        bb = model.backbone
+        with torch.no_grad():
+            book = bb.rulebook_for(example["coordinates"], len(example["num_voxels"]), example["shape"][0])
+        layers, seen = [], {}
+        for step, b in zip(bb._plan, book["steps"]):
+            if step["kind"] == "stage_end":
+                continue
+            m = step["mod"]
+            key = b["nbr"].data_ptr()
+            if key not in seen:
+                seen[key] = int((b["nbr"][:, :max(b["n"], 1)] >= 0).sum().item()) if b["n"] else 0
+            layers.append(dict(cin=m.in_channels, cout=m.out_channels, K=b["K"], n_out=b["n"], pairs=seen[key],
+                               kind=step["kind"], residual=bool(step.get("residual"))))
+        self.layers = layers
+        self.batch_frames = len(example["num_voxels"])
+
+    def result(self):
+        if not self.events or not self.layers:
+            return None
+        nl = len(self.layers)
+        ms = [0.0] * nl
+        cnt = [0] * nl
+        for i, e0, e1 in self.events:
+            ms[i % nl] += e0.elapsed_time(e1)
+            cnt[i % nl] += 1
+        rows, tot_flop, tot_bytes, tot_ms = [], 0.0, 0.0, 0.0
+        for L, t, c in zip(self.layers, ms, cnt):
+            if c == 0:
+                continue
+            us = t * 1e3 / c
+            flop = 2.0 * L["pairs"] * L["cin"] * L["cout"]
+            byts = L["pairs"] * (L["cin"] + L["cout"]) * 4.0 + L["n_out"] * L["cout"] * 4.0 + \
+                L["K"] * L["cin"] * L["cout"] * 4.0
+            rows.append(dict(cin=L["cin"], cout=L["cout"], K=L["K"], n_out=L["n_out"], pairs=L["pairs"],
+                             valid=round(L["pairs"] / max(1, L["n_out"] * L["K"]), 3), avg_us=round(us, 1),
+                             tflops=round(flop / us / 1e6, 1), gbs=round(byts / us / 1e3, 1)))
+            tot_flop += flop
+            tot_bytes += byts
+            tot_ms += us / 1e3
+        tf = tot_flop / tot_ms / 1e9
+        gbs = tot_bytes / tot_ms / 1e6
+        from al3d import detector_ops as D
+        prod = {"f16x3": 3, "bf16x6": 6}.get(D.MATH)
+        peak = MFMA_BF16_PEAK_TFLOPS / prod if prod else MFMA_F32_PEAK_TFLOPS
+        return dict(kernel="sp_conv family (21 launches per batch)", bound="hbm (gather) below 64 channels, mfma at 128",
+                    frames_per_launch=self.batch_frames, ms_per_batch=round(tot_ms, 3),
+                    ms_per_frame=round(tot_ms / self.batch_frames, 4),
+                    algorithmic_gflop_per_frame=round(tot_flop / self.batch_frames / 1e9, 3),
+                    algorithmic_mb_per_frame=round(tot_bytes / self.batch_frames / 1e6, 2),
+                    achieved_tflops=round(tf, 1), mfma_peak_tflops=round(peak, 1), frac_mfma=round(tf / peak, 4),
+                    achieved_gbs=round(gbs, 1), hbm_peak_gbs=HBM_PEAK_GBS, frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
+                    measured="HIP events around each sparse-conv launch of the timed steps (rank 0); pairs from "
+                             "the rulebook of one batch (every batch holds the same base frames)",
+                    layers=rows)
+
+
 def write_pool_files(tmp, infos, logs):
     ip = os.path.join(tmp, "infos.pkl")
     with open(ip, "wb") as f:
@@ -164,11 +266,15 @@ def cpu_baseline(cfg, model_cpu_state, infos, feats, sample_frames=2):
 def main():
     args = parse()
     global BUDGET
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.scenes is None:
+        args.scenes = SCENES_PER_RANK if world == 1 else SCENES_PER_RANK_MULTI
     if args.budget is not None:
         BUDGET = args.budget
-    elif args.scenes < SCENES_PER_RANK:
-        BUDGET = max(10, BUDGET * args.scenes // SCENES_PER_RANK)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    elif world > 1 and args.scenes * world >= SCENES_PER_RANK:
+        BUDGET = BUDGET_MULTI
+    elif args.scenes * world < SCENES_PER_RANK:
+        BUDGET = max(10, BUDGET * args.scenes * world // SCENES_PER_RANK)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal knob: AL3D_DIST_BACKEND=gloo lets several ranks share cuda:0 of a one-GPU box (device
@@ -200,6 +306,8 @@ def main():
     model = model.to(dev).eval()
     timer = ConvTimer()
     timer.wrap(model)
+    sp_timer = SparseTimer()
+    sp_timer.wrap(model)
     anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
 
     per_rank = args.scenes * FRAMES_PER_SCENE
@@ -241,10 +349,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ranks_seen = 1
     if world > 1:
+        # RCCL sanity before the timed region: an all-reduce of ones must count every rank
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = rank == 0
+    timer.enabled = sp_timer.enabled = rank == 0
     t0 = time.perf_counter()
     sweep_s = select_s = 0.0
     for _ in range(args.steps):
@@ -259,16 +372,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = sp_timer.enabled = False
+    rank_sweep_s = [sweep_s / args.steps]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([sweep_s / args.steps], dtype=torch.float64, device=dev)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine)
+        rank_sweep_s = [round(float(v), 4) for v in allt.tolist()]
 
     if rank == 0:
         value = n_total * args.steps / elapsed
+        verified = None if args.no_verify else verify_selection(infos, state["feats"], state["selected"])
+        first_selected = list(state["selected"])
+        first_feats = state["feats"]
         out = {
-            "metric": "unlabeled frames scored+selected/sec (whole node; 40 frames = 1 scene); selected-set equals ref",
+            "metric": "unlabeled frames scored+selected/sec (whole node; 40 frames = 1 scene); "
+                      + {True: "selected set equals the CPU oracle's", False: "SELECTED SET DIFFERS FROM THE CPU ORACLE",
+                         None: "selection not verified (--no-verify)"}[verified],
             "value": round(value, 2), "unit": "frames/s", "scenes_per_s": round(value / FRAMES_PER_SCENE, 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
@@ -277,12 +400,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.scenes * world}-scene nuScenes-shaped pool ({n_total} frames, "
                                    f"10-sweep ~250k-point clouds resident in HBM), FPNVoxelNet sweep + "
-                                   f"SpatialTemporalFeatureSelector budget {BUDGET} (BASELINE configs[1] per GPU)",
+                                   f"SpatialTemporalFeatureSelector budget {BUDGET} "
+                                   + ("(BASELINE configs[1])" if world == 1 and args.scenes == SCENES_PER_RANK else
+                                      f"(BASELINE configs[2] shape: {args.scenes} scenes per rank x {world} ranks"
+                                      + ("= the full pool)" if args.scenes * world == 704 else ")")),
                        "frames_per_rank": per_rank, "batch": args.batch,
                        "weights": "seeded random-init (al3d.synthetic.seeded_init_, seed 0)"},
             "breakdown_s_per_step": {"sweep+allgather": round(sweep_s / args.steps, 4),
                                      "select": round(select_s / args.steps, 4)},
             "selected_frames": len(state["selected"]),
+            "ranks_seen": ranks_seen, "sweep_s_per_rank": rank_sweep_s,
         }
         roof = timer.result()
         if roof:
@@ -293,11 +420,38 @@ def main():
                                    "ahead": "; the next batch's voxelization + rulebook (small latency-bound kernels) "
                                             "run on a second stream meanwhile"}.get(_sweep.PIPELINE, ""))
             out["roofline"] = roof
-        if not args.no_verify:
-            out["selected_equals_oracle"] = verify_selection(infos, state["feats"], state["selected"])
+        try:
+            sp_timer.measure_rulebook(model, next(iter(loader)))
+            roof_sp = sp_timer.result()
+            if roof_sp:
+                out["roofline_sparse"] = roof_sp
+        except Exception as e:           # a report, never a reason to lose the line
+            out["roofline_sparse"] = {"error": repr(e)}
+        if verified is not None:
+            out["selected_equals_oracle"] = verified
+        if world == 1 and not args.no_extra_math and _math() == "f16x3":
+            # the strict-range arithmetic (full fp32 exponent range, six bf16 products per MAC) on the same
+            # workload: one extra step outside the timed region, so the driver record carries both
+            try:
+                from al3d import detector_ops as D
+                D.MATH = "bf16x6"
+                step()                                  # re-packs the weights (untimed)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                out["value_bf16x6"] = round(n_total / dt, 2)
+                out["value_bf16x6_note"] = ("frames/s of one step under AL3D_MATH=bf16x6 (exact 3-way bf16 split, "
+                                            "6 MFMA products per MAC, full fp32 range), same workload, same process")
+                out["selected_equal_f16x3_bf16x6"] = bool(list(state["selected"]) == first_selected)
+            except Exception as e:
+                out["value_bf16x6"] = {"error": repr(e)}
+            finally:
+                D.MATH = "f16x3"
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, cpu_state, infos, state["feats"].cpu().numpy())
+                out["cpu_baseline"] = cpu_baseline(cfg, cpu_state, infos, first_feats.cpu().numpy())
             except Exception as e:       # the baseline is a report, never a reason to lose the line
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
@@ -361,9 +515,12 @@ def verify_selection(infos, feats, selected):
         f_row = acc
         ok &= np.array_equal(S[r].cpu().numpy().view(np.int64), s_row.view(np.int64))
         ok &= np.array_equal(F[r].cpu().numpy().view(np.int32), f_row.view(np.int32))
+        # combined map row: the oracle's row-block combine on the oracle rows
+        d_row = oracle.combine_rows(n, int(r), spatial_rows=s_row[None], temporal_id=run_id, feat_rows=f_row[None],
+                                    normalize="exp", aggregate="sum", lambda_t=1.0, lambda_f=1.0)[0]
+        ok &= np.array_equal(D[r].cpu().numpy().view(np.int64), d_row.view(np.int64))
     Dh = D.cpu().numpy()
     del S, F, D
-    # combined map rows: oracle combine on the sampled rows only (row-sliced inputs)
     rc, picks = oracle.greedy(Dh, [], first, box, 0.12, 0.0, float(BUDGET))
     return bool(ok and rc == 0 and picks.tolist() == list(selected))
 

@@ -33,6 +33,20 @@ def master_only(func):
     return wrapper
 
 
+def save_npy_atomic(path, array) -> None:
+    """``np.save`` through a temporary file + ``os.replace``: a reader (the next round's
+    ``os.path.exists`` + ``np.load``) never sees a torn map.  Same name rule as ``np.save``
+    (``.npy`` appended when missing)."""
+    import os
+    import numpy as np
+    if not str(path).endswith(".npy"):
+        path = str(path) + ".npy"
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        np.save(f, array)
+    os.replace(tmp, path)
+
+
 def logfile_of(info) -> str:
     """``cam_front_path`` basename up to the first ``__`` (spatial_temporal_selector.py:80)."""
     return info["cam_front_path"].split("/")[-1].split("__")[0]
@@ -221,6 +235,6 @@ class BaseSelector(object):
         xy = torch.from_numpy(np.ascontiguousarray(self._ego_xy(), dtype=np.float64)).to(device)
         spatial = ops.spatial_map(xy, k)
         if distance_store_file and _rank() == 0:
-            np.save(distance_store_file, spatial.cpu().numpy())
+            save_npy_atomic(distance_store_file, spatial.cpu().numpy())
             self.logger.info(f"save the distance map as {distance_store_file}")
         return spatial

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .base_selector import BaseSelector
+from .base_selector import BaseSelector, _rank, save_npy_atomic
 from .registry import SELECTORS
 
 _DEFAULT_LOGS = "/home/st2000/data/Datasets/nuScenes/train/v1.0-trainval/log.json"
@@ -84,8 +84,8 @@ class FeatureSelector(_SweepMixin, BaseSelector):
         if self.distance_store_file and os.path.exists(self.distance_store_file):
             return torch.from_numpy(np.load(self.distance_store_file)).to(feats.device)
         distance_map = ops.l1_distance(feats, self.p)
-        if self.distance_store_file:
-            np.save(self.distance_store_file, distance_map.cpu().numpy())
+        if self.distance_store_file and _rank() == 0:
+            save_npy_atomic(self.distance_store_file, distance_map.cpu().numpy())
         return distance_map
 
     def select_samples(self, **kwargs) -> None:
@@ -107,11 +107,11 @@ class SpatialTemporalFeatureSelector(_SweepMixin, BaseSelector):
             buffer_file: str,
             dump_file_name: Optional[str] = None,
             infos_origin: List[Dict] = [],
-            buffer_path: str = "",
+            buffer_path: str = "/home/st2000/data/buffers/feature_pred.pt",
             detector: Optional[torch.nn.Module] = None,
             dataloader=None,
             logger: Optional[logging.Logger] = None,
-            pred: bool = False,
+            pred: bool = True,
             k: int = 8,
             p: int = 2,
             logs_file: str = _DEFAULT_LOGS,

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ..utils.fileio import load
-from .base_selector import BaseSelector, logfile_of
+from .base_selector import BaseSelector, _rank, logfile_of, save_npy_atomic
 from .registry import SELECTORS
 
 _DEFAULT_LOGS = "/home/st2000/data/Datasets/nuScenes/train/v1.0-trainval/log.json"
@@ -175,6 +175,6 @@ class EuSpatialSelector(BaseSelector):
                               for i in self.infos_origin], dtype=np.int64)
             xy = torch.from_numpy(np.ascontiguousarray(self._ego_xy(), dtype=np.float64)).to(device)
             distance_map = ops.euclid_map(xy, torch.from_numpy(loc).to(device))
-            if self.distance_store_file:
-                np.save(self.distance_store_file, distance_map.cpu().numpy())
+            if self.distance_store_file and _rank() == 0:
+                save_npy_atomic(self.distance_store_file, distance_map.cpu().numpy())
         self._greedy(distance_map, device, check_seeded=True)

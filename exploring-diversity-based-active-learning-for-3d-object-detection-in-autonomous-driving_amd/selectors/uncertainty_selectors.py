@@ -12,7 +12,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .base_selector import BaseSelector, _rank
+from .base_selector import BaseSelector, _rank, save_npy_atomic
 from .registry import SELECTORS
 
 
@@ -108,7 +108,7 @@ class _WeightedFeatureSelector(BaseSelector):
             return torch.from_numpy(np.load(self.distance_store_file)).to(feats.device)
         distance_map = ops.l1_distance(feats, self.p)
         if self.distance_store_file and _rank() == 0:
-            np.save(self.distance_store_file, distance_map.cpu().numpy())
+            save_npy_atomic(self.distance_store_file, distance_map.cpu().numpy())
         return distance_map
 
     def select_samples(self, **kwargs) -> None:

@@ -189,10 +189,12 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                 pending = (example, ahead, ev)
             main.wait_stream(side)
     local = torch.cat(feats, dim=0)
-    _check_range(local)
     idx = torch.as_tensor(index, dtype=torch.int64, device=local.device)
     n = num_frames if num_frames is not None else int(idx.max().item()) + 1
     out = gather_in_dataset_order(local, idx, n)
+    # checked AFTER the collective, on the gathered tensor: every rank sees the same rows, so all
+    # ranks raise together instead of one rank leaving the others inside the all-gather
+    _check_range(out)
     if with_entropy:
         e = gather_in_dataset_order(torch.cat(ents).unsqueeze(1), idx, n).squeeze(1)
         return out, e

@@ -260,16 +260,20 @@ double al3d_oracle_max_finite(const double* a, int64_t n)
  * spatial may be NULL (term absent), temporal id may be NULL, feat may be NULL.
  * The feature term is float32: 1.0f - expf(-F), times (float)lambda_f, then
  * widened (numpy weak-scalar promotion). */
-void al3d_oracle_combine(const double* spatial, const int64_t* temporal_id, const float* feat,
-                         int64_t n, int normalize, int aggregate,
-                         double lambda_t, double lambda_f,
-                         double spatial_scale, double temporal_scale, double* out)
+/* Rows [row0, row0 + nrows) of the combined map: `spatial`, `feat` and `out` are [nrows, n] row
+ * blocks (row i of the block is map row row0 + i).  Same arithmetic per element as the full map;
+ * lets the checker compare sampled rows of a pool whose full O(N^2) oracle maps are too large. */
+void al3d_oracle_combine_rows(const double* spatial, const int64_t* temporal_id, const float* feat,
+                              int64_t n, int64_t row0, int64_t nrows, int normalize, int aggregate,
+                              double lambda_t, double lambda_f,
+                              double spatial_scale, double temporal_scale, double* out)
 {
     float lf = (float)lambda_f;
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t ii = 0; ii < nrows; ++ii) {
+        int64_t i = row0 + ii;
         for (int64_t j = 0; j < n; ++j) {
-            int64_t e = i * n + j;
+            int64_t e = ii * n + j;
             double s = 0.0, t = 0.0, f = 0.0;
             int nterm = 0;
             double terms[3];
@@ -305,6 +309,15 @@ void al3d_oracle_combine(const double* spatial, const int64_t* temporal_id, cons
             out[e] = r;
         }
     }
+}
+
+void al3d_oracle_combine(const double* spatial, const int64_t* temporal_id, const float* feat,
+                         int64_t n, int normalize, int aggregate,
+                         double lambda_t, double lambda_f,
+                         double spatial_scale, double temporal_scale, double* out)
+{
+    al3d_oracle_combine_rows(spatial, temporal_id, feat, n, 0, n, normalize, aggregate, lambda_t, lambda_f,
+                             spatial_scale, temporal_scale, out);
 }
 
 /* pairwise embedding distance, float32 (feature_selector.py:96-105): both the

@@ -147,6 +147,21 @@ def combine(n, spatial=None, temporal_id=None, feat=None, normalize="exp", aggre
     return out
 
 
+def combine_rows(n, row0, spatial_rows=None, temporal_id=None, feat_rows=None, normalize="exp",
+                 aggregate="sum", lambda_t=1.0, lambda_f=1.0, spatial_scale=1.0, temporal_scale=1.0):
+    """Rows [row0, row0+nrows) of ``combine``: ``spatial_rows`` / ``feat_rows`` are [nrows, n] blocks."""
+    spatial_rows = _c(spatial_rows, np.float64)
+    temporal_id = _c(temporal_id, np.int64)
+    feat_rows = _c(feat_rows, np.float32)
+    nrows = (spatial_rows if spatial_rows is not None else feat_rows).shape[0]
+    out = np.empty((nrows, n), dtype=np.float64)
+    lib().al3d_oracle_combine_rows(_p(spatial_rows), _p(temporal_id), _p(feat_rows), c_i64(n), c_i64(row0),
+                                   c_i64(nrows), c_int(NORMALIZE[normalize]), c_int(AGGREGATE[aggregate]),
+                                   c_dbl(lambda_t), c_dbl(lambda_f), c_dbl(spatial_scale),
+                                   c_dbl(temporal_scale), _p(out))
+    return out
+
+
 def l1_map_f32(feats, p=2):
     feats = _c(feats, np.float32)
     n, c = feats.shape

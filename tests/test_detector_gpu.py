@@ -104,6 +104,96 @@ def test_sparse_conv_residual_and_empty(oracle):
     assert e.shape[0] == 0 and ec.shape[0] == 0
 
 
+# ---------------------------------------------------------------- the encoder's OWN index path vs the oracle
+def _one_stage_encoder(mods):
+    """A one-stage encoder built from the product's `_SparseEncoderBase`: its `_run` goes through
+    `build_rulebook` (al3d_sp_scatter_index / al3d_sp_subm_table / al3d_sp_down_sites /
+    al3d_sp_down_table), `_pack` (incl. the zero-padded 5 -> 16 first layer) and `_conv` -- the code the
+    shipped FPNSpMiddleResNetFHD runs, unlike `detector_ops.sparse_conv_layer` (al3d_sp_down_claim)."""
+    from torch import nn
+    from al3d.models.backbones import _SparseEncoderBase
+
+    class OneStage(_SparseEncoderBase):
+        def __init__(self):
+            super().__init__()
+            self.stage = nn.Sequential(*mods)
+
+        def _stages(self):
+            return [self.stage]
+    return OneStage()
+
+
+def _np_fold(bn):
+    inv = 1.0 / np.sqrt(bn.running_var.numpy().astype(np.float64) + bn.eps)
+    scale = bn.weight.detach().numpy() * inv
+    return scale.astype(np.float32), (bn.bias.detach().numpy() - bn.running_mean.numpy() * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "f32"])
+@pytest.mark.parametrize("cin,cout,subm,k,s,p", [
+    (5, 16, True, (3, 3, 3), (1, 1, 1), (0, 0, 0)),          # first layer: zero-padded to 16 input channels
+    (16, 32, False, (3, 3, 3), (2, 2, 2), (1, 1, 1)),        # the three strided geometries of the encoder
+    (64, 128, False, (3, 3, 3), (2, 2, 2), (0, 1, 1)),
+    (128, 128, False, (3, 1, 1), (2, 1, 1), (0, 0, 0)),
+    (32, 32, True, (3, 3, 3), (1, 1, 1), (0, 0, 0)),
+    (64, 64, True, (3, 3, 3), (1, 1, 1), (0, 0, 0))])
+def test_encoder_rulebook_path_single_layer_vs_oracle(oracle, math, cin, cout, subm, k, s, p):
+    """scn.py:331-369 layer by layer through the product's rulebook + packing + conv dispatch."""
+    from al3d import detector_ops as D, synthetic
+    from al3d.models.backbones import SparseConv3d, SubMConv3d, _bn
+    from torch import nn
+    rng = np.random.default_rng(cin * 17 + cout + sum(s))
+    shape, batch = [9, 40, 37], 3
+    feats, coords = random_sparse(rng, batch, shape, 4001, cin)
+    conv = SubMConv3d(cin, cout, k, bias=False) if subm else SparseConv3d(cin, cout, k, s, padding=p, bias=False)
+    enc = _one_stage_encoder([conv, _bn(cout), nn.ReLU()])
+    synthetic.seeded_init_(enc, seed=cin + cout)
+    enc.eval()
+    sc, sh = _np_fold(enc.stage[1])
+    fo, co, oshape = oracle.spconv(feats, coords, batch, shape, conv.weight.detach().numpy(), k, s, p, subm)
+    ref = np.maximum(fo * sc + sh, 0)
+    saved = D.MATH
+    try:
+        D.MATH = math
+        enc = enc.to(DEV)
+        with torch.no_grad():
+            final, middle = enc._run(_t(feats), _t(coords), batch, shape)
+    finally:
+        D.MATH = saved
+    assert list(final.spatial_shape) == oshape and final.features.shape == (len(co), cout)
+    got, gco = final.features.cpu().numpy(), final.indices.cpu().numpy()
+    if subm:
+        assert np.array_equal(gco, coords)              # SubM keeps the sites and their order
+    np.testing.assert_allclose(to_dense(got, gco, batch, oshape), to_dense(ref, co, batch, oshape),
+                               rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("c", [16, 128])
+def test_encoder_rulebook_path_basic_block_vs_oracle(oracle, c):
+    """SparseBasicBlock (scn.py:54-97): conv+bias, BN, ReLU, conv+bias, BN, +identity, ReLU through the
+    product path; both convs share one rulebook (indice_key)."""
+    from al3d import synthetic
+    from al3d.models.backbones import SparseBasicBlock
+    rng = np.random.default_rng(c)
+    shape, batch = [9, 40, 37], 2
+    feats, coords = random_sparse(rng, batch, shape, 3000, c)
+    blk = SparseBasicBlock(c, c, indice_key="res")
+    enc = _one_stage_encoder([blk])
+    synthetic.seeded_init_(enc, seed=c)
+    enc.eval()
+    k3, s1, p0 = (3, 3, 3), (1, 1, 1), (0, 0, 0)
+    sc1, sh1 = _np_fold(blk.bn1)
+    sc2, sh2 = _np_fold(blk.bn2)
+    f, _, _ = oracle.spconv(feats, coords, batch, shape, blk.conv1.weight.detach().numpy(), k3, s1, p0, True)
+    f = np.maximum((f + blk.conv1.bias.detach().numpy()) * sc1 + sh1, 0)
+    f, _, _ = oracle.spconv(f, coords, batch, shape, blk.conv2.weight.detach().numpy(), k3, s1, p0, True)
+    ref = np.maximum((f + blk.conv2.bias.detach().numpy()) * sc2 + sh2 + feats, 0)
+    enc = enc.to(DEV)
+    with torch.no_grad():
+        final, _ = enc._run(_t(feats), _t(coords), batch, shape)
+    np.testing.assert_allclose(final.features.cpu().numpy(), ref, rtol=5e-5, atol=5e-5)
+
+
 # ---------------------------------------------------------------- full encoder vs dense torch
 def _dense_encoder_reference(model, feats, coords, batch, shape):
     """FPNSpMiddleResNetFHD emulated with dense conv3d + site masks on CPU (independent of the

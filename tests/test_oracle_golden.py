@@ -98,3 +98,23 @@ def test_greedy_tie_rule_and_budget(oracle):
     # exhausting the pool trips the duplicate assertion like the reference (A.1 #13)
     rc, picks = oracle.greedy(D, [], 0, box, 0.12, 0.0, 100.0)
     assert rc == -1 and len(picks) == n
+
+
+def test_combine_rows_equals_rows_of_the_full_map(oracle):
+    """The row-block form the large-pool checkers use (bench.verify_selection, test_config2_*) gives
+    the bits of the full-map form, for every normalisation / aggregation."""
+    rng = np.random.default_rng(8)
+    n = 97
+    S = rng.uniform(0, 60, (n, n))
+    S[rng.random((n, n)) < 0.1] = np.inf
+    F = rng.uniform(0, 3, (n, n)).astype(np.float32)
+    run_id = np.sort(rng.integers(0, 5, n)).astype(np.int64)
+    for norm in ("exp", "linear", "none"):
+        for agg in ("sum", "min", "max"):
+            kw = dict(normalize=norm, aggregate=agg, lambda_t=0.7, lambda_f=1.3, spatial_scale=55.0,
+                      temporal_scale=31.0)
+            full = oracle.combine(n, spatial=S, temporal_id=run_id, feat=F, **kw)
+            blk = oracle.combine_rows(n, 40, spatial_rows=S[40:53], temporal_id=run_id, feat_rows=F[40:53], **kw)
+            assert np.array_equal(full[40:53].view(np.int64), blk.view(np.int64)), (norm, agg)
+    st = oracle.combine_rows(n, 5, spatial_rows=S[5:6], temporal_id=run_id)
+    assert np.array_equal(st.view(np.int64), oracle.combine(n, spatial=S, temporal_id=run_id)[5:6].view(np.int64))

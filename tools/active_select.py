@@ -59,7 +59,9 @@ def main():
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
     if distributed:
         torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group(backend="nccl", init_method="env://")
+        # RCCL ("nccl" on ROCm), one GPU per rank; AL3D_DIST_BACKEND=gloo is the one-GPU rehearsal knob
+        torch.distributed.init_process_group(backend=os.environ.get("AL3D_DIST_BACKEND", "nccl"),
+                                             init_method="env://")
     rank = torch.distributed.get_rank() if distributed else 0
     world = torch.distributed.get_world_size() if distributed else 1
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.ERROR)
