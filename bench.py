@@ -161,12 +161,12 @@ class SparseTimer:
         conv = bb._conv
         timer = self
 
-        def timed(m, feats, nbr, K, step, residual, out, n, st):
+        def timed(*a, **k):
             if not timer.enabled:
-                return conv(m, feats, nbr, K, step, residual, out, n, st)
+                return conv(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            conv(m, feats, nbr, K, step, residual, out, n, st)
+            conv(*a, **k)
             e1.record()
             timer.events.append((timer._i, e0, e1))
             timer._i += 1
@@ -444,7 +444,15 @@ def main():
                 out["value_bf16x6"] = round(n_total / dt, 2)
                 out["value_bf16x6_note"] = ("frames/s of one step under AL3D_MATH=bf16x6 (exact 3-way bf16 split, "
                                             "6 MFMA products per MAC, full fp32 range), same workload, same process")
-                out["selected_equal_f16x3_bf16x6"] = bool(list(state["selected"]) == first_selected)
+                # the selection is a discrete function of tolerance-bound embeddings: report how far the two
+                # arithmetics' picks agree (identical prefix + set overlap), not just a yes/no
+                other = list(state["selected"])
+                same_prefix = next((i for i, (a, b) in enumerate(zip(first_selected, other)) if a != b),
+                                   min(len(other), len(first_selected)))
+                out["selection_f16x3_vs_bf16x6"] = {
+                    "identical": bool(other == first_selected), "identical_prefix": same_prefix,
+                    "common": len(set(other) & set(first_selected)), "of": len(first_selected),
+                    "max_abs_embedding_diff": float((state["feats"] - first_feats).abs().max())}
             except Exception as e:
                 out["value_bf16x6"] = {"error": repr(e)}
             finally:

@@ -200,6 +200,66 @@ __global__ void sp_down_table_kernel(const int* __restrict__ coords_out, int n_o
     }
 }
 
+// ------------------------------------------------------------------ tiled rulebook (csrc/spconv_glds.hip)
+// The same tables with a row pitch that is a multiple of 64 (rows >= n hold -1), so that the 32 entries of
+// one (tap, 32-row tile) are one aligned 128-byte line, plus tmask[tile] = the set of taps with at least
+// one neighbour in that tile: the conv kernel reads one word per tile instead of scanning 27 x 32 entries.
+__global__ void sp_subm_table_tiles_kernel(const int* __restrict__ coords, int n, int pitch, SpDims g,
+                                           const int* __restrict__ grid, int kd, int kh, int kw,
+                                           int* __restrict__ nbr, unsigned* __restrict__ tmask)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // exact grid: pitch * kd * kh threads
+    const int kzy = (int)(e / pitch), i = (int)(e % pitch);
+    const int ky = kzy % kh, kz = kzy / kh;
+    int z = 0, y = 0, x0 = 0, b = 0;
+    bool row_ok = false;
+    if (i < n) {
+        const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)i);
+        b = c.x; z = c.y + kz - kd / 2; y = c.z + ky - kh / 2; x0 = c.w - kw / 2;
+        row_ok = z >= 0 && z < g.D && y >= 0 && y < g.H;
+    }
+    const int64_t base = row_ok ? sp_cell(g, b, z, y, 0) : 0;
+    const int lane = threadIdx.x & 63;
+    for (int kx = 0; kx < kw; ++kx) {
+        const int x = x0 + kx;
+        int v = -1;
+        if (row_ok && x >= 0 && x < g.W) v = grid[base + x];
+        const int k = kzy * kw + kx;
+        nbr[(int64_t)k * pitch + i] = v;
+        const unsigned long long bal = __ballot(v >= 0);                    // the wave's 64 rows = tiles i/32, i/32 + 1
+        if (lane == 0 && (bal & 0xffffffffull)) atomicOr(&tmask[i >> 5], 1u << k);
+        if (lane == 32 && (bal >> 32)) atomicOr(&tmask[i >> 5], 1u << k);
+    }
+}
+
+__global__ void sp_down_table_tiles_kernel(const int* __restrict__ coords_out, int n_out, int pitch, SpConvGeom q,
+                                           SpDims gi, const int* __restrict__ grid_in, int* __restrict__ nbr,
+                                           unsigned* __restrict__ tmask)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kzy = (int)(e / pitch), o = (int)(e % pitch);
+    const int ky = kzy % q.kh, kz = kzy / q.kh;
+    int z = 0, y = 0, x0 = 0, b = 0;
+    bool row_ok = false;
+    if (o < n_out) {
+        const int4 c = *reinterpret_cast<const int4*>(coords_out + 4 * (int64_t)o);
+        b = c.x; z = c.y * q.sd - q.pd + kz; y = c.z * q.sh - q.ph + ky; x0 = c.w * q.sw - q.pw;
+        row_ok = z >= 0 && z < gi.D && y >= 0 && y < gi.H;
+    }
+    const int64_t base = row_ok ? sp_cell(gi, b, z, y, 0) : 0;
+    const int lane = threadIdx.x & 63;
+    for (int kx = 0; kx < q.kw; ++kx) {
+        const int x = x0 + kx;
+        int v = -1;
+        if (row_ok && x >= 0 && x < gi.W) v = grid_in[base + x];
+        const int k = kzy * q.kw + kx;
+        nbr[(int64_t)k * pitch + o] = v;
+        const unsigned long long bal = __ballot(v >= 0);
+        if (lane == 0 && (bal & 0xffffffffull)) atomicOr(&tmask[o >> 5], 1u << k);
+        if (lane == 32 && (bal >> 32)) atomicOr(&tmask[o >> 5], 1u << k);
+    }
+}
+
 // ------------------------------------------------------------------ the conv itself
 // 32 output rows x COUT per 256-thread workgroup.  Thread -> one output channel and
 // 32*COUT/256 rows; per kernel offset the 32 gathered input rows sit in LDS (broadcast
@@ -325,6 +385,28 @@ extern "C" int al3d_sp_subm_table(const int* coords, int n, int B, int D, int H,
     return AL3D_OK;
 }
 
+// multiple of 256: the table kernels run exact grids of 256-thread blocks whose waves cover 64 consecutive rows
+extern "C" int al3d_sp_table_pitch(int n) { return (int)al3d_align(n > 0 ? n : 1, 256); }
+
+extern "C" int al3d_sp_subm_table_tiles(const int* coords, int n, int B, int D, int H, int W, const int* grid,
+                                        int kd, int kh, int kw, int* nbr, int pitch, unsigned* tile_mask,
+                                        void* stream)
+{
+    AL3D_REQUIRE(n >= 0 && pitch == al3d_sp_table_pitch(n), "al3d_sp_subm_table_tiles: pitch must be al3d_sp_table_pitch(n)");
+    AL3D_REQUIRE(nbr && tile_mask && (n == 0 || (coords && grid)), "al3d_sp_subm_table_tiles: null pointer");
+    AL3D_REQUIRE(kd % 2 == 1 && kh % 2 == 1 && kw % 2 == 1 && kd * kh * kw <= 27,
+                 "al3d_sp_subm_table_tiles: odd kernel sizes, at most 27 taps");
+    AL3D_REQUIRE(((uintptr_t)coords & 15) == 0, "al3d_sp_subm_table_tiles: coords must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(tile_mask, 0, (size_t)(pitch / 32) * 4, s) != hipSuccess)
+        return al3d_fail(AL3D_ELAUNCH, "al3d_sp_subm_table_tiles: memset failed");
+    SpDims g = {B, D, H, W};
+    hipLaunchKernelGGL(sp_subm_table_tiles_kernel, dim3((unsigned)((int64_t)pitch * kd * kh / 256)), dim3(256), 0, s,
+                       coords, n, pitch, g, grid, kd, kh, kw, nbr, tile_mask);
+    AL3D_CHECK_LAUNCH("sp_subm_table_tiles_kernel");
+    return AL3D_OK;
+}
+
 extern "C" int al3d_sp_down_claim(const int* coords_in, int n_in, const int* ksize, const int* stride,
                                   const int* pad, int B, int OD, int OH, int OW, int* grid_out,
                                   int* coords_out, int* counter, int cap, void* stream)
@@ -398,6 +480,27 @@ extern "C" int al3d_sp_down_table(const int* coords_out, int n_out, const int* k
     hipLaunchKernelGGL(sp_down_table_kernel, dim3(blocks_for((int64_t)n_out * q.kd * q.kh, 256)),
                        dim3(256), 0, (hipStream_t)stream, coords_out, n_out, q, gi, grid_in, nbr);
     AL3D_CHECK_LAUNCH("sp_down_table_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_sp_down_table_tiles(const int* coords_out, int n_out, const int* ksize, const int* stride,
+                                        const int* pad, int B, int ID, int IH, int IW, const int* grid_in,
+                                        int* nbr, int pitch, unsigned* tile_mask, void* stream)
+{
+    AL3D_REQUIRE(n_out >= 0 && pitch == al3d_sp_table_pitch(n_out),
+                 "al3d_sp_down_table_tiles: pitch must be al3d_sp_table_pitch(n_out)");
+    AL3D_REQUIRE(ksize && stride && pad && nbr && tile_mask && (n_out == 0 || (coords_out && grid_in)),
+                 "al3d_sp_down_table_tiles: null pointer");
+    AL3D_REQUIRE(((uintptr_t)coords_out & 15) == 0, "al3d_sp_down_table_tiles: coords_out must be 16-byte aligned");
+    AL3D_REQUIRE(ksize[0] * ksize[1] * ksize[2] <= 27, "al3d_sp_down_table_tiles: at most 27 taps");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(tile_mask, 0, (size_t)(pitch / 32) * 4, s) != hipSuccess)
+        return al3d_fail(AL3D_ELAUNCH, "al3d_sp_down_table_tiles: memset failed");
+    SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
+    SpDims gi = {B, ID, IH, IW};
+    hipLaunchKernelGGL(sp_down_table_tiles_kernel, dim3((unsigned)((int64_t)pitch * q.kd * q.kh / 256)), dim3(256), 0, s,
+                       coords_out, n_out, pitch, q, gi, grid_in, nbr, tile_mask);
+    AL3D_CHECK_LAUNCH("sp_down_table_tiles_kernel");
     return AL3D_OK;
 }
 

@@ -120,6 +120,27 @@ def pack_bstream_f16x3(planes):
     return F16x3Packed("bstream", out, cout, taps, cin)
 
 
+class GldsPacked:
+    """f16x3 sparse-conv weights in the LDS image order of the DMA-gather kernel
+    (al3d_sp_pack_glds_f16x3: [K][Cin/16][2][ceil32(Cout)][16] f16, halves swizzled)."""
+    dtype = torch.float16
+
+    def __init__(self, data, cout, K, cin):
+        self.data, self.cout, self.K, self.cin = data, cout, K, cin
+
+
+def pack_glds_f16x3(planes):
+    """f16 planes [2,Cout,K,Cin] (split_f16x3 of the [Cout,K,Cin] weights) -> GldsPacked."""
+    planes = _dev(planes, torch.float16, "planes")
+    _, cout, K, cin = planes.shape
+    n = lib.load().al3d_sp_pack_glds_f16x3_elems(cout, K, cin)
+    if n <= 0:
+        raise lib.Al3dError(f"pack_glds_f16x3: unsupported shape Cout={cout} K={K} Cin={cin}")
+    out = torch.empty((n,), dtype=torch.float16, device=planes.device)
+    lib.call("al3d_sp_pack_glds_f16x3", _ptr(planes), cout, K, cin, _ptr(out), _stream())
+    return GldsPacked(out, cout, K, cin)
+
+
 def frag_ok(cout, cin, ksize, stride, pad):
     return ksize == 3 and stride == 1 and pad == 1 and cout % 128 == 0 and cin % 32 == 0
 
@@ -144,9 +165,19 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
     return w_packed, scale
 
 
-# sparse-conv structure for the bf16x6 arithmetic: "auto" = the software-pipelined wave kernel;
-# "wave" (unpipelined wave kernel) and "tile" (LDS-staged 128-row tile) give the same bits, for A/B
+# sparse-conv structure.  f16x3: "auto" = per channel pair whichever of the two kernels measured faster on the real
+# rulebooks (GLDS_PAIRS: the LDS-DMA gather kernel, else the register-gather wave kernel), "glds" / "wave2" = one of
+# them everywhere (same bits either way).  bf16x6: "auto" = the software-pipelined wave kernel; "wave" (unpipelined
+# wave kernel) and "tile" (LDS-staged 128-row tile) give the same bits, for A/B
 SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
+GLDS_PAIRS = {(32, 32), (64, 64)}
+
+
+def sparse_glds(cin=None, cout=None):
+    """True when the f16x3 sparse layer cin -> cout runs on the LDS-DMA gather kernel (no arguments: any layer may)."""
+    if MATH != "f16x3" or SPCONV not in ("auto", "glds"):
+        return False
+    return SPCONV == "glds" or cin is None or (cin, cout) in GLDS_PAIRS
 
 
 # ------------------------------------------------------------------ kernels
@@ -309,10 +340,22 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
     D_, H_, W_ = [int(v) for v in in_shape]
     grid_in = torch.full((batch * D_ * H_ * W_,), -1, dtype=torch.int32, device=dev)
     lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch, D_, H_, W_, _ptr(grid_in), 1, st)
+    if mfma is None:
+        mfma = (cin, cout) in MFMA_PAIRS and ({"bf16x6": "wave2", "f16x3": "glds_f16x3" if sparse_glds(cin, cout) else "wave2_f16x3"}
+                                               .get(sparse_math(), True))
+    tiled = mfma == "glds_f16x3"              # pitched table + per-tile tap masks (al3d_sp_*_table_tiles)
+    tmask = None
     if subm:
-        nbr = torch.empty((max(n, 1), K), dtype=torch.int32, device=dev)
-        lib.call("al3d_sp_subm_table", _ptr(coords), n, batch, D_, H_, W_, _ptr(grid_in), k[0], k[1], k[2],
-                 _ptr(nbr), st)
+        if tiled:
+            pitch = lib.load().al3d_sp_table_pitch(n)
+            nbr = torch.empty((K, pitch), dtype=torch.int32, device=dev)
+            tmask = torch.empty((pitch // 32,), dtype=torch.int32, device=dev)
+            lib.call("al3d_sp_subm_table_tiles", _ptr(coords), n, batch, D_, H_, W_, _ptr(grid_in), k[0], k[1], k[2],
+                     _ptr(nbr), pitch, _ptr(tmask), st)
+        else:
+            nbr = torch.empty((max(n, 1), K), dtype=torch.int32, device=dev)
+            lib.call("al3d_sp_subm_table", _ptr(coords), n, batch, D_, H_, W_, _ptr(grid_in), k[0], k[1], k[2],
+                     _ptr(nbr), st)
         ocoords, n_out, oshape = coords, n, [D_, H_, W_]
     else:
         s3, p3 = [int(v) for v in stride], [int(v) for v in pad]
@@ -326,13 +369,23 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
                  _ptr(grid_out), _ptr(ocoords), _ptr(counter), cap, st)
         n_out = int(counter.item())
         ocoords = ocoords[:n_out].contiguous()
-        nbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
-        lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
-                 _ptr(grid_in), _ptr(nbr), st)
+        if tiled:
+            pitch = lib.load().al3d_sp_table_pitch(n_out)
+            nbr = torch.empty((K, pitch), dtype=torch.int32, device=dev)
+            tmask = torch.empty((pitch // 32,), dtype=torch.int32, device=dev)
+            lib.call("al3d_sp_down_table_tiles", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
+                     _ptr(grid_in), _ptr(nbr), pitch, _ptr(tmask), st)
+        else:
+            nbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
+            lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
+                     _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    if mfma is None:
-        mfma = (cin, cout) in MFMA_PAIRS and ({"bf16x6": "wave2", "f16x3": "wave2_f16x3"}.get(sparse_math(), True))
-    if mfma == "wave2_f16x3":
+    if mfma == "glds_f16x3":
+        w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
+        pk = pack_glds_f16x3(w3)
+        lib.call("al3d_sp_conv_glds_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(pk.data), cin,
+                 cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+    elif mfma == "wave2_f16x3":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
         lib.call("al3d_sp_conv_wave2_f16x3", _ptr(feats), _ptr(nbr), K, _ptr(w3), cin, cout, _ptr(sc3),
                  _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)

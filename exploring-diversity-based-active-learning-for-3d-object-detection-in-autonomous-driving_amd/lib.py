@@ -78,6 +78,15 @@ SIGNATURES = {
                                                  c_int, c_p]),
     "al3d_sp_conv_wave2_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int, c_p,
                                                  c_int, c_p]),
+    "al3d_sp_pack_glds_f16x3_elems": (c_i64, [c_int, c_int, c_int]),
+    "al3d_sp_pack_glds_f16x3": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_sp_conv_glds_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
+                                        c_p, c_int, c_p]),
+    "al3d_sp_table_pitch": (c_int, [c_int]),
+    "al3d_sp_subm_table_tiles": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_int,
+                                         c_p, c_int, c_p, c_p]),
+    "al3d_sp_down_table_tiles": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
+                                         c_int, c_p, c_p]),
     "al3d_merge_bf16x3": (c_int, [c_p, c_i64, c_p, c_p]),
     "al3d_sp_to_dense_nhwc": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_head_decode_nms": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p,

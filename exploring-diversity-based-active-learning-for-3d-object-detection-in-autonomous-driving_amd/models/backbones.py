@@ -93,7 +93,7 @@ class _SparseEncoderBase(nn.Module):
 
     def _prepare(self, device):
         """Pack weights / fold BN once per device (eval only)."""
-        if getattr(self, "_packed_dev", None) == (device, D.MATH):
+        if getattr(self, "_packed_dev", None) == (device, D.MATH, D.SPCONV):
             return
         plan = []
         for seq in self._stages():
@@ -123,7 +123,7 @@ class _SparseEncoderBase(nn.Module):
                     i += 1
             plan.append(dict(kind="stage_end"))
         self._plan = plan
-        self._packed_dev = (device, D.MATH)
+        self._packed_dev = (device, D.MATH, D.SPCONV)
         self._levels = {}
 
     @staticmethod
@@ -146,16 +146,23 @@ class _SparseEncoderBase(nn.Module):
         if (cin, m.out_channels) in MFMA_PAIRS:
             w = w.permute(2, 0, 1).contiguous().to(device)
             if D.sparse_math() == "f16x3":
-                return D.split_f16x3(w, scale)
+                planes, scale = D.split_f16x3(w, scale)
+                return (D.pack_glds_f16x3(planes) if D.sparse_glds(cin, m.out_channels) else planes), scale
             return (D.split_bf16x3(w) if D.sparse_math() == "bf16x6" else w), scale
         return w.contiguous().to(device), scale
 
     @staticmethod
-    def _conv(m, feats, nbr, K, step, residual, out, n, st):
+    def _conv(m, feats, nbr, K, step, residual, out, n, st, tmask=None):
         """One fused sparse layer (conv + folded BN + optional residual + ReLU)."""
         res_ptr = None if residual is None else _ptr(residual)
         cin = feats.shape[-1]                    # == m.in_channels, or 16 for a zero-padded narrow first layer
         mfma_pair = (cin, m.out_channels) in MFMA_PAIRS
+        if mfma_pair and isinstance(step["w"], D.GldsPacked):
+            # f16x3 arithmetic, LDS-DMA row gather (full-line fetches) + producer-wave weight slabs
+            lib.call("al3d_sp_conv_glds_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K,
+                     _ptr(step["w"].data), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr,
+                     1, _ptr(out), n, st)
+            return
         if mfma_pair and step["w"].dtype == torch.float16:
             fn = "al3d_sp_conv_wave2_f16x3"           # f16x3 arithmetic, software-pipelined wave kernel
         elif mfma_pair and step["w"].dtype == torch.bfloat16:
@@ -206,14 +213,22 @@ class _SparseEncoderBase(nn.Module):
                 continue
             m = step["mod"]
             K = int(np.prod(m.kernel_size))
+            tiled = isinstance(step["w"], D.GldsPacked)      # LDS-DMA gather kernel: pitched table + tile masks
             if step["kind"] == "subm":
-                key = (id(lv), m.kernel_size)
+                key = (id(lv), m.kernel_size, tiled)
                 if nbr_key != key:
-                    nbr = torch.empty((K, max(n, 1)), dtype=torch.int32, device=dev)
-                    lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
-                             _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
+                    if tiled:
+                        pitch = lib.load().al3d_sp_table_pitch(n)
+                        nbr = torch.empty((K, pitch), dtype=torch.int32, device=dev)
+                        tmask = torch.empty((pitch // 32,), dtype=torch.int32, device=dev)
+                        lib.call("al3d_sp_subm_table_tiles", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
+                                 _ptr(lv.grid), *m.kernel_size, _ptr(nbr), pitch, _ptr(tmask), st)
+                    else:
+                        nbr, tmask = torch.empty((K, max(n, 1)), dtype=torch.int32, device=dev), None
+                        lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
+                                 _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
                     nbr_key = key
-                steps.append(dict(nbr=nbr, n=n, K=K))
+                steps.append(dict(nbr=nbr, n=n, K=K, tmask=tmask))
             else:
                 oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
                 olv = self._level(oshape, batch_size, dev)
@@ -228,10 +243,17 @@ class _SparseEncoderBase(nn.Module):
                 n_out = int(counter.item())      # one small D2H per stage
                 ocoords = ocoords[:n_out]
                 used.append((olv, ocoords, n_out))
-                dnbr = torch.empty((K, max(n_out, 1)), dtype=torch.int32, device=dev)
-                lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
-                         lv.W, _ptr(lv.grid), _ptr(dnbr), st)
-                steps.append(dict(nbr=dnbr, n=n_out, K=K))
+                if tiled:
+                    pitch = lib.load().al3d_sp_table_pitch(n_out)
+                    dnbr = torch.empty((K, pitch), dtype=torch.int32, device=dev)
+                    dmask = torch.empty((pitch // 32,), dtype=torch.int32, device=dev)
+                    lib.call("al3d_sp_down_table_tiles", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
+                             lv.W, _ptr(lv.grid), _ptr(dnbr), pitch, _ptr(dmask), st)
+                else:
+                    dnbr, dmask = torch.empty((K, max(n_out, 1)), dtype=torch.int32, device=dev), None
+                    lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
+                             lv.W, _ptr(lv.grid), _ptr(dnbr), st)
+                steps.append(dict(nbr=dnbr, n=n_out, K=K, tmask=dmask))
                 coords, n, shape, lv = ocoords, n_out, oshape, olv
                 nbr_key = None
         for g, c, cnt in used:      # leave every level grid clean for the next call
@@ -262,7 +284,8 @@ class _SparseEncoderBase(nn.Module):
             if step.get("block_start"):
                 identity = feats
             out = torch.empty((b["n"], m.out_channels), dtype=torch.float32, device=dev)
-            self._conv(m, feats, b["nbr"], b["K"], step, identity if step.get("residual") else None, out, b["n"], st)
+            self._conv(m, feats, b["nbr"], b["K"], step, identity if step.get("residual") else None, out, b["n"], st,
+                       tmask=b.get("tmask"))
             feats = out
         last = middle[-1]
         return SparseTensor(feats, last.indices, last.spatial_shape, batch_size), middle

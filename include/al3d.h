@@ -290,6 +290,30 @@ int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K, const voi
 int al3d_sp_conv_wave2_f16x3(const float* fin, const int* nbr, int K, const void* wgt_f16x2, int cin,
                              int cout, const float* scale, const float* shift, const float* residual,
                              int relu, float* fout, int n_out, void* stream);
+/* Tiled rulebook for al3d_sp_conv_glds_f16x3: the tables of al3d_sp_subm_table / al3d_sp_down_table with a
+ * row pitch of al3d_sp_table_pitch(n) (a multiple of 256; entries of rows >= n are -1), so that the 32
+ * indices of one (tap, 32-row tile) form one aligned 128-byte line, plus tile_mask[pitch/32]: bit k set
+ * iff tap k has a neighbour for at least one row of the tile (zeroed and filled here).  At most 27 taps.
+ * Same rulebook statement as above: geometry.h:25-82,145-194. */
+int al3d_sp_table_pitch(int n);
+int al3d_sp_subm_table_tiles(const int* coords, int n, int B, int D, int H, int W, const int* grid, int kd,
+                             int kh, int kw, int* nbr, int pitch, unsigned* tile_mask, void* stream);
+int al3d_sp_down_table_tiles(const int* coords_out, int n_out, const int* ksize, const int* stride,
+                             const int* pad, int B, int ID, int IH, int IW, const int* grid_in, int* nbr,
+                             int pitch, unsigned* tile_mask, void* stream);
+/* The sparse layer (scn.py:331-369 via spconv_ops.h:260-361) with an LDS-DMA row gather: every gathered
+ * row is fetched as full 128-byte lines by global_load_lds (8 line lookups per KiB instead of the 64 of
+ * fragment-shaped register loads) into a swizzled LDS image, each wave owns several 32-row tiles and
+ * walks the (tap, tile) items their tile masks name, a producer wave streams the weight slabs; f16x3
+ * arithmetic in al3d_sp_conv_wave2_f16x3's summation order, so results are BIT-IDENTICAL to it.
+ * nbr / nbr_pitch / tile_mask: a tiled rulebook (above).  `wgt_image` = al3d_sp_pack_glds_f16x3 of the two
+ * f16 planes ([K][Cin/16][2][ceil32(Cout)][16] f16, halves swizzled, LDS image order, zero rows beyond
+ * Cout); al3d_sp_pack_glds_f16x3_elems gives its element count (-1: unsupported shape). */
+int64_t al3d_sp_pack_glds_f16x3_elems(int cout, int K, int cin);
+int al3d_sp_pack_glds_f16x3(const void* planes_f16x2, int cout, int K, int cin, void* out_image, void* stream);
+int al3d_sp_conv_glds_f16x3(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                            const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
+                            const float* residual, int relu, float* fout, int n_out, void* stream);
 /* planes [3][count] bf16 -> f32 [count], exact (inverse of al3d_split_bf16x3) */
 int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));
