@@ -181,7 +181,11 @@ class MultiGroupHead(nn.Module):
         # only waits for it when somebody actually reads the detections.
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_side", None) is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
+            from ..sweep import masked_stream
+            import os
+            # AL3D_NMS_CUS=n: decode + NMS (192 one-workgroup problems per batch) on n compute units
+            self._side = masked_stream(dev, int(os.environ.get("AL3D_NMS_CUS", "0")),
+                                       int(os.environ.get("AL3D_NMS_CU0", "0")))
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(self._side):

@@ -77,10 +77,26 @@ PIPELINE = {"1": "split", "split": "split", "0": None, "off": None, "none": None
 _SIDE = {}
 
 
+# AL3D_SIDE_CUS=n: the side stream may use only n compute units (hipExtStreamCreateWithCUMask); 0 = all
+SIDE_CUS = int(_os.environ.get("AL3D_SIDE_CUS", "0"))
+
+
+def masked_stream(device, n_cus, first_cu=0):
+    """A torch stream on ``n_cus`` compute units of ``device`` (0: an ordinary stream)."""
+    if n_cus <= 0:
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    from . import lib
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        lib.call("al3d_stream_create_cu_mask", int(n_cus), int(first_cu), ctypes.byref(out))
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 def _side_stream(device):
     key = torch.device(device).index or 0
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        _SIDE[key] = masked_stream(device, SIDE_CUS)
     return _SIDE[key]
 
 

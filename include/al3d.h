@@ -399,6 +399,38 @@ int64_t al3d_gap_workspace_bytes(int B, int H, int C);
 int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out, void* workspace,
                       void* stream);
 
+/* ---------------------------------------------------------------- streaming file loader (a1 / f2)
+ * Host reader pool (csrc/reader.cpp, pthreads): replaces the reference's DataLoader worker processes
+ * (det3d/datasets/loader/build_loader.py:23-59) for the part that touches files -- read_file / read_sweep's
+ * np.fromfile (det3d/datasets/pipelines/loading.py:17-24,27-36).  plan() stats the files (rows = whole
+ * 20-byte x,y,z,intensity,ring records); submit() starts reading file i's rows to dst + 20*row_off[i]
+ * (dst is the caller's pinned staging buffer) on the pool and returns a job id; wait() blocks until that
+ * job's files have landed (an I/O error of a worker is reported here).  Thread-safe per reader. */
+typedef struct al3d_reader al3d_reader;
+int al3d_reader_create(int n_threads, al3d_reader** out);
+void al3d_reader_destroy(al3d_reader* reader);
+int64_t al3d_reader_plan(const char* const* paths, int n_files, int64_t* rows_out);
+int al3d_reader_submit(al3d_reader* reader, const char* const* paths, int n_files, const int64_t* row_off,
+                       const int64_t* rows, void* dst, int64_t dst_bytes);
+int al3d_reader_wait(al3d_reader* reader, int job_id);
+/* al3d_merge_sweeps_f32 for the files of n_frames frames back to back (loading.py:98-126 per frame):
+ * is_key[f] marks a frame's key file (kept whole, time 0), frame_first_file [n_frames+1] the file index each
+ * frame starts at; out = the frames' clouds back to back, out_frame_off [n_frames+1] int64 their first
+ * points.  Same arithmetic as al3d_merge_sweeps_f32 (bit-identical per frame); workspace as
+ * al3d_merge_sweeps_workspace_bytes(total_rows). */
+int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                                const double* xform, const unsigned char* has_xform, const double* time_lag,
+                                const unsigned char* is_key, const int* frame_first_file, int n_frames,
+                                float min_distance, float* out, int64_t* out_frame_off, void* workspace,
+                                void* stream);
+
+/* ---------------------------------------------------------------- runtime
+ * A HIP stream restricted to n_cus compute units starting at first_cu (hipExtStreamCreateWithCUMask); the
+ * reference has no analogue (its loader workers are host processes, det3d/datasets/loader/build_loader.py:23-59):
+ * here the next batch's voxelizer + rulebook and the decode/NMS kernels run on such a stream next to the main
+ * stream's convolutions.  The stream lives until process exit. */
+int al3d_stream_create_cu_mask(int n_cus, int first_cu, void** out_stream);
+
 #ifdef __cplusplus
 }
 #endif

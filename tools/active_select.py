@@ -107,15 +107,19 @@ def main():
         n = len(infos)
         per = (n + world - 1) // world
         mine = list(range(rank * per, min(n, (rank + 1) * per)))
-        if args.synthetic_scenes:
-            pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
-        else:
-            pool = PoolFrames.from_files([infos[i] for i in mine], dev, nsweeps=cfg.nsweeps,
-                                         root=cfg.data_root)
         # embedding-only models (bbox_head=None, e.g. the BEVFusion lidar branch) need no anchors
         anchors = None if cfg.model.get("bbox_head") is None else \
             generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
-        loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
+        if args.synthetic_scenes:
+            pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
+            loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
+        else:
+            # real files: streamed by the native reader pool one batch ahead of the detector (the reference's
+            # 8 DataLoader workers, build_loader.py:23-59), never staged as a whole pool
+            from al3d.datasets import FileSweepLoader
+            loader = FileSweepLoader([infos[i] for i in mine], cfg.voxel_generator, anchors, batch_size=args.batch,
+                                     device=dev, nsweeps=cfg.nsweeps, root=cfg.data_root,
+                                     threads=int(os.environ.get("AL3D_READER_THREADS", "8")))
         loader.sampler = mine
 
     sel_cfg.update({"detector": model, "dataloader": loader, "logger": logger, "pred": args.pred})
