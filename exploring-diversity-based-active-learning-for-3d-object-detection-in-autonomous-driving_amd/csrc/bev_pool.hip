@@ -1,0 +1,239 @@
+// BEV pooling of the camera branch (reference
+// bevfusion/mmdet3d/models/vtransforms/base.py:127-163 + bevfusion/mmdet3d/ops/bev_pool/bev_pool.py:82-97 +
+// src/bev_pool_cuda.cu:21-44): every frustum point p carries a C-vector x[p] and a lidar-frame position;
+// points that fall into the same BEV cell are summed, out[b, ix, iy, iz*C + c] (the reference's
+// [B,C,D,H,W] -> cat(unbind(2), 1) layout, channels last).
+//
+// The reference sorts the points by cell rank (torch.argsort, unstable) and sums each run with one thread per
+// (run, channel).  Here nothing is sorted globally: cell ids -> per-cell counts (integer atomics: order-free) ->
+// exclusive scan -> per-cell member lists filled in arrival order -> one wave per cell puts its (short) list into
+// ascending point order by rank counting and sums in that order.  The summation order is therefore FIXED
+// (ascending p, i.e. what a stable sort would give) and the result deterministic; the reference's own order is
+// implementation-defined, so parity with it is a floating-point tolerance either way.
+//
+// Two forms: x materialised ([P,C], the reference's exact op) and the Lift-Splat outer product fused in
+// (x[p] = depth[p] * ctx[pixel(p)], depth_lss.py:92-97) so that the [B,N,D,fH,fW,C] tensor -- 638 MB per sample at
+// 6 x 118 x 32 x 88 x 80 -- is never written: the pooling then reads 13 MB.
+#include "al3d_common.h"
+#include "al3d_scan.h"
+
+struct BevGrid {
+    float lo[3], dx[3];       // lo = bx - dx/2 (float32, as the reference computes it), cell size
+    int nx[3];                // cells along x, y, z
+    int B;
+    int64_t per_batch;        // points per sample
+};
+
+// ((g - lo) / dx).long(): truncation toward zero; kept iff 0 <= cell < nx (base.py:136,147-154)
+__device__ __forceinline__ int bev_axis_cell(float g, float lo, float dx, int nx)
+{
+    const float t = (g - lo) / dx;
+    if (!(t > -1.0f && t < (float)nx)) return -1;          // also drops NaN
+    return (int)t;
+}
+
+__global__ void bev_cell_kernel(const float* __restrict__ geom, int64_t P, BevGrid g, int* __restrict__ cell,
+                                int* __restrict__ count)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int ix = bev_axis_cell(geom[3 * p], g.lo[0], g.dx[0], g.nx[0]);
+    const int iy = bev_axis_cell(geom[3 * p + 1], g.lo[1], g.dx[1], g.nx[1]);
+    const int iz = bev_axis_cell(geom[3 * p + 2], g.lo[2], g.dx[2], g.nx[2]);
+    int c = -1;
+    if (ix >= 0 && iy >= 0 && iz >= 0) {
+        const int b = (int)(p / g.per_batch);
+        c = ((b * g.nx[0] + ix) * g.nx[1] + iy) * g.nx[2] + iz;
+        atomicAdd(&count[c], 1);
+    }
+    cell[p] = c;
+}
+
+__global__ void bev_scatter_kernel(const int* __restrict__ cell, int64_t P, const int* __restrict__ start,
+                                   int* __restrict__ fill, int* __restrict__ list)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int c = cell[p];
+    if (c < 0) return;
+    list[start[c] + atomicAdd(&fill[c], 1)] = (int)p;
+}
+
+// One wave per cell.  LSS = 1: x[p][c] = depth[p] * ctx[row(p)][c] with p = ((bn*D + d)*fH + h)*fW + w and
+// row = (bn*fH + h)*fW + w; product and sum are separate fp32 roundings (no contraction), like the reference's
+// materialised tensor.
+template <int LSS>
+__global__ __launch_bounds__(256) void bev_sum_kernel(const float* __restrict__ x, const float* __restrict__ depth,
+                                                      int C, int Dd, int fHW, const int* __restrict__ count,
+                                                      const int* __restrict__ start, const int* __restrict__ list,
+                                                      int* __restrict__ sorted, int ncell, int nz,
+                                                      float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c0 >= ncell) return;
+    const int len = count[c0], base = start[c0];
+    // ascending point order by rank counting: point indices are distinct, so ranks are a permutation
+    for (int e = lane; e < len; e += 64) {
+        const int v = list[base + e];
+        int rank = 0;
+        for (int j = 0; j < len; ++j) rank += list[base + j] < v ? 1 : 0;
+        // L2-scope store / loads below: neighbouring cells share cache lines of this array and a CU's vector L1 is
+        // not refreshed by stores (MI355X_MICROARCH.md, inter-workgroup visibility)
+        __hip_atomic_store(&sorted[base + rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // out[(b, ix, iy), iz*C + c]: cell id = ((b*nx0 + ix)*nx1 + iy)*nz + iz, so the address is cell * C + c
+    float* o = out + (int64_t)c0 * C;
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.f;
+        for (int i = 0; i < len; ++i) {
+            const int p = __hip_atomic_load(&sorted[base + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float v;
+            if (LSS) {
+                const int bn = p / (Dd * fHW), pix = p % fHW;
+                v = depth[p] * x[((int64_t)bn * fHW + pix) * C + c];
+            } else {
+                v = x[(int64_t)p * C + c];
+            }
+            acc += v;
+        }
+        o[c] = acc;
+    }
+    (void)nz;
+}
+
+extern "C" int64_t al3d_bev_pool_workspace_bytes(int64_t n_points, int64_t n_cells)
+{
+    const int64_t p = n_points > 0 ? n_points : 1, c = n_cells > 0 ? n_cells : 1;
+    return 3 * al3d_align(p * 4, 256) + 3 * al3d_align((c + 1) * 4, 256) + al3d_scan_workspace_bytes(c + 1);
+}
+
+static int bev_pool_run(const float* x, const float* depth, int lss, int Dd, int fHW, const float* geom, int64_t P,
+                        int C, int B, const float* lo, const float* dx, const int* nx, float* out, void* workspace,
+                        hipStream_t s, const char* name)
+{
+    AL3D_REQUIRE(P >= 0 && P < (1LL << 31) && C >= 1 && B >= 1 && lo && dx && nx, "%s: bad arguments", name);
+    AL3D_REQUIRE(nx[0] >= 1 && nx[1] >= 1 && nx[2] >= 1 && P % B == 0, "%s: bad grid / points not divisible by B", name);
+    const int64_t ncell64 = (int64_t)B * nx[0] * nx[1] * nx[2];
+    AL3D_REQUIRE(ncell64 < (1LL << 31) && ncell64 * C < (1LL << 40), "%s: grid too large", name);
+    AL3D_REQUIRE(out && workspace, "%s: null pointer", name);
+    const int ncell = (int)ncell64;
+    if (P == 0) {
+        if (hipMemsetAsync(out, 0, (size_t)ncell64 * C * 4, s) != hipSuccess) return al3d_fail(AL3D_ELAUNCH, "%s: memset failed", name);
+        return AL3D_OK;
+    }
+    AL3D_REQUIRE(x && geom && (!lss || depth), "%s: null pointer", name);
+    unsigned char* w = (unsigned char*)workspace;
+    const int64_t pb = al3d_align(P * 4, 256), cb = al3d_align(((int64_t)ncell + 1) * 4, 256);
+    int* cell = (int*)w;
+    int* list = (int*)(w + pb);
+    int* sorted = (int*)(w + 2 * pb);
+    int* count = (int*)(w + 3 * pb);
+    int* start = (int*)(w + 3 * pb + cb);
+    int* fill = (int*)(w + 3 * pb + 2 * cb);
+    void* scan_ws = w + 3 * pb + 3 * cb;
+    if (hipMemsetAsync(count, 0, (size_t)cb, s) != hipSuccess || hipMemsetAsync(fill, 0, (size_t)cb, s) != hipSuccess)
+        return al3d_fail(AL3D_ELAUNCH, "%s: memset failed", name);
+    BevGrid g;
+    for (int k = 0; k < 3; ++k) { g.lo[k] = lo[k]; g.dx[k] = dx[k]; g.nx[k] = nx[k]; }
+    g.B = B; g.per_batch = P / B;
+    const unsigned pblocks = (unsigned)al3d_cdiv(P, 256);
+    hipLaunchKernelGGL(bev_cell_kernel, dim3(pblocks), dim3(256), 0, s, geom, P, g, cell, count);
+    int rc = al3d_exclusive_scan_i32(count, start, (int64_t)ncell + 1, scan_ws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bev_scatter_kernel, dim3(pblocks), dim3(256), 0, s, cell, P, start, fill, list);
+    const unsigned cblocks = (unsigned)al3d_cdiv(ncell, 4);
+    if (lss)
+        hipLaunchKernelGGL(bev_sum_kernel<1>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, count, start, list,
+                           sorted, ncell, nx[2], out);
+    else
+        hipLaunchKernelGGL(bev_sum_kernel<0>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, count, start, list,
+                           sorted, ncell, nx[2], out);
+    AL3D_CHECK_LAUNCH(name);
+    return AL3D_OK;
+}
+
+extern "C" int al3d_bev_pool_f32(const float* x, const float* geom, int64_t n_points, int C, int B, const float* lo,
+                                 const float* dx, const int* nx, float* out, void* workspace, void* stream)
+{
+    return bev_pool_run(x, nullptr, 0, 1, 1, geom, n_points, C, B, lo, dx, nx, out, workspace, (hipStream_t)stream,
+                        "al3d_bev_pool_f32");
+}
+
+extern "C" int al3d_bev_pool_lss_f32(const float* depth, const float* ctx, const float* geom, int BN, int D, int fH,
+                                     int fW, int C, int B, const float* lo, const float* dx, const int* nx, float* out,
+                                     void* workspace, void* stream)
+{
+    AL3D_REQUIRE(BN >= 1 && D >= 1 && fH >= 1 && fW >= 1 && B >= 1 && BN % B == 0, "al3d_bev_pool_lss_f32: bad shape");
+    const int64_t P = (int64_t)BN * D * fH * fW;
+    return bev_pool_run(ctx, depth, 1, D, fH * fW, geom, P, C, B, lo, dx, nx, out, workspace, (hipStream_t)stream,
+                        "al3d_bev_pool_lss_f32");
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Frustum geometry (vtransforms/base.py:79-122): for camera bn and frustum point f = (u, v, d):
+//   q = inv(post_rot) (f - post_trans);  q = (q.x*q.z, q.y*q.z, q.z);  g = combine q + cam_trans
+//   [g = extra_rot g] [g += extra_trans]       with combine = camera2lidar_rot inv(intrins).
+// The 3x3 inverses / products are per-camera host algebra; this kernel does the 2 M points per sample that take
+// torch's batched matmul 53 ms.  Dot products are evaluated as ((a0*x + a1*y) + a2*z), no contraction.
+struct LssCam { float ipr[9], pt[3], comb[9], ct[3], er[9], et[3]; int has_er, has_et; };
+
+__global__ void lss_geometry_kernel(const float* __restrict__ frustum, const LssCam* __restrict__ cams, int64_t per_cam,
+                                    int64_t total, float* __restrict__ geom)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int bn = (int)(p / per_cam);
+    const int64_t f = p % per_cam;
+    const LssCam& c = cams[bn];
+    const float x = frustum[3 * f] - c.pt[0], y = frustum[3 * f + 1] - c.pt[1], z = frustum[3 * f + 2] - c.pt[2];
+    float qx = (c.ipr[0] * x + c.ipr[1] * y) + c.ipr[2] * z;
+    float qy = (c.ipr[3] * x + c.ipr[4] * y) + c.ipr[5] * z;
+    const float qz = (c.ipr[6] * x + c.ipr[7] * y) + c.ipr[8] * z;
+    qx = qx * qz; qy = qy * qz;
+    float gx = ((c.comb[0] * qx + c.comb[1] * qy) + c.comb[2] * qz) + c.ct[0];
+    float gy = ((c.comb[3] * qx + c.comb[4] * qy) + c.comb[5] * qz) + c.ct[1];
+    float gz = ((c.comb[6] * qx + c.comb[7] * qy) + c.comb[8] * qz) + c.ct[2];
+    if (c.has_er) {
+        const float rx = (c.er[0] * gx + c.er[1] * gy) + c.er[2] * gz;
+        const float ry = (c.er[3] * gx + c.er[4] * gy) + c.er[5] * gz;
+        const float rz = (c.er[6] * gx + c.er[7] * gy) + c.er[8] * gz;
+        gx = rx; gy = ry; gz = rz;
+    }
+    if (c.has_et) { gx += c.et[0]; gy += c.et[1]; gz += c.et[2]; }
+    geom[3 * p] = gx; geom[3 * p + 1] = gy; geom[3 * p + 2] = gz;
+}
+
+// cams: [BN][44] float32 rows = inv(post_rot)[9] | post_trans[3] | combine[9] | cam_trans[3] | extra_rot[9] |
+// extra_trans[3] | has_extra_rot | has_extra_trans (the two flags as 0.0 / 1.0), device memory
+__global__ void lss_unpack_cams_kernel(const float* __restrict__ rows, int BN, LssCam* __restrict__ cams)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BN) return;
+    const float* r = rows + 44 * i;
+    LssCam c;
+    for (int k = 0; k < 9; ++k) { c.ipr[k] = r[k]; c.comb[k] = r[12 + k]; c.er[k] = r[24 + k]; }
+    for (int k = 0; k < 3; ++k) { c.pt[k] = r[9 + k]; c.ct[k] = r[21 + k]; c.et[k] = r[33 + k]; }
+    c.has_er = r[36] != 0.f; c.has_et = r[37] != 0.f;
+    cams[i] = c;
+}
+
+extern "C" int64_t al3d_lss_geometry_workspace_bytes(int BN) { return al3d_align((int64_t)(BN > 0 ? BN : 1) * sizeof(LssCam), 256); }
+
+extern "C" int al3d_lss_geometry_f32(const float* frustum, int64_t points_per_camera, const float* cam_rows, int BN,
+                                     float* geom, void* workspace, void* stream)
+{
+    AL3D_REQUIRE(frustum && cam_rows && geom && workspace && BN >= 1 && points_per_camera >= 1,
+                 "al3d_lss_geometry_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    LssCam* cams = (LssCam*)workspace;
+    hipLaunchKernelGGL(lss_unpack_cams_kernel, dim3((unsigned)al3d_cdiv(BN, 64)), dim3(64), 0, s, cam_rows, BN, cams);
+    const int64_t total = points_per_camera * BN;
+    hipLaunchKernelGGL(lss_geometry_kernel, dim3((unsigned)al3d_cdiv(total, 256)), dim3(256), 0, s, frustum, cams,
+                       points_per_camera, total, geom);
+    AL3D_CHECK_LAUNCH("lss_geometry_kernel");
+    return AL3D_OK;
+}

@@ -109,6 +109,12 @@ SIGNATURES = {
     "al3d_conv2d_nhwc_f16x3_bstream": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p]),
     "al3d_deconv2x2_nhwc_f16x3_bstream": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_stream_create_cu_mask": (c_int, [c_int, c_int, c_p]),
+    "al3d_lss_geometry_workspace_bytes": (c_i64, [c_int]),
+    "al3d_lss_geometry_f32": (c_int, [c_p, c_i64, c_p, c_int, c_p, c_p, c_p]),
+    "al3d_bev_pool_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "al3d_bev_pool_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "al3d_bev_pool_lss_f32": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p,
+                                      c_p, c_p]),
     "al3d_reader_create": (c_int, [c_int, c_p]),
     "al3d_reader_destroy": (None, [c_p]),
     "al3d_reader_plan": (c_i64, [c_p, c_int, c_p]),

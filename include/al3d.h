@@ -399,6 +399,30 @@ int64_t al3d_gap_workspace_bytes(int B, int H, int C);
 int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out, void* workspace,
                       void* stream);
 
+/* ---------------------------------------------------------------- camera branch: BEV pooling (f4)
+ * bevfusion/mmdet3d/models/vtransforms/base.py:127-163 (`bev_pool`: cell = ((geom - (bx - dx/2)) / dx).long(),
+ * points outside the grid dropped) + ops/bev_pool/bev_pool.py:82-97 + src/bev_pool_cuda.cu:21-44 (sum of the points
+ * of a cell).  geom [P,3] f32 lidar-frame positions (points of sample b: [b*P/B, (b+1)*P/B)); lo = bx - dx/2 and dx
+ * as float32[3], nx int[3]; out [B, nx0, nx1, nx2*C] f32 channels-last with channel = iz*C + c (the reference's
+ * [B,C,D,H,W] -> cat(unbind(2),1)), every cell written (empty cells 0).  Summation order: ascending point index
+ * (deterministic; the reference's argsort order is implementation-defined).
+ * _lss: the Lift-Splat outer product fused in (depth_lss.py:92-97): x[p] = depth[p] * ctx[pixel(p)] with
+ * depth [BN,D,fH,fW], ctx [BN,fH,fW,C] channels-last, p = ((bn*D + d)*fH + h)*fW + w; the [BN,D,fH,fW,C] tensor
+ * is never materialised. */
+/* Frustum geometry of the Lift-Splat transform (vtransforms/base.py:79-122) for BN cameras: frustum [D*fH*fW,3]
+ * (u, v, depth), cam_rows [BN,44] f32 on device = inv(post_rot)[9] | post_trans[3] | camera2lidar_rot inv(intrins)[9]
+ * | camera2lidar_trans[3] | extra_rot[9] | extra_trans[3] | has_extra_rot | has_extra_trans | pad[6];
+ * geom [BN*D*fH*fW,3] lidar-frame positions. */
+int64_t al3d_lss_geometry_workspace_bytes(int BN);
+int al3d_lss_geometry_f32(const float* frustum, int64_t points_per_camera, const float* cam_rows, int BN, float* geom,
+                          void* workspace, void* stream);
+int64_t al3d_bev_pool_workspace_bytes(int64_t n_points, int64_t n_cells);
+int al3d_bev_pool_f32(const float* x, const float* geom, int64_t n_points, int C, int B, const float* lo,
+                      const float* dx, const int* nx, float* out, void* workspace, void* stream);
+int al3d_bev_pool_lss_f32(const float* depth, const float* ctx, const float* geom, int BN, int D, int fH, int fW,
+                          int C, int B, const float* lo, const float* dx, const int* nx, float* out,
+                          void* workspace, void* stream);
+
 /* ---------------------------------------------------------------- streaming file loader (a1 / f2)
  * Host reader pool (csrc/reader.cpp, pthreads): replaces the reference's DataLoader worker processes
  * (det3d/datasets/loader/build_loader.py:23-59) for the part that touches files -- read_file / read_sweep's

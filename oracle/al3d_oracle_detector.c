@@ -296,3 +296,40 @@ int64_t al3d_oracle_merge_sweeps(const float* raw, const int64_t* file_off, int 
     }
     return n;
 }
+
+/* ---------------------------------------------------------------- f4: BEV pooling (camera branch)
+ * CPU restatement of BaseTransform.bev_pool (bevfusion/mmdet3d/models/vtransforms/base.py:127-163) around
+ * bev_pool() / bev_pool_kernel (bevfusion/mmdet3d/ops/bev_pool/bev_pool.py:82-97, src/bev_pool_cuda.cu:21-44):
+ * cell = trunc((geom - lo) / dx) per axis in float32 (lo = bx - dx/2), points outside [0, nx) dropped, the
+ * C-vectors of a cell summed in float32.  The reference sums in the order its (unstable) argsort leaves the
+ * points of a cell; this restatement -- like the device kernel -- uses ascending point index.
+ * depth != NULL: the Lift-Splat outer product x[p] = depth[p] * ctx[pixel(p)] (depth_lss.py:92-97) with
+ * x = ctx [BN,fH*fW,C], p = (bn*D + d)*fHW + pix; product rounded to float32 before the sum, as the reference's
+ * materialised tensor.  out [B, nx0, nx1, nx2*C] must be zero-filled by the caller. */
+void al3d_oracle_bev_pool(const float* x, const float* depth, int D, int fHW, const float* geom, int64_t P, int C,
+                          int B, const float* lo, const float* dx, const int* nx, float* out)
+{
+    const int64_t per = P / B;
+    for (int64_t p = 0; p < P; ++p) {
+        int c3[3], ok = 1;
+        for (int k = 0; k < 3; ++k) {
+            const float t = (geom[3 * p + k] - lo[k]) / dx[k];
+            if (!(t > -1.0f && t < (float)nx[k])) { ok = 0; break; }
+            c3[k] = (int)t;
+        }
+        if (!ok) continue;
+        const int64_t b = p / per;
+        float* o = out + ((((b * nx[0] + c3[0]) * nx[1] + c3[1]) * nx[2]) + c3[2]) * (int64_t)C;
+        if (depth) {
+            const int64_t bn = p / ((int64_t)D * fHW), pix = p % fHW;
+            const float* row = x + (bn * fHW + pix) * C;
+            for (int c = 0; c < C; ++c) {
+                const float v = depth[p] * row[c];
+                o[c] += v;
+            }
+        } else {
+            const float* row = x + p * C;
+            for (int c = 0; c < C; ++c) o[c] += row[c];
+        }
+    }
+}

@@ -300,3 +300,17 @@ def merge_sweeps(files, xforms, time_lags, min_distance=1.0):
     fn.restype = c_i64
     n = fn(_p(raw), _p(off), c_int(len(files)), _p(xf), _p(has), _p(tl), ctypes.c_float(min_distance), _p(out))
     return out[:n].copy()
+
+
+def bev_pool(x, geom, B, lo, dx, nx, depth=None, D=1, fHW=1):
+    """base.py:127-163 + bev_pool_cuda.cu:21-44 restated (ascending point order).  x [P,C] (or ctx [BN*fHW,C] with
+    depth [P]); geom [P,3]; -> [B, nx0, nx1, nx2*C] float32."""
+    x = _c(x, np.float32)
+    geom = _c(geom, np.float32)
+    depth = _c(depth, np.float32)
+    P, C = geom.shape[0], x.shape[1]
+    lo, dx, nx = _c(lo, np.float32), _c(dx, np.float32), _c(nx, np.int32)
+    out = np.zeros((B, int(nx[0]), int(nx[1]), int(nx[2]) * C), dtype=np.float32)
+    lib().al3d_oracle_bev_pool(_p(x), _p(depth), c_int(D), c_int(fHW), _p(geom), c_i64(P), c_int(C), c_int(B),
+                               _p(lo), _p(dx), _p(nx), _p(out))
+    return out
