@@ -134,13 +134,18 @@ class ConvTimer:
         else:
             out.update(kernel="conv2d_mfma_kernel", peak=MFMA_F32_PEAK_TFLOPS,
                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc):      # PMC passes are separate runs (rocprofv3 --pmc); see DESIGN.md
+        for pmc in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            pmc = os.path.join(ROOT, "profiles", pmc)
+            if not os.path.exists(pmc):      # PMC passes are separate runs (rocprofv3 --pmc); see DESIGN.md
+                continue
             try:
                 rec = json.load(open(pmc)).get(out["kernel"])
                 if rec:
                     out["traffic"] = round(rec["hbm_mb_corrected"] * 1e6)
-                    out["traffic_note"] = rec.get("note", "")
+                    out["traffic_detail"] = {k: rec[k] for k in ("fetch_mb_raw", "fetch_mb_x2", "write_mb", "launches",
+                                                                 "correction") if k in rec}
+                    out["traffic_note"] = rec.get("note", "") + " (" + os.path.basename(pmc) + ")"
+                    break
             except Exception:
                 pass
         return out
@@ -189,14 +194,16 @@ class SparseTimer:
         with torch.no_grad():
             book = bb.rulebook_for(example["coordinates"], len(example["num_voxels"]), example["shape"][0])
         layers, seen = [], {}
+        n_prev = int(example["coordinates"].shape[0])
         for step, b in zip(bb._plan, book["steps"]):
             if step["kind"] == "stage_end":
                 continue
             m = step["mod"]
+            n_in, n_prev = (b["n"] if step["kind"] == "subm" else n_prev), b["n"]
             key = b["nbr"].data_ptr()
             if key not in seen:
                 seen[key] = int((b["nbr"][:, :max(b["n"], 1)] >= 0).sum().item()) if b["n"] else 0
-            layers.append(dict(cin=m.in_channels, cout=m.out_channels, K=b["K"], n_out=b["n"], pairs=seen[key],
+            layers.append(dict(cin=m.in_channels, cout=m.out_channels, K=b["K"], n_out=b["n"], n_in=n_in, pairs=seen[key],
                                kind=step["kind"], residual=bool(step.get("residual"))))
         self.layers = layers
         self.batch_frames = len(example["num_voxels"])
@@ -210,7 +217,7 @@ class SparseTimer:
         for i, e0, e1 in self.events:
             ms[i % nl] += e0.elapsed_time(e1)
             cnt[i % nl] += 1
-        rows, tot_flop, tot_bytes, tot_ms = [], 0.0, 0.0, 0.0
+        rows, tot_flop, tot_bytes, tot_ms, tot_unique = [], 0.0, 0.0, 0.0, 0.0
         for L, t, c in zip(self.layers, ms, cnt):
             if c == 0:
                 continue
@@ -218,6 +225,10 @@ class SparseTimer:
             flop = 2.0 * L["pairs"] * L["cin"] * L["cout"]
             byts = L["pairs"] * (L["cin"] + L["cout"]) * 4.0 + L["n_out"] * L["cout"] * 4.0 + \
                 L["K"] * L["cin"] * L["cout"] * 4.0
+            # bytes that must cross HBM once: input rows + output rows (+ residual rows) + weights
+            uniq = (L["n_in"] * L["cin"] + L["n_out"] * L["cout"] * (2 if L["residual"] else 1)) * 4.0 + \
+                L["K"] * L["cin"] * L["cout"] * 4.0
+            tot_unique += uniq
             rows.append(dict(cin=L["cin"], cout=L["cout"], K=L["K"], n_out=L["n_out"], pairs=L["pairs"],
                              valid=round(L["pairs"] / max(1, L["n_out"] * L["K"]), 3), avg_us=round(us, 1),
                              tflops=round(flop / us / 1e6, 1), gbs=round(byts / us / 1e3, 1)))
@@ -236,6 +247,12 @@ class SparseTimer:
                     algorithmic_mb_per_frame=round(tot_bytes / self.batch_frames / 1e6, 2),
                     achieved_tflops=round(tf, 1), mfma_peak_tflops=round(peak, 1), frac_mfma=round(tf / peak, 4),
                     achieved_gbs=round(gbs, 1), hbm_peak_gbs=HBM_PEAK_GBS, frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
+                    bytes_note="achieved_gbs uses SURVEY 8d's per-layer formula, which prices every gathered (row, tap) "
+                               "pair as memory traffic (a gather/GEMM/scatter formulation); here outputs are written once "
+                               "and gathers are served by L2 / LDS-DMA, so it is a gather rate, not HBM traffic -- "
+                               "unique_* counts the bytes that must cross HBM once",
+                    unique_mb_per_frame=round(tot_unique / self.batch_frames / 1e6, 2),
+                    unique_gbs=round(tot_unique / tot_ms / 1e6, 1), frac_hbm_unique=round(tot_unique / tot_ms / 1e6 / HBM_PEAK_GBS, 4),
                     measured="HIP events around each sparse-conv launch of the timed steps (rank 0); pairs from "
                              "the rulebook of one batch (every batch holds the same base frames)",
                     layers=rows)

@@ -171,6 +171,8 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
 # wave kernel) and "tile" (LDS-staged 128-row tile) give the same bits, for A/B
 SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
 GLDS_PAIRS = {(32, 32), (64, 64)}
+if _os.environ.get("AL3D_GLDS_PAIRS"):           # dev override, e.g. "32x32,64x64,128x128"
+    GLDS_PAIRS = {tuple(int(v) for v in t.split("x")) for t in _os.environ["AL3D_GLDS_PAIRS"].split(",")}
 
 
 def sparse_glds(cin=None, cout=None):
