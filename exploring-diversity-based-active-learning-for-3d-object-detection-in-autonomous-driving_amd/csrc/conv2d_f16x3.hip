@@ -61,6 +61,8 @@ struct ConvF3Params {
     int tiles_x, tiles_y;
     int nblocks, ntiles;    // 128-channel column blocks; pixel tiles (tiles_x * tiles_y * B)
     int64_t plane;          // elements per weight plane = Cout * taps * Cin
+    float* gap;             // optional [B][gap_parts][ldc]: per-workgroup channel sums of the stored values (fused GAP)
+    int gap_parts;
 };
 
 // 1-D grid -> (pixel tile, column block).  Blocks with equal blockIdx % 8 share an XCD and its L2,
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_kernel(ConvF3Params p)
         if (n >= p.Cout) continue;
         const float sc = p.scale[n];
         const float sh = p.shift ? p.shift[n] : 0.0f;
+        float gsum = 0.f;                                             // this lane's column: sum of the values it stores
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -236,9 +239,31 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_kernel(ConvF3Params p)
                 int oy = y, ox = x;
                 if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
                 p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;
+                gsum += v;
+            }
+        }
+        if (p.gap) {
+            // fused global average pooling: one partial per (workgroup, wave row) and channel, fixed order
+            // (rows of the lane, then the other half of the fragment), reduced by gap_parts_reduce_kernel
+            gsum += __shfl_xor(gsum, 32);
+            if (fh == 0) {
+                const int part = (((ty_ * p.tiles_x + tx_) * (MODE == 1 ? 4 : 1) + tap0) << 1) + wm;
+                p.gap[((int64_t)b * p.gap_parts + part) * p.ldc + p.coff + n] = gsum;
             }
         }
     }
+}
+
+// out[b][c] = (sum over the parts, ascending) / count
+__global__ __launch_bounds__(64) void gap_parts_reduce_kernel(const float* __restrict__ gap, int parts, int C, float count,
+                                                               float* __restrict__ out)
+{
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+#pragma unroll 16
+    for (int q = 0; q < parts; ++q) s += gap[((int64_t)b * parts + q) * C + c];
+    out[(int64_t)b * C + c] = s / count;
 }
 
 // ------------------------------------------------------------------ 3x3 / stride 1 / pad 1
@@ -852,6 +877,7 @@ extern "C" int al3d_conv2d_nhwc_f16x3_bstream(const float* in, const void* wgt_f
                                               int relu, void* stream)
 {
     ConvF3Params p;
+    p.gap = nullptr; p.gap_parts = 0;
     p.in = in; p.wgt = (const _Float16*)wgt_frag; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.ldc = ldc; p.coff = coff; p.relu = relu;
@@ -875,6 +901,7 @@ extern "C" int al3d_deconv2x2_nhwc_f16x3_bstream(const float* in, const void* wg
                                                  int Cout, int ldc, int coff, int relu, void* stream)
 {
     ConvF3Params p;
+    p.gap = nullptr; p.gap_parts = 0;
     p.in = in; p.wgt = (const _Float16*)wgt_frag; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = 2; p.stride = 2; p.pad = 0; p.ldc = ldc; p.coff = coff; p.relu = relu;
@@ -925,6 +952,7 @@ extern "C" int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_fra
                                             int Cout, int ldc, int coff, int relu, void* stream)
 {
     ConvF3Params p;
+    p.gap = nullptr; p.gap_parts = 0;
     p.in = in; p.wgt = (const _Float16*)wgt_frag; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = 3; p.stride = 1; p.pad = 1; p.ldc = ldc; p.coff = coff; p.relu = relu;
@@ -969,12 +997,30 @@ extern "C" int al3d_split_f16x3(const float* w, int64_t count, int scale_exp, vo
 }
 
 
-extern "C" int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x3, const float* scale,
-                                      const float* shift, float* out, int B, int H, int W, int Cin,
-                                      int Cout, int ksize, int stride, int pad, int ldc, int coff,
-                                      int relu, void* stream)
+// workgroup partials per image of the fused GAP: pixel tiles of the generic kernel x 2 wave rows (x 4 deconv taps)
+extern "C" int al3d_gap_parts_count(int OH, int OW, int deconv)
+{
+    if (deconv) return (int)(al3d_cdiv(OW / 2, F3_TW) * al3d_cdiv(OH / 2, F3_TH)) * 8;
+    return (int)(al3d_cdiv(OW, F3_TW) * al3d_cdiv(OH, F3_TH)) * 2;
+}
+
+extern "C" int al3d_gap_reduce_parts_f32(const float* gap_part, int B, int parts, int C, int64_t count, float* out,
+                                         void* stream)
+{
+    AL3D_REQUIRE(gap_part && out && B >= 1 && parts >= 1 && C >= 1 && count >= 1, "al3d_gap_reduce_parts_f32: bad arguments");
+    hipLaunchKernelGGL(gap_parts_reduce_kernel, dim3((unsigned)al3d_cdiv(C, 64), (unsigned)B), dim3(64), 0,
+                       (hipStream_t)stream, gap_part, parts, C, (float)count, out);
+    AL3D_CHECK_LAUNCH("gap_parts_reduce_kernel");
+    return AL3D_OK;
+}
+
+static int conv2d_f16x3_impl(const float* in, const void* wgt_f16x3, const float* scale,
+                             const float* shift, float* out, int B, int H, int W, int Cin,
+                             int Cout, int ksize, int stride, int pad, int ldc, int coff,
+                             int relu, float* gap_part, int gap_parts, void* stream)
 {
     ConvF3Params p;
+    p.gap = gap_part; p.gap_parts = gap_parts;
     p.in = in; p.wgt = (const _Float16*)wgt_f16x3; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.ldc = ldc; p.coff = coff; p.relu = relu;
@@ -985,7 +1031,9 @@ extern "C" int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x3, co
     p.plane = (int64_t)Cout * ksize * ksize * Cin;
     int rc = convf3_check(p, "al3d_conv2d_nhwc_f16x3");
     if (rc) return rc;
-    if (ksize == 3 && stride == 1 && pad == 1 && Cin % (2 * F3_BK) == 0) {     // halo-staged fast path (chunk pairs)
+    AL3D_REQUIRE(!gap_part || gap_parts >= al3d_gap_parts_count(p.OH, p.OW, 0),
+                 "al3d_conv2d_nhwc_f16x3_gap: gap_parts must be at least al3d_gap_parts_count(OH, OW, 0)");
+    if (!gap_part && ksize == 3 && stride == 1 && pad == 1 && Cin % (2 * F3_BK) == 0) {     // halo-staged fast path (chunk pairs)
         p.tiles_x = (int)al3d_cdiv(p.OW, G3_TW);
         p.tiles_y = (int)al3d_cdiv(p.OH, G3_TH);
         p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
@@ -1001,11 +1049,31 @@ extern "C" int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x3, co
     return AL3D_OK;
 }
 
-extern "C" int al3d_deconv2x2_nhwc_f16x3(const float* in, const void* wgt_f16x3, const float* scale,
-                                         const float* shift, float* out, int B, int H, int W, int Cin,
-                                         int Cout, int ldc, int coff, int relu, void* stream)
+extern "C" int al3d_conv2d_nhwc_f16x3(const float* in, const void* wgt_f16x3, const float* scale,
+                                      const float* shift, float* out, int B, int H, int W, int Cin,
+                                      int Cout, int ksize, int stride, int pad, int ldc, int coff,
+                                      int relu, void* stream)
+{
+    return conv2d_f16x3_impl(in, wgt_f16x3, scale, shift, out, B, H, W, Cin, Cout, ksize, stride, pad, ldc, coff, relu,
+                             nullptr, 0, stream);
+}
+
+extern "C" int al3d_conv2d_nhwc_f16x3_gap(const float* in, const void* wgt_f16x3, const float* scale,
+                                          const float* shift, float* out, int B, int H, int W, int Cin,
+                                          int Cout, int ksize, int stride, int pad, int ldc, int coff,
+                                          int relu, float* gap_part, int gap_parts, void* stream)
+{
+    AL3D_REQUIRE(gap_part, "al3d_conv2d_nhwc_f16x3_gap: null gap_part");
+    return conv2d_f16x3_impl(in, wgt_f16x3, scale, shift, out, B, H, W, Cin, Cout, ksize, stride, pad, ldc, coff, relu,
+                             gap_part, gap_parts, stream);
+}
+
+static int deconv2x2_f16x3_impl(const float* in, const void* wgt_f16x3, const float* scale,
+                                const float* shift, float* out, int B, int H, int W, int Cin,
+                                int Cout, int ldc, int coff, int relu, float* gap_part, int gap_parts, void* stream)
 {
     ConvF3Params p;
+    p.gap = gap_part; p.gap_parts = gap_parts;
     p.in = in; p.wgt = (const _Float16*)wgt_f16x3; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = 2; p.stride = 2; p.pad = 0; p.ldc = ldc; p.coff = coff; p.relu = relu;
@@ -1016,7 +1084,26 @@ extern "C" int al3d_deconv2x2_nhwc_f16x3(const float* in, const void* wgt_f16x3,
     p.tiles_x = (int)al3d_cdiv(W, F3_TW);
     p.tiles_y = (int)al3d_cdiv(H, F3_TH);
     p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+    AL3D_REQUIRE(!gap_part || gap_parts >= al3d_gap_parts_count(p.OH, p.OW, 1),
+                 "al3d_deconv2x2_nhwc_f16x3_gap: gap_parts must be at least al3d_gap_parts_count(2H, 2W, 1)");
     hipLaunchKernelGGL(conv2d_f16x3_kernel<1>, dim3(f3_grid(p), 1, 4), dim3(256), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("conv2d_f16x3_kernel<deconv>");
     return AL3D_OK;
+}
+
+extern "C" int al3d_deconv2x2_nhwc_f16x3(const float* in, const void* wgt_f16x3, const float* scale,
+                                         const float* shift, float* out, int B, int H, int W, int Cin,
+                                         int Cout, int ldc, int coff, int relu, void* stream)
+{
+    return deconv2x2_f16x3_impl(in, wgt_f16x3, scale, shift, out, B, H, W, Cin, Cout, ldc, coff, relu, nullptr, 0, stream);
+}
+
+extern "C" int al3d_deconv2x2_nhwc_f16x3_gap(const float* in, const void* wgt_f16x3, const float* scale,
+                                             const float* shift, float* out, int B, int H, int W, int Cin,
+                                             int Cout, int ldc, int coff, int relu, float* gap_part, int gap_parts,
+                                             void* stream)
+{
+    AL3D_REQUIRE(gap_part, "al3d_deconv2x2_nhwc_f16x3_gap: null gap_part");
+    return deconv2x2_f16x3_impl(in, wgt_f16x3, scale, shift, out, B, H, W, Cin, Cout, ldc, coff, relu, gap_part, gap_parts,
+                                stream);
 }

@@ -91,18 +91,18 @@ __global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg
                                   const int* __restrict__ first, const int* __restrict__ pframe,
                                   const int* __restrict__ pcell, const int* __restrict__ lscan,
                                   const int* __restrict__ row_base, int* __restrict__ prow,
-                                  int* __restrict__ coords, int* __restrict__ cnt)
+                                  int* __restrict__ ppos, int* __restrict__ coords, int* __restrict__ cnt)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= off[B]) return;
     const int cell = pcell[i], b = pframe[i];
-    int row = -1;
+    int row = -1, pos = 0;
     if (cell >= 0) {
         const int lead = first[(int64_t)b * cells + cell];
         const int vid = lscan[off[b] + lead] - lscan[off[b]];
         if (vid < c.max_voxels) {
             row = row_base[b] + vid;
-            atomicAdd(&cnt[row], 1);
+            pos = atomicAdd(&cnt[row], 1);          // arrival position inside the voxel: the bucket slot (pass 5)
             if (lead == (int)(i - off[b])) {
                 const int x = cell % c.gx, y = (cell / c.gx) % c.gy, z = cell / (c.gx * c.gy);
                 coords[4 * row + 0] = b; coords[4 * row + 1] = z;
@@ -111,18 +111,19 @@ __global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg
         }
     }
     prow[i] = row;
+    ppos[i] = pos;
 }
 
-// pass 5: bucket the point indices per voxel (arrival order is irrelevant: pass 6 sorts)
-__global__ void vox_bucket_kernel(int64_t npts, const int* __restrict__ prow, const int* __restrict__ boff,
-                                  int* __restrict__ cursor, int* __restrict__ bucket)
+// pass 5: bucket the point indices per voxel at the arrival positions pass 4's counter handed out (arrival
+// order is irrelevant: pass 6 sorts) -- no second round of atomics
+__global__ void vox_bucket_kernel(int64_t npts, const int* __restrict__ prow, const int* __restrict__ ppos,
+                                  const int* __restrict__ boff, int* __restrict__ bucket)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npts) return;
     const int row = prow[i];
     if (row < 0) return;
-    const int pos = atomicAdd(&cursor[row], 1);
-    bucket[boff[row] + pos] = (int)i;
+    bucket[boff[row] + ppos[i]] = (int)i;
 }
 
 // pass 6: one thread per voxel: its max_points smallest point indices, ascending;
@@ -248,9 +249,9 @@ extern "C" int al3d_voxelize_grid_init(void* grid, int B, int gx, int gy, int gz
 extern "C" int64_t al3d_voxelize_workspace_bytes(int64_t npts, int B, int max_voxels)
 {
     const int64_t rows = (int64_t)B * max_voxels;
-    // pframe, pcell, flag, lscan, prow, bucket (npts each) + cnt, boff, cursor (rows+1 each)
+    // pframe, pcell, flag, lscan, prow, bucket, ppos (npts each) + cnt, boff (rows+1 each)
     // + scan scratch
-    return al3d_align(npts * 4, 256) * 6 + al3d_align((rows + 1) * 4, 256) * 3 +
+    return al3d_align(npts * 4, 256) * 7 + al3d_align((rows + 1) * 4, 256) * 2 +
            al3d_scan_workspace_bytes(npts > rows ? npts : rows) + 1024;
 }
 
@@ -286,12 +287,11 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
     int* bucket = (int*)take(npts * 4);
     int* cnt = (int*)take((rows + 1) * 4);
     int* boff = (int*)take((rows + 1) * 4);
-    int* cursor = (int*)take((rows + 1) * 4);
+    int* ppos = (int*)take(npts * 4);
     void* scan_ws = (void*)w;
     int* first = (int*)first_grid;
     const unsigned pb = (unsigned)al3d_cdiv(npts > 0 ? npts : 1, 256);
-    if (hipMemsetAsync(cnt, 0, (rows + 1) * 4, s) != hipSuccess ||
-        hipMemsetAsync(cursor, 0, (rows + 1) * 4, s) != hipSuccess)
+    if (hipMemsetAsync(cnt, 0, (rows + 1) * 4, s) != hipSuccess)
         return al3d_fail(AL3D_ELAUNCH, "al3d_voxelize_mean_f32: memset failed");
     hipLaunchKernelGGL(vox_first_kernel, dim3(pb), dim3(256), 0, s, points, point_offsets, B, c, cells,
                        first, pframe, pcell);
@@ -302,10 +302,10 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
     hipLaunchKernelGGL(vox_base_kernel, dim3(1), dim3(64), 0, s, point_offsets, B, lscan, flag, max_voxels,
                        num_voxels, row_base);
     hipLaunchKernelGGL(vox_assign_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, c, cells, first,
-                       pframe, pcell, lscan, row_base, prow, coords, cnt);
+                       pframe, pcell, lscan, row_base, prow, ppos, coords, cnt);
     rc = al3d_exclusive_scan_i32(cnt, boff, rows + 1, scan_ws, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_bucket_kernel, dim3(pb), dim3(256), 0, s, npts, prow, boff, cursor, bucket);
+    hipLaunchKernelGGL(vox_bucket_kernel, dim3(pb), dim3(256), 0, s, npts, prow, ppos, boff, bucket);
     if (c.max_points == 10 && c.nfeat == 5)      // the nuScenes configuration: register-resident selection
         hipLaunchKernelGGL((vox_gather_fixed_kernel<10, 5>), dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s,
                            points, (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);

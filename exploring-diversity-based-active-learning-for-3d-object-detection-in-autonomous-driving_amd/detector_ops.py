@@ -186,7 +186,14 @@ def sparse_glds(cin=None, cout=None):
 _DENSE_KIND = {torch.float32: "f32", torch.bfloat16: "bf16x6", torch.float16: "f16x3"}
 
 
-def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, coff=0):
+def gap_fusable(w_packed):
+    """The fused-GAP epilogue exists in the generic f16x3 kernel (plain f16 planes: the deblock launches)."""
+    return isinstance(w_packed, torch.Tensor) and w_packed.dtype == torch.float16
+
+
+def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, coff=0, gap=None):
+    """gap: optional [B, parts, ldc] f32 buffer (parts = al3d_gap_parts_count): the launch also writes its
+    workgroups' channel sums there (f16x3 planes only, see gap_fusable)."""
     x = _dev(x, torch.float32, "x")
     # the weight format selects the arithmetic: bf16 [3,Cout,taps,Cin] (split_bf16x3),
     # f16 [2,Cout,taps,Cin] (split_f16x3, scale required) or plain f32 [Cout,taps,Cin]
@@ -221,12 +228,19 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
     if out is None:
         out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, OH, OW) and out.is_contiguous()
+    if gap is not None:
+        if not gap_fusable(w_packed):
+            raise lib.Al3dError("conv2d_nhwc: the fused GAP needs plain f16x3 planes")
+        lib.call("al3d_conv2d_nhwc_f16x3_gap", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
+                 B, H, W, Cin, Cout, ksize, stride, pad, out.shape[3], coff, 1 if relu else 0, _ptr(gap), gap.shape[1],
+                 _stream())
+        return out
     lib.call("al3d_conv2d_nhwc_" + kind, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
              B, H, W, Cin, Cout, ksize, stride, pad, out.shape[3], coff, 1 if relu else 0, _stream())
     return out
 
 
-def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0):
+def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0, gap=None):
     x = _dev(x, torch.float32, "x")
     B, H, W, Cin = x.shape
     kind = _DENSE_KIND[w_packed.dtype]
@@ -246,9 +260,33 @@ def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0):
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, 2 * H, 2 * W) and out.is_contiguous()
+    if gap is not None:
+        if not gap_fusable(w_packed):
+            raise lib.Al3dError("deconv2x2_nhwc: the fused GAP needs plain f16x3 planes")
+        lib.call("al3d_deconv2x2_nhwc_f16x3_gap", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
+                 B, H, W, Cin, Cout, out.shape[3], coff, 1 if relu else 0, _ptr(gap), gap.shape[1], _stream())
+        return out
     lib.call("al3d_deconv2x2_nhwc_" + kind, _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out),
              B, H, W, Cin, Cout, out.shape[3], coff, 1 if relu else 0, _stream())
     return out
+
+
+def gap_parts(OH, OW, deconv):
+    return int(lib.load().al3d_gap_parts_count(int(OH), int(OW), 1 if deconv else 0))
+
+
+def gap_reduce_parts(gap, count):
+    """[B, parts, C] workgroup partial sums -> [B, C] means (sum in ascending part order / count)."""
+    gap = _dev(gap, torch.float32, "gap")
+    B, parts, C = gap.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=gap.device)
+    lib.call("al3d_gap_reduce_parts_f32", _ptr(gap), B, parts, C, int(count), _ptr(out), _stream())
+    return out
+
+
+# AL3D_GAP=fused (default): the neck's deblock launches emit the embedding's partial sums; "kernel": the stand-alone
+# two-stage GAP kernel re-reads the map (round-1 path; W-then-H summation order)
+GAP = _os.environ.get("AL3D_GAP", "fused")
 
 
 def gap_nhwc(x):

@@ -17,8 +17,9 @@ from .registry import DETECTORS
 class NHWCFeature:
     """A ``[B,C,H,W]``-shaped view of an NHWC buffer for the selectors' embedding tap."""
 
-    def __init__(self, nhwc):
+    def __init__(self, nhwc, embedding=None):
         self.nhwc = nhwc
+        self._emb = embedding           # [B,C] global average the neck already produced (fused GAP), or None
         B, H, W, C = nhwc.shape
         self.shape = torch.Size((B, C, H, W))
         self.device = nhwc.device
@@ -27,8 +28,10 @@ class NHWCFeature:
     def mean(self, dim=-1):
         if not self._w_reduced:
             r = NHWCFeature.__new__(NHWCFeature)
-            r.nhwc, r.shape, r.device, r._w_reduced = self.nhwc, self.shape[:3], self.device, True
+            r.nhwc, r.shape, r.device, r._w_reduced, r._emb = self.nhwc, self.shape[:3], self.device, True, self._emb
             return r
+        if self._emb is not None:
+            return self._emb                   # emitted by the neck's deblock launches (al3d_*_gap)
         return D.gap_nhwc(self.nhwc)          # mean over W, then over H, in one kernel
 
     def nchw(self):
@@ -64,7 +67,7 @@ class FPNVoxelNet(SingleStageDetector):
         x, middle = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
         if self.with_neck:
             x = self.neck(x)
-            middle.append(NHWCFeature(x))
+            middle.append(NHWCFeature(x, getattr(self.neck, "embedding", None)))
         return x, middle
 
     # The forward pass is exposed in two halves so that the sweep can run the sparse half of batch
@@ -94,7 +97,7 @@ class FPNVoxelNet(SingleStageDetector):
     def dense_stage(self, example, x, middle, finetune=False, **kwargs):
         if self.with_neck:
             x = self.neck(x)
-            middle.append(NHWCFeature(x))
+            middle.append(NHWCFeature(x, getattr(self.neck, "embedding", None)))
         if self.bbox_head is None:
             if not kwargs.get("estimate", False):
                 raise RuntimeError("this detector was built without a bbox_head: only the estimate=True "

@@ -393,6 +393,20 @@ int al3d_deconv2x2_nhwc_f16x3_bstream(const float* in, const void* wgt_frag, con
                                       const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
                                       int ldc, int coff, int relu, void* stream);
 
+/* Fused global average pooling (feature_selector.py:68-71 tap): the two deblock launches of
+ * the neck (1x1 conv and 2x2 transposed conv, rpn.py:124-142) can also emit, per workgroup and wave row, the channel
+ * sums of the values they store -- gap_part [B][gap_parts][ldc], gap_parts >= al3d_gap_parts_count(OH, OW, deconv), the
+ * launch fills its own count of slots and leaves the rest untouched (zero them when launches share a buffer) -- so the
+ * [B,128,128,512] map is not read again (33.5 MB per frame); al3d_gap_reduce_parts_f32 adds the parts in ascending order
+ * and divides by count = OH*OW.  Deterministic; differs from al3d_gap_nhwc_f32's W-then-H order in the last bits. */
+int al3d_gap_parts_count(int OH, int OW, int deconv);
+int al3d_conv2d_nhwc_f16x3_gap(const float* in, const void* wgt_f16x3, const float* scale, const float* shift,
+                               float* out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
+                               int ldc, int coff, int relu, float* gap_part, int gap_parts, void* stream);
+int al3d_deconv2x2_nhwc_f16x3_gap(const float* in, const void* wgt_f16x3, const float* scale, const float* shift,
+                                  float* out, int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu,
+                                  float* gap_part, int gap_parts, void* stream);
+int al3d_gap_reduce_parts_f32(const float* gap_part, int B, int parts, int C, int64_t count, float* out, void* stream);
 /* BEV embedding: mean over W then over H of an NHWC map, [B,H,W,C] -> [B,C].
  * Replaces `fpn_feats[-1].mean(-1).mean(-1)` (det3d/selectors/feature_selector.py:68-71). */
 int64_t al3d_gap_workspace_bytes(int B, int H, int C);

@@ -317,6 +317,12 @@ def test_rpn_matches_reference_golden():
         y = net(x)                                         # NHWC [1,32,48,512]
     from al3d import detector_ops as D
     emb = D.gap_nhwc(y).cpu().numpy()
+    # the embedding the deblock launches emit themselves (fused GAP: workgroup partial sums, ascending order) against
+    # the stand-alone W-then-H kernel on the stored map: same numbers up to the summation order
+    if D.MATH == "f16x3" and D.GAP == "fused":
+        assert net.embedding is not None and net.embedding.shape == (1, 512)
+        np.testing.assert_allclose(net.embedding.cpu().numpy(), emb, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(net.embedding.cpu().numpy(), z["emb"], rtol=1e-4, atol=1e-5)
     y = y.permute(0, 3, 1, 2).cpu().numpy()
     # 7 stacked 3x3 fp32 convs with BN: values O(1); reference ran on CPU torch
     np.testing.assert_allclose(y[0, ::16, ::4, ::4], z["y_slice"], rtol=1e-3, atol=1e-4)
