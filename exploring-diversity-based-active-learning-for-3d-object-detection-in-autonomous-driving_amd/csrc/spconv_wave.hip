@@ -242,8 +242,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ residual, int relu,
-                                                            float* __restrict__ fout, int n_out)
+                                                            float* __restrict__ fout, int n_out,
+                                                            int64_t pitch, const unsigned* __restrict__ tmask)
 {
+    // pitch: row pitch of the tap-major table (n_out for the plain rulebook, al3d_sp_table_pitch(n_out) for the tiled
+    // one); tmask: per-32-row-tile tap masks of a tiled rulebook (or null: the masks are scanned from the table)
     constexpr int KG = CIN / 16;
     constexpr int TN = (COUT + 31) / 32;
     constexpr int NROWS = COUT;
@@ -287,12 +290,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     // offsets with a neighbour in this wave's rows: all 14 index loads are issued before the first
     // ballot (one memory latency per wave instead of fourteen)
     unsigned wmask = 0u;
-    {
+    if (tmask) {
+        // tiled rulebook: one word per 32-row tile instead of scanning 27 x 32 table entries
+        const int wtile = (row0 >> 5) + wave;
+        wmask = (int64_t)wtile * 32 < n_out ? tmask[wtile] : 0u;
+    } else {
         int nv[14];
 #pragma unroll
         for (int i = 0; i < 14; ++i) {
             const int k = 2 * i + fh;
-            const int* ip = (k < K && row_ok) ? nbr + (int64_t)k * n_out + my_row : &g_sw_neg1;
+            const int* ip = (k < K && row_ok) ? nbr + (int64_t)k * pitch + my_row : &g_sw_neg1;
             nv[i] = *ip;
         }
 #pragma unroll
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     };
     auto load_idx = [&](const Cursor& c) -> int {
         const int t = cur_tap(c);
-        const int* ip = (t >= 0 && row_ok) ? nbr + (int64_t)t * n_out + my_row : &g_sw_neg1;
+        const int* ip = (t >= 0 && row_ok) ? nbr + (int64_t)t * pitch + my_row : &g_sw_neg1;
         return *ip;                                                    // the loaded word is used as is, P units later
     };
     float4 dlo[P], dhi[P];
@@ -510,7 +517,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
     if (cin == CI && cout == CO) {                                                                    \
         hipLaunchKernelGGL((sp_conv_wave2_kernel<CI, CO, NW, UPS, P, NPL>),                           \
                            dim3((unsigned)al3d_cdiv(n_out, 32 * NW)), dim3(64 * NW), 0, s, fin, nbr, K, \
-                           (const unsigned short*)wgt, scale, shift, residual, relu, fout, n_out);    \
+                           (const unsigned short*)wgt, scale, shift, residual, relu, fout, n_out,     \
+                           (int64_t)nbr_pitch, tile_mask);                                            \
         AL3D_CHECK_LAUNCH("sp_conv_wave2_kernel");                                                    \
         return AL3D_OK;                                                                               \
     }
@@ -525,15 +533,41 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
     AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave2_bf16x6: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const void* wgt = wgt_bf16x3;
+    const int nbr_pitch = n_out;
+    const unsigned* tile_mask = nullptr;
     SW2_DISPATCH(16, 16, 4, 4, 4, 3) SW2_DISPATCH(16, 32, 8, 2, 2, 3) SW2_DISPATCH(32, 32, 8, 2, 2, 3) SW2_DISPATCH(32, 64, 8, 4, 2, 3)
     SW2_DISPATCH(64, 64, 8, 4, 2, 3) SW2_DISPATCH(64, 128, 16, 2, 2, 3) SW2_DISPATCH(128, 128, 16, 2, 2, 3)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_bf16x6: unsupported channel pair %d -> %d", cin, cout);
 }
 
+static int sp_conv_wave2_f16x3_impl(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                                    const void* wgt_f16x2, int cin, int cout, const float* scale, const float* shift,
+                                    const float* residual, int relu, float* fout, int n_out, void* stream);
+
 extern "C" int al3d_sp_conv_wave2_f16x3(const float* fin, const int* nbr, int K, const void* wgt_f16x2,
                                         int cin, int cout, const float* scale, const float* shift,
                                         const float* residual, int relu, float* fout, int n_out,
                                         void* stream)
+{
+    return sp_conv_wave2_f16x3_impl(fin, nbr, n_out, nullptr, K, wgt_f16x2, cin, cout, scale, shift, residual, relu, fout,
+                                    n_out, stream);
+}
+
+// the same kernel on a tiled rulebook (al3d_sp_*_table_tiles): pitched table, per-tile tap masks read instead of scanned
+extern "C" int al3d_sp_conv_wave2_f16x3_tiles(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask,
+                                              int K, const void* wgt_f16x2, int cin, int cout, const float* scale,
+                                              const float* shift, const float* residual, int relu, float* fout, int n_out,
+                                              void* stream)
+{
+    AL3D_REQUIRE(tile_mask && nbr_pitch >= n_out && nbr_pitch % 256 == 0,
+                 "al3d_sp_conv_wave2_f16x3_tiles: needs a tiled rulebook (pitch = al3d_sp_table_pitch(n_out), tile masks)");
+    return sp_conv_wave2_f16x3_impl(fin, nbr, nbr_pitch, tile_mask, K, wgt_f16x2, cin, cout, scale, shift, residual, relu,
+                                    fout, n_out, stream);
+}
+
+static int sp_conv_wave2_f16x3_impl(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                                    const void* wgt_f16x2, int cin, int cout, const float* scale, const float* shift,
+                                    const float* residual, int relu, float* fout, int n_out, void* stream)
 {
     AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_wave2_f16x3: bad sizes");
     if (n_out == 0) return AL3D_OK;

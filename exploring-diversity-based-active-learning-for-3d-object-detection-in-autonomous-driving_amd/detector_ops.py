@@ -383,7 +383,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
     if mfma is None:
         mfma = (cin, cout) in MFMA_PAIRS and ({"bf16x6": "wave2", "f16x3": "glds_f16x3" if sparse_glds(cin, cout) else "wave2_f16x3"}
                                                .get(sparse_math(), True))
-    tiled = mfma == "glds_f16x3"              # pitched table + per-tile tap masks (al3d_sp_*_table_tiles)
+    tiled = mfma in ("glds_f16x3", "wave2_f16x3_tiles")     # pitched table + per-tile tap masks (al3d_sp_*_table_tiles)
     tmask = None
     if subm:
         if tiled:
@@ -424,6 +424,10 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
         pk = pack_glds_f16x3(w3)
         lib.call("al3d_sp_conv_glds_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(pk.data), cin,
+                 cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+    elif mfma == "wave2_f16x3_tiles":
+        w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
+        lib.call("al3d_sp_conv_wave2_f16x3_tiles", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(w3), cin,
                  cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
     elif mfma == "wave2_f16x3":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)

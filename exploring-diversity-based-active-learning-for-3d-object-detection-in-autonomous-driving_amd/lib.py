@@ -82,6 +82,8 @@ SIGNATURES = {
     "al3d_sp_pack_glds_f16x3": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
     "al3d_sp_conv_glds_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
                                         c_p, c_int, c_p]),
+    "al3d_sp_conv_wave2_f16x3_tiles": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
+                                               c_p, c_int, c_p]),
     "al3d_sp_table_pitch": (c_int, [c_int]),
     "al3d_sp_subm_table_tiles": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_int,
                                          c_p, c_int, c_p, c_p]),

@@ -163,8 +163,14 @@ class _SparseEncoderBase(nn.Module):
                      _ptr(step["w"].data), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr,
                      1, _ptr(out), n, st)
             return
+        if mfma_pair and step["w"].dtype == torch.float16 and tmask is not None:
+            # f16x3 arithmetic, software-pipelined register-gather wave kernel on the tiled rulebook
+            lib.call("al3d_sp_conv_wave2_f16x3_tiles", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K,
+                     _ptr(step["w"]), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1,
+                     _ptr(out), n, st)
+            return
         if mfma_pair and step["w"].dtype == torch.float16:
-            fn = "al3d_sp_conv_wave2_f16x3"           # f16x3 arithmetic, software-pipelined wave kernel
+            fn = "al3d_sp_conv_wave2_f16x3"           # the same kernel on a plain table
         elif mfma_pair and step["w"].dtype == torch.bfloat16:
             # bf16x6 arithmetic.  Measured per channel pair on the real rulebooks
             # (tools/bench_splayers.py): the software-pipelined wave kernel wins everywhere;
@@ -213,7 +219,9 @@ class _SparseEncoderBase(nn.Module):
                 continue
             m = step["mod"]
             K = int(np.prod(m.kernel_size))
-            tiled = isinstance(step["w"], D.GldsPacked)      # LDS-DMA gather kernel: pitched table + tile masks
+            # f16x3 (both matrix-core kernels): pitched table + per-tile tap masks; other arithmetics: plain table
+            tiled = isinstance(step["w"], D.GldsPacked) or (isinstance(step["w"], torch.Tensor) and
+                                                            step["w"].dtype == torch.float16)
             if step["kind"] == "subm":
                 key = (id(lv), m.kernel_size, tiled)
                 if nbr_key != key:

@@ -314,6 +314,11 @@ int al3d_sp_pack_glds_f16x3(const void* planes_f16x2, int cout, int K, int cin, 
 int al3d_sp_conv_glds_f16x3(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
                             const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
                             const float* residual, int relu, float* fout, int n_out, void* stream);
+/* al3d_sp_conv_wave2_f16x3 on a tiled rulebook: the offsets a wave needs come from tile_mask[tile] (one word) instead
+ * of a scan of the tile's 27 x 32 table entries; same arithmetic, same bits. */
+int al3d_sp_conv_wave2_f16x3_tiles(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                                   const void* wgt_f16x2, int cin, int cout, const float* scale, const float* shift,
+                                   const float* residual, int relu, float* fout, int n_out, void* stream);
 /* planes [3][count] bf16 -> f32 [count], exact (inverse of al3d_split_bf16x3) */
 int al3d_merge_bf16x3(const void* planes_bf16x3, int64_t count, float* out, void* stream);
 /* dense(): out NHWC [B,H,W,C*D] with channel = c*D + z (== .dense().view(N, C*D, H, W));

@@ -93,7 +93,7 @@ def test_sparse_conv_glds_kernel_is_bit_identical(cin, cout, geom):
     shift = rng.normal(0, 0.1, cout).astype(np.float32)
     res = rng.normal(size=(feats.shape[0], cout)).astype(np.float32) if (cin == cout and subm) else None
     outs = []
-    for mode in ("wave2_f16x3", "glds_f16x3"):
+    for mode in ("wave2_f16x3", "glds_f16x3", "wave2_f16x3_tiles"):
         got, gco, _ = D.sparse_conv_layer(_t(feats), _t(coords), batch, shape, _t(w), k, s, p, subm,
                                           scale=_t(scale), shift=_t(shift),
                                           residual=None if res is None else _t(res), relu=True, mfma=mode)
@@ -105,6 +105,8 @@ def test_sparse_conv_glds_kernel_is_bit_identical(cin, cout, geom):
     a = to_dense(outs[0][0], outs[0][1], batch, oshape)
     b = to_dense(outs[1][0], outs[1][1], batch, oshape)
     assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    c = to_dense(outs[2][0], outs[2][1], batch, oshape)          # the wave kernel reading the tiled rulebook's masks
+    assert np.array_equal(a.view(np.int32), c.view(np.int32))
 
 
 @pytest.mark.parametrize("k,s,p,subm", [((1, 1, 3), (1, 1, 2), (0, 0, 0), False),     # BEVFusion-style conv_out
