@@ -672,6 +672,179 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
     }
 }
 
+// ------------------------------------------------------------------ 3x3 / stride 1 / pad 1 on v_mfma_f32_16x16x32_f16
+// The kernel above is power-limited: its matrix-core instructions toggle enough silicon that the chip drops to
+// ~1.64 GHz under it.  On random f16 operands a bare v_mfma_f32_16x16x32_f16 loop sustains 1.93
+// PFLOP/s against 1.63 for v_mfma_f32_32x32x16_f16 (tools/probes/mfma_shape_probe.hip) -- the same work at less power.
+// This is the same data flow on the narrower shape: a step is (tap, PAIR of 16-channel chunks) = one K=32 MFMA depth,
+// the wave tile stays 2 image rows x 32 pixels x 64 channels = 4 x 4 tiles of 16 x 16, the halo of both chunks of a pair
+// sits in LDS (double-buffered by pair parity), weights stream from L2 in 16x16x32 fragment order
+// ([plane][Cout/16][pair][tap][lane][8], al3d_pack_f16x3_frag16) one step ahead.  The k-blocks of a fragment are
+// assigned so that the two lane quarters a b128 read group mixes (q = 0,1 / 2,3) read the SAME 16-byte half of their
+// halo rows from the two chunk buffers (bases 256-byte aligned): (3 * pixel + const) mod 16 over 16 distinct pixels ->
+// conflict-free at the 48-byte pitch.  Per (pixel, channel) the products are still al*wd, ah*wl, ah*wh into one fp32
+// accumulator, but 32 input channels deep per instruction instead of 16: NOT bit-identical to the kernels above
+// (same error class; tests compare at fp32 tolerance).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define F3_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define G16_HBUF 9984                  // one (chunk, plane) halo buffer: 204 pixels x 48 B, padded to a multiple of 256
+
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag16_kernel(ConvF3Params p)
+{
+    __shared__ __attribute__((aligned(256))) unsigned char Ah[2][2][2][G16_HBUF];        // [pair parity][chunk][plane] 78 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    int tile, nblk;
+    if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = nblk * F3_BN;
+    const int y0 = ty_ * G3_TH - 1, x0 = tx_ * G3_TW - 1;       // image coords of halo (0,0)
+    const int npairs = p.Cin / 32;
+    const int total = 9 * npairs;
+    const float* zero = reinterpret_cast<const float*>(&g_f3_zero16);
+
+    // ---- halo of a chunk pair: 2 x 204 pixels x 4 float4 pieces = 1632 pieces, 8 passes of 256 threads in 4 quarters
+    float4 rh[2];
+    auto load_halo = [&](int pair, int quarter) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = tid + 256 * (2 * quarter + k);
+            const int c = piece >= 816 ? 1 : 0, rem = piece - 816 * c;
+            const int hp = rem >> 2, q = rem & 3;
+            const int iy = y0 + hp / G3_HW, ix = x0 + hp % G3_HW;
+            const bool ok = piece < 1632 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float* src = p.in + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + (2 * pair + c) * F3_BK + 4 * q;
+            rh[k] = *reinterpret_cast<const float4*>(ok ? src : zero);
+        }
+    };
+    auto store_halo = [&](int buf, int quarter) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = tid + 256 * (2 * quarter + k);
+            if (piece >= 1632) continue;
+            const int c = piece >= 816 ? 1 : 0, rem = piece - 816 * c;
+            const int hp = rem >> 2, q = rem & 3;
+            f16x4 h, l;
+            split_act4(rh[k], h, l);
+            const int off = hp * F3_LDB + 8 * q;
+            *reinterpret_cast<f16x4*>(&Ah[buf][c][0][off]) = h;
+            *reinterpret_cast<f16x4*>(&Ah[buf][c][1][off]) = l;
+        }
+    };
+
+    // ---- this wave's weight stream: [plane][ntile16][step][lane][8]
+    const int NT = p.Cout >> 4;
+    const int nt0 = (n0 >> 4) + wn * 4;
+    const _Float16* bsrc[2];                          // [plane], tile stride = total * 512 elements
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) bsrc[pl] = p.wgt + ((int64_t)(pl * NT + nt0) * total) * 512 + lane * 8;
+    const int64_t bt = (int64_t)total * 512;
+    // ONE register set [plane][ntile], rolling: the fragments of 16-channel tile j for step s+1 are requested right
+    // after tile j's MFMAs of step s were issued -- a full step (48 MFMAs) between request and use, half the registers
+    // of a double set
+    f16x8 fb[2][4];
+    auto load_b1 = [&](int j, int sidx) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            fb[pl][j] = *reinterpret_cast<const f16x8*>(bsrc[pl] + j * bt + (int64_t)sidx * 512);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // A fragment of m-tile mt (image row 2*wm + (mt >> 1), pixels 16*(mt & 1) + lr): k-block lq = chunk (lq & 1),
+    // 16-byte half (lq >> 1) of the pixel's 32-byte f16 row
+    const int a_off = (lq & 1) * (2 * G16_HBUF) + ((2 * wm) * G3_HW + lr) * F3_LDB + 16 * (lq >> 1);
+    f16x8 fa[2][2][4];                                // [set][plane][mtile]
+    auto read_a = [&](int set, int pl, int hbuf, int tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const unsigned char* base = &Ah[hbuf][0][pl][0] + a_off;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            fa[set][pl][mt] = *reinterpret_cast<const f16x8*>(base + (((mt >> 1) + ky) * G3_HW + 16 * (mt & 1) + kx) * F3_LDB);
+    };
+    auto mfma_step = [&](int set, int snext, auto&& between0, auto&& between1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x8 wd = lift_down(fb[0][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = F3_MFMA16(fa[set][1][i], wd, acc[i][j]);          // xl' * wd
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = F3_MFMA16(fa[set][0][i], fb[1][j], acc[i][j]);    // xh * wl
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = F3_MFMA16(fa[set][0][i], fb[0][j], acc[i][j]);    // xh * wh
+            load_b1(j, snext);                        // tile j of the next step into the registers just consumed
+            if (j == 0) between0();
+            if (j == 1) between1();
+        }
+    };
+
+    // ---- prologue: halo(pair 0) in LDS, B(0) in flight
+    const int last = npairs - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_b1(j, 0);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) { load_halo(0, qd); store_halo(0, qd); }
+    __syncthreads();
+    read_a(0, 1, 0, 0);
+    read_a(0, 0, 0, 0);
+
+    auto step = [&](auto pp_, auto tap_, int pair, int pn) {
+        constexpr int pp = decltype(pp_)::value, tap = decltype(tap_)::value;
+        constexpr int q = (pp + tap) & 1;             // A fragment set of this step (9 taps: odd)
+        const int s1 = pair * 9 + tap + 1;            // the next step's weights (clamped at the end: harmless re-read)
+        if (tap == 0 || tap == 2 || tap == 4 || tap == 6) load_halo(pn, tap >> 1);      // next pair's halo, by quarters
+        __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top of the step
+        constexpr int nh = tap < 8 ? pp : pp ^ 1, nt = tap < 8 ? tap + 1 : 0;
+        auto b0 = [&]() { read_a(q ^ 1, 1, nh, nt); };
+        auto b1 = [&]() { read_a(q ^ 1, 0, nh, nt); };
+        mfma_step(q, s1 < total ? s1 : total - 1, b0, b1);
+        if (tap == 1 || tap == 3 || tap == 5 || tap == 7) store_halo(pp ^ 1, tap >> 1);
+        // tap 0: every wave is past the previous pair's tap 7, the last reader of halo buffer pp^1, before anyone
+        // overwrites it at tap 1; tap 7: all quarters stored before the reads of tap 8
+        if (tap == 0 || tap == 7) __syncthreads();
+    };
+    auto pair_body = [&](auto pp_, int pair) {
+        const int pn = pair < last ? pair + 1 : pair;            // clamped: the last pair re-reads itself
+        step(pp_, F3_IC(0), pair, pn); step(pp_, F3_IC(1), pair, pn); step(pp_, F3_IC(2), pair, pn);
+        step(pp_, F3_IC(3), pair, pn); step(pp_, F3_IC(4), pair, pn); step(pp_, F3_IC(5), pair, pn);
+        step(pp_, F3_IC(6), pair, pn); step(pp_, F3_IC(7), pair, pn); step(pp_, F3_IC(8), pair, pn);
+    };
+    for (int pair0 = 0; pair0 < npairs; pair0 += 2) {            // npairs is even (checked by the launcher)
+        pair_body(F3_IC(0), pair0);
+        pair_body(F3_IC(1), pair0 + 1);
+    }
+
+    // C fragment of a 16 x 16 tile: lane (lr, lq) holds column lr, rows 4*lq .. 4*lq + 3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + lr;
+        const float sc = p.scale[n];
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = ty_ * G3_TH + 2 * wm + (i >> 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = tx_ * G3_TW + 16 * (i & 1) + 4 * lq + r;
+                if (y >= p.OH || x >= p.OW) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
+                p.out[(((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ any geometry, weights from L2
 // The generic kernel with the weight half of its staging removed, like the 3x3 kernel above: the
 // activation tile (128 pixels x 16 channels per step; no tap reuse to keep a halo for) is still
@@ -944,6 +1117,64 @@ extern "C" int al3d_pack_f16x3_frag(const void* planes_f16x2, int Cout, int Cin,
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const _Float16*)planes_f16x2, Cout, Cin, (_Float16*)out_frag);
     AL3D_CHECK_LAUNCH("pack_frag_kernel");
+    return AL3D_OK;
+}
+
+// [2][Cout][9][Cin] planes -> 16x16x32 fragment order [plane][Cout/16][pair][tap][lane][8]; lane (c, q) = output channel
+// 16*ntile + c, k-block q = input channels 32*pair + 16*(q & 1) + 8*(q >> 1) .. + 7 (conv3x3_f16x3_frag16_kernel)
+__global__ void pack_frag16_kernel(const _Float16* __restrict__ planes, int Cout, int Cin, _Float16* __restrict__ out)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_plane = (int64_t)Cout * 9 * Cin;
+    if (o >= 2 * per_plane) return;
+    const int npairs = Cin / 32;
+    int64_t r = o;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int tap = r % 9; r /= 9;
+    const int pair = r % npairs; r /= npairs;
+    const int nt = r % (Cout / 16); r /= (Cout / 16);
+    const int pl = (int)r;
+    const int q = lane >> 4;
+    const int n = nt * 16 + (lane & 15), k = pair * 32 + 16 * (q & 1) + 8 * (q >> 1) + e;
+    out[o] = planes[pl * per_plane + ((int64_t)n * 9 + tap) * Cin + k];
+}
+
+extern "C" int al3d_pack_f16x3_frag16(const void* planes_f16x2, int Cout, int Cin, void* out_frag, void* stream)
+{
+    AL3D_REQUIRE(planes_f16x2 && out_frag, "al3d_pack_f16x3_frag16: null pointer");
+    AL3D_REQUIRE(Cout >= 128 && Cout % 128 == 0 && Cin >= 64 && Cin % 64 == 0,
+                 "al3d_pack_f16x3_frag16: needs Cout %% 128 == 0 and Cin %% 64 == 0 (got %d, %d)", Cout, Cin);
+    const int64_t count = 2 * (int64_t)Cout * 9 * Cin;
+    hipLaunchKernelGGL(pack_frag16_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)planes_f16x2, Cout, Cin, (_Float16*)out_frag);
+    AL3D_CHECK_LAUNCH("pack_frag16_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_conv3x3_nhwc_f16x3_frag16(const float* in, const void* wgt_frag16, const float* scale,
+                                              const float* shift, float* out, int B, int H, int W, int Cin,
+                                              int Cout, int ldc, int coff, int relu, void* stream)
+{
+    ConvF3Params p;
+    p.gap = nullptr; p.gap_parts = 0;
+    p.in = in; p.wgt = (const _Float16*)wgt_frag16; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = 3; p.stride = 1; p.pad = 1; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    p.OH = H; p.OW = W;
+    p.plane = (int64_t)Cout * 9 * Cin;
+    AL3D_REQUIRE(in && wgt_frag16 && out && scale, "al3d_conv3x3_nhwc_f16x3_frag16: null pointer");
+    AL3D_REQUIRE(B >= 1 && H >= 1 && W >= 1, "al3d_conv3x3_nhwc_f16x3_frag16: bad shape");
+    AL3D_REQUIRE(Cout % 128 == 0 && Cin % 64 == 0 && Cout >= 128 && Cin >= 64,
+                 "al3d_conv3x3_nhwc_f16x3_frag16: needs Cout %% 128 == 0 and Cin %% 64 == 0 (got %d, %d)", Cout, Cin);
+    AL3D_REQUIRE(coff >= 0 && coff + Cout <= ldc, "al3d_conv3x3_nhwc_f16x3_frag16: channel window exceeds ldc=%d", ldc);
+    AL3D_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)wgt_frag16 & 15) == 0,
+                 "al3d_conv3x3_nhwc_f16x3_frag16: in/wgt must be 16-byte aligned");
+    p.tiles_x = (int)al3d_cdiv(p.OW, G3_TW);
+    p.tiles_y = (int)al3d_cdiv(p.OH, G3_TH);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = Cout / F3_BN;
+    hipLaunchKernelGGL(conv3x3_f16x3_frag16_kernel, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv3x3_f16x3_frag16_kernel");
     return AL3D_OK;
 }
 

@@ -176,11 +176,21 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
         const int shift = 24 - 8 * pass;
         for (int q = tid; q < 256; q += HN_THREADS) hist[q] = 0;
         __syncthreads();
-        for (int a = tid; a < tk.A; a += HN_THREADS) {
-            const unsigned bits = sb[a];
-            if (!bits) continue;
-            if (pass == 0 || (bits >> (shift + 8)) == (prefix >> (shift + 8)))
-                atomicAdd(&hist[(bits >> shift) & 255], 1u);
+        for (int a0 = 0; a0 < tk.A; a0 += HN_THREADS) {
+            const int a = a0 + tid;
+            const unsigned bits = a < tk.A ? sb[a] : 0u;
+            int bin = -1;
+            if (bits && (pass == 0 || (bits >> (shift + 8)) == (prefix >> (shift + 8)))) bin = (int)((bits >> shift) & 255u);
+            // scores of one task share their leading bits (all in (0.1, 1)): a plain per-thread atomicAdd serialises
+            // ~A deep on one LDS word.  Aggregate per wave: one atomic per distinct bin and wave.
+            unsigned long long pending = __ballot(bin >= 0);
+            while (pending) {
+                const int leader = (int)__builtin_ctzll(pending);
+                const int lb = __builtin_amdgcn_readlane(bin, leader);
+                const unsigned long long same = __ballot(bin == lb);
+                if ((tid & 63) == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+                pending &= ~same;
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -200,20 +210,49 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
     // entries equal to it still fit (ties -> lower anchor index first).
     __syncthreads();
     const unsigned thr_bits = prefix;
-    // strictly-greater entries first
+    // Entries strictly above the threshold are taken in any order (the sort below orders them by (score, anchor));
+    // entries EQUAL to it are admitted in ascending anchor order until `need` of them fit: they are collected into
+    // a small list (exact score ties are rare), ranked by anchor, and the first `need` are taken.  No barrier per
+    // chunk of anchors.  More than HN_MAXK ties: the chunked path below (three barriers per 1024 anchors).
+    __shared__ unsigned s_eq_cnt;
+    __shared__ int eq_list[HN_MAXK];
+    if (tid == 0) s_eq_cnt = 0;
+    __syncthreads();
+    for (int a = tid; a < tk.A; a += HN_THREADS) {
+        const unsigned bits = sb[a];
+        if (!bits) continue;
+        if (need == 0xffffffffu || bits > thr_bits) {
+            const unsigned slot = atomicAdd(&s_sel_cnt, 1u);
+            if (slot < HN_MAXK) key_s[slot] = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)a);
+        } else if (bits == thr_bits) {
+            const unsigned e = atomicAdd(&s_eq_cnt, 1u);
+            if (e < HN_MAXK) eq_list[e] = a;
+        }
+    }
+    __syncthreads();
+    const unsigned neq = s_eq_cnt;
+    if (neq <= HN_MAXK) {
+        // rank of an equal entry = number of equal entries with a smaller anchor (anchors are distinct)
+        if (tid < (int)neq && need != 0xffffffffu) {
+            const int a = eq_list[tid];
+            unsigned rank = 0;
+            for (unsigned q = 0; q < neq; ++q) rank += eq_list[q] < a ? 1u : 0u;
+            if (rank < need) {
+                const unsigned slot = atomicAdd(&s_sel_cnt, 1u);
+                if (slot < HN_MAXK) key_s[slot] = ((unsigned long long)thr_bits << 32) | (unsigned)(0xffffffffu - (unsigned)a);
+            }
+        }
+        __syncthreads();
+    } else {
+    // more ties than the list holds: admit them chunk by chunk in anchor order
     for (int a0 = 0; a0 < tk.A; a0 += HN_THREADS) {
         const int a = a0 + tid;
         bool take = false, eq = false;
         unsigned bits = 0;
         if (a < tk.A) {
             bits = sb[a];
-            if (bits) {
-                if (need == 0xffffffffu || bits > thr_bits) take = true;
-                else if (bits == thr_bits) eq = true;
-            }
+            if (bits && bits == thr_bits) eq = true;
         }
-        // equal-to-threshold entries are admitted in ascending anchor order: wave ballots give
-        // the rank inside the chunk, s_eq_seen carries it across chunks.
         __shared__ unsigned eq_wave[HN_THREADS / 64];
         const unsigned long long em = __ballot(eq);
         const int lane = tid & 63, wv = tid >> 6;
@@ -231,6 +270,7 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
             if (slot < HN_MAXK) key_s[slot] = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)a);
         }
         __syncthreads();
+    }
     }
     const int n = (int)(s_sel_cnt < (unsigned)K ? s_sel_cnt : (unsigned)K);
     // ---- bitonic sort of the (<= 1024) keys, descending

@@ -106,6 +106,16 @@ def pack_frag_f16x3(planes):
     return F16x3Packed("frag3x3", out, cout, 9, cin)
 
 
+def pack_frag16_f16x3(planes):
+    """f16 planes [2,Cout,9,Cin] -> 16x16x32 fragment order for the 3x3/s1/p1 kernel on the narrow MFMA shape."""
+    planes = _dev(planes, torch.float16, "planes")
+    _, cout, taps, cin = planes.shape
+    assert taps == 9
+    out = torch.empty((2, cout // 16, cin // 32, 9, 64, 8), dtype=torch.float16, device=planes.device)
+    lib.call("al3d_pack_f16x3_frag16", _ptr(planes), cout, cin, _ptr(out), _stream())
+    return F16x3Packed("frag16", out, cout, 9, cin)
+
+
 def pack_bstream_f16x3(planes):
     """f16 planes [2,Cout,taps,Cin] -> fragment order for the streamed-weight kernel of the other geometries."""
     planes = _dev(planes, torch.float16, "planes")
@@ -153,6 +163,8 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
         planes, scale = split_f16x3(w_packed, scale)
         if ksize is not None and DENSE != "lds":
             if ksize != "deconv" and frag_ok(planes.shape[1], planes.shape[3], ksize, stride, pad):
+                if DENSE == "frag16" and planes.shape[3] % 64 == 0:
+                    return pack_frag16_f16x3(planes), scale
                 return pack_frag_f16x3(planes), scale
             # streamed weights pay off once a launch has enough steps to amortise the deeper prologue:
             # stride-2 3x3 (72 steps) -12 %, fused head (32) -5 %, 1x1 deblock (8) +8 % -> LDS-staged
@@ -203,14 +215,17 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
     if isinstance(w_packed, F16x3Packed):             # fragment-ordered f16x3
         pk = w_packed
         B, H, W, Cin = x.shape
-        if pk.cin != Cin or pk.taps != ksize * ksize or (pk.kind == "frag3x3" and (stride, pad) != (1, 1)):
+        if pk.cin != Cin or pk.taps != ksize * ksize or (pk.kind in ("frag3x3", "frag16") and (stride, pad) != (1, 1)):
             raise lib.Al3dError("conv2d_nhwc: fragment-ordered weights do not match this layer's geometry")
         OH = (H + 2 * pad - ksize) // stride + 1
         OW = (W + 2 * pad - ksize) // stride + 1
         if out is None:
             out = torch.empty((B, OH, OW, pk.cout), dtype=torch.float32, device=x.device)
         assert out.shape[:3] == (B, OH, OW) and out.is_contiguous()
-        if pk.kind == "frag3x3":
+        if pk.kind == "frag16":
+            lib.call("al3d_conv3x3_nhwc_f16x3_frag16", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
+                     B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
+        elif pk.kind == "frag3x3":
             lib.call("al3d_conv3x3_nhwc_f16x3_frag", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
                      B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
         else:

@@ -105,6 +105,8 @@ SIGNATURES = {
     "al3d_conv2d_nhwc_f16x3": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p]),
     "al3d_deconv2x2_nhwc_f16x3": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_pack_f16x3_frag": (c_int, [c_p, c_int, c_int, c_p, c_p]),
+    "al3d_pack_f16x3_frag16": (c_int, [c_p, c_int, c_int, c_p, c_p]),
+    "al3d_conv3x3_nhwc_f16x3_frag16": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_conv3x3_nhwc_f16x3_frag": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_pack_f16x3_bstream_elems": (c_i64, [c_int, c_int, c_int]),
     "al3d_pack_f16x3_bstream": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),

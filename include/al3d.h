@@ -379,6 +379,14 @@ int al3d_deconv2x2_nhwc_f16x3(const float* in, const void* wgt_f16x2, const floa
  * fragment order [2][Cout/32][Cin/16][9][64 lanes][8] so that every wave streams its B operands
  * straight from L2 into registers (no LDS staging of weights).  Cout % 128 == 0, Cin % 32 == 0. */
 int al3d_pack_f16x3_frag(const void* planes_f16x2, int Cout, int Cin, void* out_frag, void* stream);
+/* The same layer on v_mfma_f32_16x16x32_f16 (same flops at less power: the 3x3 kernel is power-limited): weights in
+ * 16x16x32 fragment order [2][Cout/16][Cin/32][9][64][8] from al3d_pack_f16x3_frag16 (Cout % 128 == 0, Cin % 64 == 0).
+ * Same three products per MAC into one fp32 accumulator, 32 input channels per instruction instead of 16: fp32-class
+ * like the others, not bit-identical to them. */
+int al3d_pack_f16x3_frag16(const void* planes_f16x2, int Cout, int Cin, void* out_frag, void* stream);
+int al3d_conv3x3_nhwc_f16x3_frag16(const float* in, const void* wgt_frag16, const float* scale, const float* shift,
+                                   float* out, int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu,
+                                   void* stream);
 int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_frag, const float* scale,
                                  const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
                                  int ldc, int coff, int relu, void* stream);

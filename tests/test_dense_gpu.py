@@ -149,11 +149,22 @@ def test_conv2d_f16x3_is_fp32_class(B, H, W, Cin, Cout, k, s, p, xmag):
     if (k, s, p) != (3, 1, 1) or Cin % 32:            # the geometries the generic kernels serve
         gotb = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_bstream_f16x3(w3), sc3, None, k, s, p, False)
         assert torch.equal(gotb, got3)                # streamed weights: same products, same order
+    got16 = None
+    if D.frag_ok(Cout, Cin, k, s, p) and Cin % 64 == 0:
+        # the 16x16x32 kernel: the same three products, 32 input channels per instruction -> another summation
+        # grouping (not the same bits), the same error class
+        got16 = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_frag16_f16x3(w3), sc3, None, k, s, p, False)
+        again = D.conv2d_nhwc(_nhwc(x).to(DEV), D.pack_frag16_f16x3(w3), sc3, None, k, s, p, False)
+        assert torch.equal(got16, again)              # deterministic
+        got16 = got16.cpu().double()
     got3 = got3.cpu().double()
     scale = _nhwc(F.conv2d(x.abs().double(), w.abs().double(), stride=s, padding=p))
     e32 = ((got32 - ref).abs() / scale).max().item()
     e3 = ((got3 - ref).abs() / scale).max().item()
     assert e32 < 1.5e-6 and e3 < 1.5e-6 and e3 < 3.0 * e32 + 1e-8, (e32, e3)
+    if got16 is not None:
+        e16 = ((got16 - ref).abs() / scale).max().item()
+        assert e16 < 1.5e-6 and e16 < 3.0 * e32 + 1e-8, (e32, e16)
 
 
 def test_split_f16x3_planes():

@@ -405,6 +405,42 @@ def test_head_predict_vs_oracle(oracle, score_bias):
             assert len(ss) > 50
 
 
+@pytest.mark.parametrize("levels", [3, 40])
+def test_head_predict_with_massive_score_ties(oracle, levels):
+    """Class logits quantised to a few levels: thousands of anchors share the score of the 1000th candidate, so the
+    top-k cut falls inside a run of exact ties (lower anchor index first).  levels=3: far more ties than
+    the kernel's 1024-entry tie list (chunked fallback); levels=40: tens to hundreds (list path)."""
+    B, H, W = 2, 16, 16
+    cfg, head, anchors = _head_setup(11, H, W, 0.0)
+    head._prepare(torch.device(DEV))
+    g = torch.Generator().manual_seed(levels)
+    fused = torch.randn(B, H, W, head._ch, generator=g)
+    for t, task in enumerate(head.tasks):
+        c0 = head._cls_off[t]
+        cls = fused[..., c0:c0 + task.conv_cls.out_channels]
+        fused[..., c0:c0 + task.conv_cls.out_channels] = torch.round(cls * (levels / 4.0)) / (levels / 4.0)
+    fused = fused.to(DEV).contiguous()
+    preds = [{"_fused": fused} for _ in head.tasks]
+    tc = cfg.test_cfg
+    out = head.predict({"anchors": [_t(a) for a in anchors], "metadata": [{"i": i} for i in range(B)]}, preds, tc)
+    fnp = fused.cpu().numpy().reshape(B, H * W, -1)
+    label_off = np.concatenate([[0], np.cumsum(head.num_classes)])
+    for b in range(B):
+        bb, ss, ll = [], [], []
+        for t in range(len(head.tasks)):
+            bx, sc, lb = oracle.head_predict(fnp[b], anchors[t], head.num_anchor_per_locs[t], head.num_classes[t],
+                                             head._box_off[t], head._cls_off[t], tc.score_threshold,
+                                             tc.nms.nms_iou_threshold, tc.nms.nms_pre_max_size,
+                                             tc.nms.nms_post_max_size, tc.post_center_limit_range)
+            bb.append(bx); ss.append(sc); ll.append(lb + label_off[t])
+        bb, ss, ll = np.concatenate(bb), np.concatenate(ss), np.concatenate(ll)
+        got = out[b]
+        assert got["label_preds"].cpu().numpy().tolist() == ll.tolist()
+        np.testing.assert_allclose(got["scores"].cpu().numpy(), ss, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got["box3d_lidar"].cpu().numpy()[:, :8], bb[:, :8], rtol=1e-4, atol=1e-4)
+        assert len(ss) > 20
+
+
 # ---------------------------------------------------------------- detector end to end
 def test_detector_batch_invariance_and_determinism():
     from al3d import synthetic

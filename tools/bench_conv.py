@@ -20,6 +20,9 @@ for (H, Cin, Cout, k, s, p) in shapes:
     sc = torch.ones(Cout, device=dev); sh = torch.zeros(Cout, device=dev)
     if MODE == 'f16x3':
         w, sc = D.split_f16x3(w, sc)
+    if MODE == 'f16x3frag16':
+        w, sc = D.split_f16x3(w, sc)
+        w = D.pack_frag16_f16x3(w) if (D.frag_ok(Cout, Cin, k, s, p) and Cin % 64 == 0) else D.pack_bstream_f16x3(w)
     if MODE == 'f16x3frag':
         w, sc = D.split_f16x3(w, sc)
         w = D.pack_frag_f16x3(w) if D.frag_ok(Cout, Cin, k, s, p) else D.pack_bstream_f16x3(w)
