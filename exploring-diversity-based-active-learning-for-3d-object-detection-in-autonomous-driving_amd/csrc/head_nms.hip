@@ -176,9 +176,18 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
         const int shift = 24 - 8 * pass;
         for (int q = tid; q < 256; q += HN_THREADS) hist[q] = 0;
         __syncthreads();
-        for (int a0 = 0; a0 < tk.A; a0 += HN_THREADS) {
-            const int a = a0 + tid;
-            const unsigned bits = a < tk.A ? sb[a] : 0u;
+        // four chunks of anchors per trip: the four loads are issued together (one L2 round trip per trip instead of
+        // one per chunk -- the ballots below keep the compiler from overlapping trips by itself)
+        for (int a00 = 0; a00 < tk.A; a00 += 4 * HN_THREADS) {
+          unsigned bits4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+              const int a = a00 + u * HN_THREADS + tid;
+              bits4[u] = a < tk.A ? sb[a] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned bits = bits4[u];
             int bin = -1;
             if (bits && (pass == 0 || (bits >> (shift + 8)) == (prefix >> (shift + 8)))) bin = (int)((bits >> shift) & 255u);
             // scores of one task share their leading bits (all in (0.1, 1)): a plain per-thread atomicAdd serialises
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
                 if ((tid & 63) == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
                 pending &= ~same;
             }
+          }
         }
         __syncthreads();
         if (tid == 0) {
@@ -218,8 +228,14 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
     __shared__ int eq_list[HN_MAXK];
     if (tid == 0) s_eq_cnt = 0;
     __syncthreads();
-    for (int a = tid; a < tk.A; a += HN_THREADS) {
-        const unsigned bits = sb[a];
+    for (int a00 = tid; a00 < tk.A; a00 += 4 * HN_THREADS) {
+      unsigned bits4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bits4[u] = a00 + u * HN_THREADS < tk.A ? sb[a00 + u * HN_THREADS] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = a00 + u * HN_THREADS;
+        const unsigned bits = bits4[u];
         if (!bits) continue;
         if (need == 0xffffffffu || bits > thr_bits) {
             const unsigned slot = atomicAdd(&s_sel_cnt, 1u);
@@ -228,6 +244,7 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
             const unsigned e = atomicAdd(&s_eq_cnt, 1u);
             if (e < HN_MAXK) eq_list[e] = a;
         }
+      }
     }
     __syncthreads();
     const unsigned neq = s_eq_cnt;

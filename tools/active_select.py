@@ -80,6 +80,15 @@ def main():
             torch.distributed.barrier()
         sel_cfg["logs_file"] = os.path.join(os.path.dirname(sel_cfg.infos_origin), "log.json")
         sel_cfg.setdefault("distance_store_file", None)
+        # the selectors' own defaults for their caches are the reference authors' absolute paths
+        # (spatial_temporal_feature_selector.py:24, feature_selector.py:20, ...): a synthetic run keeps them next
+        # to the buffer file instead
+        import inspect
+        from al3d.selectors import SELECTORS
+        accepted = inspect.signature(SELECTORS.get(sel_cfg.type).__init__).parameters
+        for key, name in (("buffer_path", "feature_pred.pt"), ("weighted_feat_path", "weighted_feature_pred.pt")):
+            if key in accepted:
+                sel_cfg.setdefault(key, os.path.join(os.path.dirname(sel_cfg.buffer_file) or ".", name))
     os.makedirs(os.path.dirname(sel_cfg.buffer_file) or ".", exist_ok=True)
     if not os.path.exists(sel_cfg.buffer_file):
         # first round: empty buffer (reference init_sample_dataset, active_select.py:68-71)
