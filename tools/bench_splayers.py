@@ -46,6 +46,7 @@ for (m, feats, nbr, K, step, residual, n) in calls:
     line = f"{ci:3d}->{co:3d} K={K:2d} n={n:7d} valid={valid:.2f} "
     ref = None
     ci = feats.shape[-1]                                    # 16 for the zero-padded first layer
+    plain = nbr if nbr.shape[1] == n else nbr[:, :n].contiguous()      # the encoder records pitched (tiled) tables
     tiled = None
     if any("glds" in f for f in fns):                       # the tiled form of this table: pitch + tile masks
         key = nbr.data_ptr()
@@ -64,7 +65,7 @@ for (m, feats, nbr, K, step, residual, n) in calls:
                 lib.call(f, _ptr(feats), _ptr(tiled[0]), tiled[2], _ptr(tiled[1]), K, _ptr(w), ci, co, _ptr(step["scale"]),
                          _ptr(step["shift"]), None if residual is None else _ptr(residual), 1, _ptr(out), n, _stream())
                 return
-            lib.call(f, _ptr(feats), _ptr(nbr), K, _ptr(w), ci, co, _ptr(step["scale"]), _ptr(step["shift"]),
+            lib.call(f, _ptr(feats), _ptr(plain), K, _ptr(w), ci, co, _ptr(step["scale"]), _ptr(step["shift"]),
                      None if residual is None else _ptr(residual), 1, _ptr(out), n, _stream())
         try:
             call()
