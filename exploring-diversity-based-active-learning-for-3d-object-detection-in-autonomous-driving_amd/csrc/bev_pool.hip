@@ -59,6 +59,51 @@ __global__ void bev_scatter_kernel(const int* __restrict__ cell, int64_t P, cons
     list[start[c] + atomicAdd(&fill[c], 1)] = (int)p;
 }
 
+#define BEV_SHORT 128
+#define BEV_LONG_CAP 8192
+
+// Long member lists: one 256-thread workgroup per cell with more than BEV_SHORT points sorts its list (bitonic, in LDS)
+// into `sorted`.  The cells are found by a grid-stride scan over the counts (no host round trip); lists beyond
+// BEV_LONG_CAP entries fall back to rank counting by the whole workgroup.
+__global__ __launch_bounds__(256) void bev_sort_long_kernel(const int* __restrict__ count, const int* __restrict__ start,
+                                                            const int* __restrict__ list, int* __restrict__ sorted,
+                                                            int ncell)
+{
+    __shared__ int key[BEV_LONG_CAP];
+    for (int c = blockIdx.x; c < ncell; c += gridDim.x) {
+        const int len = count[c], base = start[c];
+        if (len <= BEV_SHORT) continue;                                  // workgroup-uniform
+        if (len <= BEV_LONG_CAP) {
+            int np2 = 1;
+            while (np2 < len) np2 <<= 1;
+            for (int i = threadIdx.x; i < np2; i += 256) key[i] = i < len ? list[base + i] : 0x7fffffff;
+            __syncthreads();
+            for (int size = 2; size <= np2; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int i = threadIdx.x; i < np2; i += 256) {
+                        const int j = i ^ stride;
+                        if (j > i) {
+                            const bool asc = (i & size) == 0;
+                            const int a = key[i], b = key[j];
+                            if (asc ? a > b : a < b) { key[i] = b; key[j] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = threadIdx.x; i < len; i += 256)
+                __hip_atomic_store(&sorted[base + i], key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        } else {
+            for (int e = threadIdx.x; e < len; e += 256) {
+                const int v = list[base + e];
+                int rank = 0;
+                for (int j = 0; j < len; ++j) rank += list[base + j] < v ? 1 : 0;
+                __hip_atomic_store(&sorted[base + rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 // One wave per cell.  LSS = 1: x[p][c] = depth[p] * ctx[row(p)][c] with p = ((bn*D + d)*fH + h)*fW + w and
 // row = (bn*fH + h)*fW + w; product and sum are separate fp32 roundings (no contraction), like the reference's
 // materialised tensor.
@@ -73,33 +118,55 @@ __global__ __launch_bounds__(256) void bev_sum_kernel(const float* __restrict__ 
     const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c0 >= ncell) return;
     const int len = count[c0], base = start[c0];
-    // ascending point order by rank counting: point indices are distinct, so ranks are a permutation
-    for (int e = lane; e < len; e += 64) {
-        const int v = list[base + e];
-        int rank = 0;
-        for (int j = 0; j < len; ++j) rank += list[base + j] < v ? 1 : 0;
-        // L2-scope store / loads below: neighbouring cells share cache lines of this array and a CU's vector L1 is
-        // not refreshed by stores (MI355X_MICROARCH.md, inter-workgroup visibility)
-        __hip_atomic_store(&sorted[base + rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ascending point order.  Short lists (the common case: ~14 points per cell) by rank counting inside the wave;
+    // long ones (cells next to a camera hold ~1,000 points) were put in order by bev_sort_long_kernel already
+    // (rank counting is O(len^2 / 64) per wave: 16 k trips at len = 1,000).
+    if (len <= BEV_SHORT) {
+        for (int e = lane; e < len; e += 64) {
+            const int v = list[base + e];
+            int rank = 0;
+            for (int j = 0; j < len; ++j) rank += list[base + j] < v ? 1 : 0;
+            // L2-scope store / loads below: neighbouring cells share cache lines of this array and a CU's vector L1
+            // is not refreshed by stores (MI355X_MICROARCH.md, inter-workgroup visibility)
+            __hip_atomic_store(&sorted[base + rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
     // out[(b, ix, iy), iz*C + c]: cell id = ((b*nx0 + ix)*nx1 + iy)*nz + iz, so the address is cell * C + c
     float* o = out + (int64_t)c0 * C;
-    for (int c = lane; c < C; c += 64) {
+    // lanes = channels (two rounds at C = 80 .. 128); the member indices are fetched 64 at a time (one L2-scope load
+    // per lane) and broadcast, the feature loads of four consecutive members are issued together and added in order
+    const int nround = (C + 63) / 64;
+    for (int rd = 0; rd < nround; ++rd) {
+        const int c = rd * 64 + lane;
+        const bool live = c < C;
         float acc = 0.f;
-        for (int i = 0; i < len; ++i) {
-            const int p = __hip_atomic_load(&sorted[base + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float v;
-            if (LSS) {
-                const int bn = p / (Dd * fHW), pix = p % fHW;
-                v = depth[p] * x[((int64_t)bn * fHW + pix) * C + c];
-            } else {
-                v = x[(int64_t)p * C + c];
+        for (int i0 = 0; i0 < len; i0 += 64) {
+            const int mine = i0 + lane < len ? __hip_atomic_load(&sorted[base + i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const int cnt = len - i0 < 64 ? len - i0 : 64;
+            for (int k0 = 0; k0 < cnt; k0 += 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u < cnt ? k0 + u : cnt - 1;
+                    const int p = __shfl(mine, k);
+                    float t = 0.f;
+                    if (live) {
+                        if (LSS) {
+                            const int bn = p / (Dd * fHW), pix = p % fHW;
+                            t = depth[p] * x[((int64_t)bn * fHW + pix) * C + c];
+                        } else {
+                            t = x[(int64_t)p * C + c];
+                        }
+                    }
+                    v[u] = k0 + u < cnt ? t : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (k0 + u < cnt) acc += v[u];
             }
-            acc += v;
         }
-        o[c] = acc;
+        if (live) o[c] = acc;
     }
     (void)nz;
 }
@@ -145,6 +212,7 @@ static int bev_pool_run(const float* x, const float* depth, int lss, int Dd, int
     if (rc) return rc;
     hipLaunchKernelGGL(bev_scatter_kernel, dim3(pblocks), dim3(256), 0, s, cell, P, start, fill, list);
     const unsigned cblocks = (unsigned)al3d_cdiv(ncell, 4);
+    hipLaunchKernelGGL(bev_sort_long_kernel, dim3(1024), dim3(256), 0, s, count, start, list, sorted, ncell);
     if (lss)
         hipLaunchKernelGGL(bev_sum_kernel<1>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, count, start, list,
                            sorted, ncell, nx[2], out);
