@@ -37,6 +37,7 @@
 //   conv2d_f16x3_bstream_kernel   any geometry, activation tile in LDS, weights streamed       (>= 24 steps)
 //   conv2d_f16x3_kernel           any geometry, both tiles through LDS                         (short launches, deconv)
 #include "al3d_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #define F3_BM 128
@@ -1337,4 +1338,493 @@ extern "C" int al3d_deconv2x2_nhwc_f16x3_gap(const float* in, const void* wgt_f1
     AL3D_REQUIRE(gap_part, "al3d_deconv2x2_nhwc_f16x3_gap: null gap_part");
     return deconv2x2_f16x3_impl(in, wgt_f16x3, scale, shift, out, B, H, W, Cin, Cout, ldc, coff, relu, gap_part, gap_parts,
                                 stream);
+}
+
+// ------------------------------------------------------------------ any geometry, both operands by LDS-DMA
+// The generic kernels above move every operand through registers on its way to LDS (global load -> split ->
+// ds_write) and wait at a barrier for the slowest of 256 such round trips once per 16-channel step; the
+// streamed-weight variant trades the weight half of that for four fragment loads per wave and step, which the
+// texture-address unit serves at 64 B/clk -- as many cycles as the step's twelve MFMAs.  Profiled, the stride-2,
+// 1x1, deconvolution and fused-head launches sat at 180-240 TFLOP/s of products against 350 for the 3x3 kernel.
+//
+// Here nothing passes through a register before it is an MFMA operand.  A step's two tiles -- 128 pixels x 16
+// channels of RAW fp32 activations (8 KB) and 128 output channels x 16 x {wh, wl} f16 weights (8 KB, an image
+// pre-packed in exactly the LDS layout) -- are fetched by `global_load_lds_dwordx4`, four DMA instructions per
+// wave and step, into a ring of NS stages that runs NS-1 steps ahead; counted `s_waitcnt vmcnt` + ONE raw
+// `s_barrier` per step publish a stage.  The activation split (xh, xl') happens on the fragment, in registers,
+// after the ds_read -- 2 x more VALU than splitting once per workgroup, but off the critical path of the loads.
+// Bank conflicts are handled on the SOURCE side of the DMA (the LDS side is lane-linear by construction): lane
+// (row r, chunk s) fetches chunk s ^ f(r), the swizzle of the sparse LDS-DMA kernel (spconv_glds.hip).
+// LDS reads are inline asm with their own lgkmcnt wait: hipcc cannot see that a DMA writes LDS and would
+// otherwise drain vmcnt(0) before every read it cannot disambiguate.
+// Same tiles, same grid, same product order as conv2d_f16x3_kernel: bit-identical results, same GAP partials.
+typedef float dg_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void dg_lds_void;
+typedef const __attribute__((address_space(1))) void dg_gbl_void;
+__device__ __attribute__((aligned(256))) float g_dma_zero[64];     // stays zero: source of out-of-image pixels
+
+#define DG_STAGE 16384      // bytes per stage: A 8 KB + B 8 KB
+#define DG_BOFF 8192
+
+template <int N> __device__ __forceinline__ void dg_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ int dg_swz(int r) { return (r & 1) | (((r >> 3) & 1) << 1); }
+
+__device__ __forceinline__ void dg_split8(const dg_f32x4& lo, const dg_f32x4& hi, f16x8& ph, f16x8& pl)
+{
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { _Float16 a, b; split_act(v[e], a, b); ph[e] = a; pl[e] = b; }
+}
+
+template <int MODE, int NS>
+__global__ __launch_bounds__(256, NS <= 3 ? 3 : 2) void conv2d_f16x3_dma_kernel(ConvF3Params p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * DG_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    int tile, nblk;
+    if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = nblk * F3_BN;
+    const int MH = MODE == 0 ? p.OH : p.H, MW = MODE == 0 ? p.OW : p.W;
+    const int taps = MODE == 0 ? p.ksize * p.ksize : 1;
+    const int tap0 = MODE == 0 ? 0 : blockIdx.z;
+    const int wtaps = MODE == 0 ? taps : 4;
+    const int kchunks = p.Cin / F3_BK;
+    const int total = taps * kchunks;
+    const unsigned smem_base = (unsigned)(size_t)(dg_lds_void*)smem;
+
+    // ---- DMA side.  Wave w fetches M-tile w (pixels 32w .. 32w+31 of the 8 x 16 tile) and the 2 KB quarter w of the
+    // weight tile.  Lane (jg, sg) of piece i fetches chunk sg ^ f(r) of row r = 2 jg + i.
+    const int jg = lane >> 2, sg = lane & 3;
+    int py[2], px[2], cg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 2 * jg + i, m = 32 * wave + r;
+        py[i] = ty_ * F3_TH + m / F3_TW;
+        px[i] = tx_ * F3_TW + m % F3_TW;
+        cg[i] = (sg ^ dg_swz(r)) * 4;
+    }
+    const char* wsrc = reinterpret_cast<const char*>(p.wgt) +
+                       ((int64_t)nblk * wtaps + tap0) * kchunks * 8192 + wave * 2048 + lane * 16;
+    int ltap = 0, lchunk = 0;                          // cursor of the next stage to request
+    auto issue = [&](int stage) {
+        const int ky = MODE == 0 ? ltap / p.ksize : 0, kx = MODE == 0 ? ltap - ky * p.ksize : 0;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + stage * DG_STAGE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int iy, ix;
+            if (MODE == 0) { iy = py[i] * p.stride - p.pad + ky; ix = px[i] * p.stride - p.pad + kx; }
+            else { iy = py[i]; ix = px[i]; }
+            const bool ok = py[i] < MH && px[i] < MW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            // 32-bit element index (the entry checks B*H*W*Cin < 2^31): keeps the select a pair of v_cndmask, no branch
+            const unsigned idx = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + lchunk * F3_BK + cg[i]);
+            const float* src = ok ? p.in + idx : g_dma_zero + cg[i];
+            __builtin_amdgcn_global_load_lds((dg_gbl_void*)src, (dg_lds_void*)(size_t)(dst + i * 1024), 16, 0, 0);
+        }
+        const char* ws = wsrc + ((int64_t)ltap * kchunks + lchunk) * 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((dg_gbl_void*)(ws + i * 1024), (dg_lds_void*)(size_t)(dst + DG_BOFF + i * 1024),
+                                             16, 0, 0);
+        // steps past the end re-fetch the last one (into a free stage): the DMA count per step stays 4
+        if (ltap * kchunks + lchunk + 1 < total) { if (++lchunk == kchunks) { lchunk = 0; ++ltap; } }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment side: lane (fr, fh) reads chunks 2 fh, 2 fh + 1 of pixel row fr of M-tiles 2 wm, 2 wm + 1 and
+    // chunk fh of weight rows wn * 64 + {0, 32} + fr of both planes
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned offA0 = (unsigned)(wm * 4096 + (fr & 1) * 1024 + (fr >> 1) * 64 + (((2 * fh) ^ dg_swz(fr)) * 16));
+    const unsigned offA1 = (unsigned)(wm * 4096 + (fr & 1) * 1024 + (fr >> 1) * 64 + (((2 * fh + 1) ^ dg_swz(fr)) * 16));
+    const unsigned offB = (unsigned)(DG_BOFF + (wn * 64 + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) * 16));
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    int stage = 0, fill = NS - 1;
+    for (int s = 0; s < total; ++s) {
+        dg_wait_vm<4 * (NS - 2)>();                    // this wave's share of stage s has landed ...
+        __builtin_amdgcn_s_barrier();                  // ... everyone's has, and stage s-1 is free
+        issue(fill);
+        const unsigned sb = smem_base + stage * DG_STAGE;
+        dg_f32x4 a0l, a0h, a1l, a1h;
+        f16x8 wh0, wl0, wh1, wl1;
+        asm volatile("ds_read_b128 %0, %8\n\t"
+                     "ds_read_b128 %1, %9\n\t"
+                     "ds_read_b128 %2, %8 offset:2048\n\t"
+                     "ds_read_b128 %3, %9 offset:2048\n\t"
+                     "ds_read_b128 %4, %10\n\t"
+                     "ds_read_b128 %5, %10 offset:4096\n\t"
+                     "ds_read_b128 %6, %10 offset:1024\n\t"
+                     "ds_read_b128 %7, %10 offset:5120\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(wh0), "=&v"(wl0), "=&v"(wh1), "=&v"(wl1)
+                     : "v"(sb + offA0), "v"(sb + offA1), "v"(sb + offB) : "memory");
+        f16x8 ah[2], al[2];
+        dg_split8(a0l, a0h, ah[0], al[0]);
+        dg_split8(a1l, a1h, ah[1], al[1]);
+        const f16x8 wd0 = lift_down(wh0), wd1 = lift_down(wh1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[i][0] = F3_MFMA(al[i], wd0, acc[i][0]);                  // xl' * wd   (smallest first)
+            acc[i][0] = F3_MFMA(ah[i], wl0, acc[i][0]);                  // xh * wl
+            acc[i][0] = F3_MFMA(ah[i], wh0, acc[i][0]);                  // xh * wh
+            acc[i][1] = F3_MFMA(al[i], wd1, acc[i][1]);
+            acc[i][1] = F3_MFMA(ah[i], wl1, acc[i][1]);
+            acc[i][1] = F3_MFMA(ah[i], wh1, acc[i][1]);
+        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+    dg_wait_vm<0>();                                   // the tail's dummy requests must not outlive the workgroup's LDS
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale[n];
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+        float gsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                if (y >= MH || x >= MW) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
+                int oy = y, ox = x;
+                if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
+                p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;
+                gsum += v;
+            }
+        }
+        if (p.gap) {                                                  // as conv2d_f16x3_kernel
+            gsum += __shfl_xor(gsum, 32);
+            if (fh == 0) {
+                const int part = (((ty_ * p.tiles_x + tx_) * (MODE == 1 ? 4 : 1) + tap0) << 1) + wm;
+                p.gap[((int64_t)b * p.gap_parts + part) * p.ldc + p.coff + n] = gsum;
+            }
+        }
+    }
+}
+
+// Software-pipelined form of the kernel above (the default): the fragments of step s+1 are read while the
+// MFMAs of step s run, from ONE asm block that interleaves the eight ds_reads with the twelve MFMAs and ends in
+// the lgkmcnt wait -- hipcc never sees a register that is still in flight.  Two operand sets alternate (the loop
+// is unrolled by two), so the split of step s+1 writes registers no queued MFMA reads.  All NS stage buffers are
+// in flight: a stage's buffer is refilled as soon as every wave holds its fragments in registers.
+// The four accumulator chains are interleaved inside the block (dependent MFMAs are four instructions apart);
+// each accumulator still receives xl'*wd, xh*wl, xh*wh in that order per step: the same bits.
+struct DgOps {
+    f16x8 ah[2], al[2], wh[2], wl[2], wd[2];
+};
+
+template <int MODE, int NS>
+__global__ __launch_bounds__(256, 2) void conv2d_f16x3_dma2_kernel(ConvF3Params p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * DG_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    int tile, nblk;
+    if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = nblk * F3_BN;
+    const int MH = MODE == 0 ? p.OH : p.H, MW = MODE == 0 ? p.OW : p.W;
+    const int taps = MODE == 0 ? p.ksize * p.ksize : 1;
+    const int tap0 = MODE == 0 ? 0 : blockIdx.z;
+    const int wtaps = MODE == 0 ? taps : 4;
+    const int kchunks = p.Cin / F3_BK;
+    const int total = taps * kchunks;
+    const unsigned smem_base = (unsigned)(size_t)(dg_lds_void*)smem;
+
+    const int jg = lane >> 2, sg = lane & 3;
+    int py[2], px[2], cg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 2 * jg + i, m = 32 * wave + r;
+        py[i] = ty_ * F3_TH + m / F3_TW;
+        px[i] = tx_ * F3_TW + m % F3_TW;
+        cg[i] = (sg ^ dg_swz(r)) * 4;
+    }
+    const char* wsrc = reinterpret_cast<const char*>(p.wgt) +
+                       ((int64_t)nblk * wtaps + tap0) * kchunks * 8192 + wave * 2048 + lane * 16;
+    int ltap = 0, lchunk = 0;                          // cursor of the next stage to request
+    auto issue = [&](int stage) {
+        const int ky = MODE == 0 ? ltap / p.ksize : 0, kx = MODE == 0 ? ltap - ky * p.ksize : 0;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + stage * DG_STAGE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int iy, ix;
+            if (MODE == 0) { iy = py[i] * p.stride - p.pad + ky; ix = px[i] * p.stride - p.pad + kx; }
+            else { iy = py[i]; ix = px[i]; }
+            const bool ok = py[i] < MH && px[i] < MW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            // 32-bit element index (the entry checks B*H*W*Cin < 2^31): keeps the select a pair of v_cndmask, no branch
+            const unsigned idx = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + lchunk * F3_BK + cg[i]);
+            const float* src = ok ? p.in + idx : g_dma_zero + cg[i];
+            __builtin_amdgcn_global_load_lds((dg_gbl_void*)src, (dg_lds_void*)(size_t)(dst + i * 1024), 16, 0, 0);
+        }
+        const char* ws = wsrc + ((int64_t)ltap * kchunks + lchunk) * 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((dg_gbl_void*)(ws + i * 1024), (dg_lds_void*)(size_t)(dst + DG_BOFF + i * 1024),
+                                             16, 0, 0);
+        if (ltap * kchunks + lchunk + 1 < total) { if (++lchunk == kchunks) { lchunk = 0; ++ltap; } }
+    };
+
+    f32x16 c00, c01, c10, c11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned offA0 = (unsigned)(wm * 4096 + (fr & 1) * 1024 + (fr >> 1) * 64 + (((2 * fh) ^ dg_swz(fr)) * 16));
+    const unsigned offA1 = (unsigned)(wm * 4096 + (fr & 1) * 1024 + (fr >> 1) * 64 + (((2 * fh + 1) ^ dg_swz(fr)) * 16));
+    const unsigned offB = (unsigned)(DG_BOFF + (wn * 64 + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) * 16));
+
+    DgOps A, B;
+    auto finish = [&](DgOps& o, const dg_f32x4& r0l, const dg_f32x4& r0h, const dg_f32x4& r1l, const dg_f32x4& r1h) {
+        dg_split8(r0l, r0h, o.ah[0], o.al[0]);
+        dg_split8(r1l, r1h, o.ah[1], o.al[1]);
+        o.wd[0] = lift_down(o.wh[0]);
+        o.wd[1] = lift_down(o.wh[1]);
+    };
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) issue(s);
+    {
+        dg_wait_vm<4 * (NS - 1)>();                    // stage 0
+        __builtin_amdgcn_s_barrier();
+        dg_f32x4 r0l, r0h, r1l, r1h;
+        asm volatile("ds_read_b128 %0, %8\n\t"
+                     "ds_read_b128 %1, %9\n\t"
+                     "ds_read_b128 %2, %8 offset:2048\n\t"
+                     "ds_read_b128 %3, %9 offset:2048\n\t"
+                     "ds_read_b128 %4, %10\n\t"
+                     "ds_read_b128 %5, %10 offset:4096\n\t"
+                     "ds_read_b128 %6, %10 offset:1024\n\t"
+                     "ds_read_b128 %7, %10 offset:5120\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0l), "=&v"(r0h), "=&v"(r1l), "=&v"(r1h), "=&v"(A.wh[0]), "=&v"(A.wl[0]), "=&v"(A.wh[1]),
+                       "=&v"(A.wl[1])
+                     : "v"(smem_base + offA0), "v"(smem_base + offA1), "v"(smem_base + offB) : "memory");
+        finish(A, r0l, r0h, r1l, r1h);
+    }
+    int nstage = 1 % NS, fill = 0;
+    // one step: MFMAs on `cur`, fragments of the next stage -> `nxt`
+    auto step = [&](DgOps& cur, DgOps& nxt) {
+        dg_wait_vm<4 * (NS - 2)>();                    // this wave's share of the next stage has landed ...
+        __builtin_amdgcn_s_barrier();                  // ... everyone's has; every wave holds the current stage in registers
+        issue(fill);                                   // -> the current stage's buffer
+        const unsigned sb = smem_base + nstage * DG_STAGE;
+        dg_f32x4 r0l, r0h, r1l, r1h;
+        asm volatile("s_nop 1\n\t"
+                     "ds_read_b128 %0, %22\n\t"
+                     "ds_read_b128 %1, %23\n\t"
+                     "v_mfma_f32_32x32x16_f16 %8, %12, %16, %8\n\t"
+                     "v_mfma_f32_32x32x16_f16 %9, %12, %19, %9\n\t"
+                     "ds_read_b128 %2, %22 offset:2048\n\t"
+                     "ds_read_b128 %3, %23 offset:2048\n\t"
+                     "v_mfma_f32_32x32x16_f16 %10, %14, %16, %10\n\t"
+                     "v_mfma_f32_32x32x16_f16 %11, %14, %19, %11\n\t"
+                     "ds_read_b128 %4, %24\n\t"
+                     "ds_read_b128 %5, %24 offset:4096\n\t"
+                     "v_mfma_f32_32x32x16_f16 %8, %13, %17, %8\n\t"
+                     "v_mfma_f32_32x32x16_f16 %9, %13, %20, %9\n\t"
+                     "ds_read_b128 %6, %24 offset:1024\n\t"
+                     "ds_read_b128 %7, %24 offset:5120\n\t"
+                     "v_mfma_f32_32x32x16_f16 %10, %15, %17, %10\n\t"
+                     "v_mfma_f32_32x32x16_f16 %11, %15, %20, %11\n\t"
+                     "v_mfma_f32_32x32x16_f16 %8, %13, %18, %8\n\t"
+                     "v_mfma_f32_32x32x16_f16 %9, %13, %21, %9\n\t"
+                     "v_mfma_f32_32x32x16_f16 %10, %15, %18, %10\n\t"
+                     "v_mfma_f32_32x32x16_f16 %11, %15, %21, %11\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0l), "=&v"(r0h), "=&v"(r1l), "=&v"(r1h), "=&v"(nxt.wh[0]), "=&v"(nxt.wl[0]), "=&v"(nxt.wh[1]),
+                       "=&v"(nxt.wl[1]), "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
+                     : "v"(cur.al[0]), "v"(cur.ah[0]), "v"(cur.al[1]), "v"(cur.ah[1]),                    // 12..15
+                       "v"(cur.wd[0]), "v"(cur.wl[0]), "v"(cur.wh[0]), "v"(cur.wd[1]), "v"(cur.wl[1]), "v"(cur.wh[1]),   // 16..21
+                       "v"(sb + offA0), "v"(sb + offA1), "v"(sb + offB)                                   // 22..24
+                     : "memory");
+        finish(nxt, r0l, r0h, r1l, r1h);
+        nstage = nstage + 1 == NS ? 0 : nstage + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+    };
+    for (int s = 0; s < total; s += 2) {
+        step(A, B);
+        if (s + 1 < total) step(B, A);
+    }
+    dg_wait_vm<0>();                                   // the tail's dummy requests must not outlive the workgroup's LDS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the VALU reads them
+
+    const f32x16* accp[2][2] = {{&c00, &c01}, {&c10, &c11}};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale[n];
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+        float gsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x16& acc = *accp[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                if (y >= MH || x >= MW) continue;
+                float v = acc[r] * sc + sh;
+                if (p.relu) v = v <= 0.f ? 0.f : v;                   // NaN propagates, like torch.relu
+                int oy = y, ox = x;
+                if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
+                p.out[(((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n] = v;
+                gsum += v;
+            }
+        }
+        if (p.gap) {                                                  // as conv2d_f16x3_kernel
+            gsum += __shfl_xor(gsum, 32);
+            if (fh == 0) {
+                const int part = (((ty_ * p.tiles_x + tx_) * (MODE == 1 ? 4 : 1) + tap0) << 1) + wm;
+                p.gap[((int64_t)b * p.gap_parts + part) * p.ldc + p.coff + n] = gsum;
+            }
+        }
+    }
+}
+
+// planes [2][Cout][taps][Cin] -> [ceil(Cout/128)][taps][Cin/16][2 planes][128 rows][2 chunks of 8 f16]; chunk c of
+// row n sits at position c ^ ((n >> 3) & 1); rows >= Cout zero.  One (block, tap, chunk) = the 8 KB a stage holds.
+__global__ void pack_dma_kernel(const _Float16* __restrict__ planes, int Cout, int taps, int Cin,
+                                _Float16* __restrict__ out, int64_t count)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= count) return;
+    const int nchunks = Cin / 16;
+    int64_t r = o;
+    const int e = r % 8; r /= 8;
+    const int pos = r % 2; r /= 2;
+    const int nl = r % 128; r /= 128;
+    const int pl = r % 2; r /= 2;
+    const int chunk = r % nchunks; r /= nchunks;
+    const int tap = r % taps; r /= taps;
+    const int n = (int)r * 128 + nl;
+    const int c = pos ^ ((nl >> 3) & 1);
+    out[o] = n < Cout ? planes[(int64_t)pl * Cout * taps * Cin + ((int64_t)n * taps + tap) * Cin + chunk * 16 + 8 * c + e]
+                      : (_Float16)0.0f;
+}
+
+extern "C" int al3d_pack_f16x3_dma(const void* planes_f16x2, int Cout, int taps, int Cin, void* out_image, void* stream)
+{
+    AL3D_REQUIRE(planes_f16x2 && out_image, "al3d_pack_f16x3_dma: null pointer");
+    const int64_t count = al3d_pack_f16x3_bstream_elems(Cout, taps, Cin);     // same size: whole 128-row blocks
+    AL3D_REQUIRE(count > 0, "al3d_pack_f16x3_dma: needs Cin %% 16 == 0 (got Cout %d, taps %d, Cin %d)", Cout, taps, Cin);
+    hipLaunchKernelGGL(pack_dma_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)planes_f16x2, Cout, taps, Cin, (_Float16*)out_image, count);
+    AL3D_CHECK_LAUNCH("pack_dma_kernel");
+    return AL3D_OK;
+}
+
+static int dma_stages()
+{
+    static int ns = 0;
+    if (!ns) {
+        const char* e = getenv("AL3D_DMA_STAGES");
+        ns = e ? atoi(e) : 3;                          // 3 stages = 48 KB: three workgroups per CU (measured best)
+        if (ns != 3 && ns != 4 && ns != 5) ns = 3;
+    }
+    return ns;
+}
+
+static int dma_pipe()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AL3D_DMA_PIPE");
+        v = e ? atoi(e) != 0 : 1;
+    }
+    return v;
+}
+
+template <int MODE> static void launch_dma(const ConvF3Params& p, dim3 grid, hipStream_t s)
+{
+    if (dma_pipe()) {
+        if (dma_stages() == 5) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 5>), grid, dim3(256), 0, s, p);
+        else if (dma_stages() == 4) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3>), grid, dim3(256), 0, s, p);
+        return;
+    }
+    switch (dma_stages()) {
+    case 4: hipLaunchKernelGGL((conv2d_f16x3_dma_kernel<MODE, 4>), grid, dim3(256), 0, s, p); break;
+    case 5: hipLaunchKernelGGL((conv2d_f16x3_dma_kernel<MODE, 5>), grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((conv2d_f16x3_dma_kernel<MODE, 3>), grid, dim3(256), 0, s, p); break;
+    }
+}
+
+// gap_part may be null (no fused GAP); otherwise [B][gap_parts][ldc] with gap_parts >= al3d_gap_parts_count
+extern "C" int al3d_conv2d_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale,
+                                          const float* shift, float* out, int B, int H, int W, int Cin,
+                                          int Cout, int ksize, int stride, int pad, int ldc, int coff,
+                                          int relu, float* gap_part, int gap_parts, void* stream)
+{
+    ConvF3Params p;
+    p.gap = gap_part; p.gap_parts = gap_parts;
+    p.in = in; p.wgt = (const _Float16*)wgt_image; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    AL3D_REQUIRE(ksize >= 1 && ksize <= 7 && stride >= 1 && pad >= 0, "al3d_conv2d_nhwc_f16x3_dma: bad geometry");
+    p.OH = (H + 2 * pad - ksize) / stride + 1;
+    p.OW = (W + 2 * pad - ksize) / stride + 1;
+    AL3D_REQUIRE(p.OH >= 1 && p.OW >= 1, "al3d_conv2d_nhwc_f16x3_dma: empty output");
+    p.plane = 0;
+    int rc = convf3_check(p, "al3d_conv2d_nhwc_f16x3_dma");
+    if (rc) return rc;
+    AL3D_REQUIRE((int64_t)B * H * W * Cin < ((int64_t)1 << 31), "al3d_conv2d_nhwc_f16x3_dma: input above 2^31 elements");
+    AL3D_REQUIRE(!gap_part || gap_parts >= al3d_gap_parts_count(p.OH, p.OW, 0),
+                 "al3d_conv2d_nhwc_f16x3_dma: gap_parts must be at least al3d_gap_parts_count(OH, OW, 0)");
+    p.tiles_x = (int)al3d_cdiv(p.OW, F3_TW);
+    p.tiles_y = (int)al3d_cdiv(p.OH, F3_TH);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+    launch_dma<0>(p, dim3(f3_grid(p)), (hipStream_t)stream);
+    AL3D_CHECK_LAUNCH("conv2d_f16x3_dma_kernel<conv>");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_deconv2x2_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale,
+                                             const float* shift, float* out, int B, int H, int W, int Cin,
+                                             int Cout, int ldc, int coff, int relu, float* gap_part, int gap_parts,
+                                             void* stream)
+{
+    ConvF3Params p;
+    p.gap = gap_part; p.gap_parts = gap_parts;
+    p.in = in; p.wgt = (const _Float16*)wgt_image; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.ksize = 2; p.stride = 2; p.pad = 0; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    p.OH = 2 * H; p.OW = 2 * W;
+    p.plane = 0;
+    int rc = convf3_check(p, "al3d_deconv2x2_nhwc_f16x3_dma");
+    if (rc) return rc;
+    AL3D_REQUIRE((int64_t)B * H * W * Cin < ((int64_t)1 << 31), "al3d_deconv2x2_nhwc_f16x3_dma: input above 2^31 elements");
+    AL3D_REQUIRE(!gap_part || gap_parts >= al3d_gap_parts_count(p.OH, p.OW, 1),
+                 "al3d_deconv2x2_nhwc_f16x3_dma: gap_parts must be at least al3d_gap_parts_count(OH, OW, 1)");
+    p.tiles_x = (int)al3d_cdiv(W, F3_TW);
+    p.tiles_y = (int)al3d_cdiv(H, F3_TH);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = (int)al3d_cdiv(Cout, F3_BN);
+    launch_dma<1>(p, dim3(f3_grid(p), 1, 4), (hipStream_t)stream);
+    AL3D_CHECK_LAUNCH("conv2d_f16x3_dma_kernel<deconv>");
+    return AL3D_OK;
 }

@@ -79,9 +79,11 @@ def sparse_math():
     return MATH
 
 
-# structure of the f16x3 dense kernels: "auto" = weights streamed in fragment order (no LDS staging of
-# weights) where it pays, "bstream" = everywhere, "frag" = only the 3x3 layers, "lds" = the LDS-staged
-# kernels everywhere (same bits in all four), for A/B
+# structure of the f16x3 dense kernels: "auto" = 3x3/s1 layers on the fragment-streamed halo kernel, every other
+# geometry (stride-2 entry, 1x1 / deconv deblocks, fused head) on the LDS-DMA kernel; "stream" = round 1's policy
+# (generic launches with >= 24 steps stream their weights in fragment order, the others stage both tiles through
+# LDS), "bstream" = streamed weights everywhere, "frag" = only the 3x3 layers, "lds" = the LDS-staged kernels
+# everywhere.  The same bits in all of them; kept for A/B
 DENSE = _os.environ.get("AL3D_DENSE", "auto")
 
 
@@ -130,6 +132,19 @@ def pack_bstream_f16x3(planes):
     return F16x3Packed("bstream", out, cout, taps, cin)
 
 
+def pack_dma_f16x3(planes):
+    """f16 planes [2,Cout,taps,Cin] -> per-step LDS images for the LDS-DMA kernel of the generic geometries."""
+    planes = _dev(planes, torch.float16, "planes")
+    _, cout, taps, cin = planes.shape
+    n = lib.load().al3d_pack_f16x3_bstream_elems(cout, taps, cin)
+    if n <= 0:
+        raise lib.Al3dError(f"pack_dma_f16x3: unsupported shape Cout={cout} taps={taps} Cin={cin}")
+    out = torch.empty(((cout + 127) // 128, taps, cin // 16, 2, 128, 16), dtype=torch.float16, device=planes.device)
+    assert out.numel() == n
+    lib.call("al3d_pack_f16x3_dma", _ptr(planes), cout, taps, cin, _ptr(out), _stream())
+    return F16x3Packed("dma", out, cout, taps, cin)
+
+
 class GldsPacked:
     """f16x3 sparse-conv weights in the LDS image order of the DMA-gather kernel
     (al3d_sp_pack_glds_f16x3: [K][Cin/16][2][ceil32(Cout)][16] f16, halves swizzled)."""
@@ -168,8 +183,10 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
                 return pack_frag_f16x3(planes), scale
             # streamed weights pay off once a launch has enough steps to amortise the deeper prologue:
             # stride-2 3x3 (72 steps) -12 %, fused head (32) -5 %, 1x1 deblock (8) +8 % -> LDS-staged
+            if DENSE in ("auto", "dma"):
+                return pack_dma_f16x3(planes), scale
             steps = planes.shape[2] * planes.shape[3] // 16
-            if DENSE == "bstream" or (DENSE == "auto" and ksize != "deconv" and steps >= 24):
+            if DENSE == "bstream" or (DENSE == "stream" and ksize != "deconv" and steps >= 24):
                 return pack_bstream_f16x3(planes), scale
         return planes, scale
     if MATH == "bf16x6":
@@ -199,7 +216,10 @@ _DENSE_KIND = {torch.float32: "f32", torch.bfloat16: "bf16x6", torch.float16: "f
 
 
 def gap_fusable(w_packed):
-    """The fused-GAP epilogue exists in the generic f16x3 kernel (plain f16 planes: the deblock launches)."""
+    """The fused-GAP epilogue exists in the generic f16x3 kernels (plain f16 planes or LDS-DMA images: the deblock
+    launches)."""
+    if isinstance(w_packed, F16x3Packed):
+        return w_packed.kind == "dma"
     return isinstance(w_packed, torch.Tensor) and w_packed.dtype == torch.float16
 
 
@@ -228,10 +248,17 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
         elif pk.kind == "frag3x3":
             lib.call("al3d_conv3x3_nhwc_f16x3_frag", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
                      B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
+        elif pk.kind == "dma":
+            lib.call("al3d_conv2d_nhwc_f16x3_dma", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
+                     B, H, W, Cin, pk.cout, ksize, stride, pad, out.shape[3], coff, 1 if relu else 0,
+                     _ptr(gap), 0 if gap is None else gap.shape[1], _stream())
+            return out
         else:
             lib.call("al3d_conv2d_nhwc_f16x3_bstream", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift),
                      _ptr(out), B, H, W, Cin, pk.cout, ksize, stride, pad, out.shape[3], coff,
                      1 if relu else 0, _stream())
+        if gap is not None:
+            raise lib.Al3dError("conv2d_nhwc: this weight format has no fused GAP (see gap_fusable)")
         return out
     w_packed = _dev(w_packed, w_packed.dtype, "w")
     wshape = w_packed.shape[1:] if kind != "f32" else w_packed.shape
@@ -263,11 +290,18 @@ def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0, gap=None):
         raise lib.Al3dError("deconv2x2_nhwc: f16x3 weights need the scale returned by split_f16x3")
     if isinstance(w_packed, F16x3Packed):
         pk = w_packed
-        if pk.kind != "bstream" or pk.taps != 4 or pk.cin != Cin:
+        if pk.kind not in ("bstream", "dma") or pk.taps != 4 or pk.cin != Cin:
             raise lib.Al3dError("deconv2x2_nhwc: fragment-ordered weights do not match this layer")
         if out is None:
             out = torch.empty((B, 2 * H, 2 * W, pk.cout), dtype=torch.float32, device=x.device)
         assert out.shape[:3] == (B, 2 * H, 2 * W) and out.is_contiguous()
+        if pk.kind == "dma":
+            lib.call("al3d_deconv2x2_nhwc_f16x3_dma", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
+                     B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0,
+                     _ptr(gap), 0 if gap is None else gap.shape[1], _stream())
+            return out
+        if gap is not None:
+            raise lib.Al3dError("deconv2x2_nhwc: this weight format has no fused GAP (see gap_fusable)")
         lib.call("al3d_deconv2x2_nhwc_f16x3_bstream", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift),
                  _ptr(out), B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
         return out

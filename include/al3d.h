@@ -406,6 +406,20 @@ int al3d_deconv2x2_nhwc_f16x3_bstream(const float* in, const void* wgt_frag, con
                                       const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
                                       int ldc, int coff, int relu, void* stream);
 
+/* The same geometries with BOTH operands fetched by LDS-DMA (global_load_lds_dwordx4) into a ring of stages that
+ * runs 3 steps ahead: raw fp32 activation tile + weight tile from al3d_pack_f16x3_dma(): planes
+ * [2][Cout][taps][Cin] -> [ceil(Cout/128)][taps][Cin/16][2][128][16] f16 with the 16-byte halves of a row swizzled
+ * (the LDS image of a step; al3d_pack_f16x3_bstream_elems() elements).  The activation split runs on the fragment.
+ * gap_part may be NULL; otherwise as al3d_conv2d_nhwc_f16x3_gap.  Bit-identical to al3d_conv2d_nhwc_f16x3 /
+ * al3d_deconv2x2_nhwc_f16x3 (and their _gap partials). */
+int al3d_pack_f16x3_dma(const void* planes_f16x2, int Cout, int taps, int Cin, void* out_image, void* stream);
+int al3d_conv2d_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale, const float* shift,
+                               float* out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
+                               int ldc, int coff, int relu, float* gap_part, int gap_parts, void* stream);
+int al3d_deconv2x2_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale, const float* shift,
+                                  float* out, int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu,
+                                  float* gap_part, int gap_parts, void* stream);
+
 /* Fused global average pooling (feature_selector.py:68-71 tap): the two deblock launches of
  * the neck (1x1 conv and 2x2 transposed conv, rpn.py:124-142) can also emit, per workgroup and wave row, the channel
  * sums of the values they store -- gap_part [B][gap_parts][ldc], gap_parts >= al3d_gap_parts_count(OH, OW, deconv), the

@@ -245,6 +245,17 @@ def test_conv2d_f16x3_streamed_weights_equal_lds_staged_kernel(B, H, W, Cin, Cou
     D.conv2d_nhwc(x, D.pack_bstream_f16x3(w3), sc3, shift, k, s, p, True, out=b, coff=20)
     assert torch.equal(a, b)
     assert torch.all(b[..., :20] == -3.0)
+    # both operands by LDS-DMA, split on the fragment: the same bits again, and the same fused-GAP partials
+    c = torch.full((B, OH, OW, Cout + 20), -3.0, device=DEV)
+    parts = D.gap_parts(OH, OW, False)
+    ga = torch.full((B, parts + 3, Cout + 20), -7.0, device=DEV)
+    gc = torch.full((B, parts + 3, Cout + 20), -7.0, device=DEV)
+    D.conv2d_nhwc(x, w3, sc3, shift, k, s, p, True, out=a, coff=20, gap=ga)
+    D.conv2d_nhwc(x, D.pack_dma_f16x3(w3), sc3, shift, k, s, p, True, out=c, coff=20, gap=gc)
+    assert torch.equal(a, c) and torch.equal(ga, gc)
+    c.fill_(-3.0)
+    D.conv2d_nhwc(x, D.pack_dma_f16x3(w3), sc3, shift, k, s, p, True, out=c, coff=20)      # without the GAP
+    assert torch.equal(a, c)
 
 
 def test_deconv_f16x3_streamed_weights_equal_lds_staged_kernel():
@@ -261,6 +272,13 @@ def test_deconv_f16x3_streamed_weights_equal_lds_staged_kernel():
     D.deconv2x2_nhwc(x, D.pack_bstream_f16x3(w3), sc3, shift, True, out=b, coff=64)
     assert torch.equal(a, b)
     assert torch.all(b[..., :64] == -3.0)
+    c = torch.full((2, 66, 40, 264), -3.0, device=DEV)
+    parts = D.gap_parts(66, 40, True)
+    ga = torch.full((2, parts, 264), -7.0, device=DEV)
+    gc = torch.full((2, parts, 264), -7.0, device=DEV)
+    D.deconv2x2_nhwc(x, w3, sc3, shift, True, out=a, coff=64, gap=ga)
+    D.deconv2x2_nhwc(x, D.pack_dma_f16x3(w3), sc3, shift, True, out=c, coff=64, gap=gc)
+    assert torch.equal(a, c) and torch.equal(ga, gc)
 
 
 def test_deconv_f16x3_matches_f32_kernel():

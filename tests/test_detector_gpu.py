@@ -506,8 +506,11 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
             D.SPCONV = mode
             assert torch.equal(run(4), ref), mode
         D.SPCONV = saved[0]
-        D.DENSE = "lds"                             # f16x3: LDS-staged 3x3 kernel instead of the streamed one
-        assert torch.equal(run(4), ref), "dense lds"
+        # f16x3 dense structures: LDS-staged kernels everywhere / round 1's streamed-weight policy, against the
+        # default (3x3 streamed fragments + LDS-DMA kernel for the other geometries, fused GAP in all of them)
+        for mode in ("lds", "stream"):
+            D.DENSE = mode
+            assert torch.equal(run(4), ref), "dense " + mode
         D.DENSE = saved_dense
         for mode in (None, "ahead", "split"):
             S.PIPELINE = mode

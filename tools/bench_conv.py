@@ -23,6 +23,9 @@ for (H, Cin, Cout, k, s, p) in shapes:
     if MODE == 'f16x3frag16':
         w, sc = D.split_f16x3(w, sc)
         w = D.pack_frag16_f16x3(w) if (D.frag_ok(Cout, Cin, k, s, p) and Cin % 64 == 0) else D.pack_bstream_f16x3(w)
+    if MODE == 'f16x3dma':
+        w, sc = D.split_f16x3(w, sc)
+        w = D.pack_frag_f16x3(w) if D.frag_ok(Cout, Cin, k, s, p) else D.pack_dma_f16x3(w)
     if MODE == 'f16x3frag':
         w, sc = D.split_f16x3(w, sc)
         w = D.pack_frag_f16x3(w) if D.frag_ok(Cout, Cin, k, s, p) else D.pack_bstream_f16x3(w)
@@ -40,3 +43,26 @@ for (H, Cin, Cout, k, s, p) in shapes:
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * OH * OH * Cout * Cin * k * k
     print(f"{MODE} B={B} H={H} Cin={Cin} Cout={Cout} k={k} s={s}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
+
+# the 2x2 transposed convolution of the second deblock (rpn.py:124-142): [B,64,64,256] -> [B,128,128,256]
+if MODE.startswith("f16x3"):
+    x = torch.randn(B, 64, 64, 256, device=dev)
+    w = torch.randn(256, 4, 256, device=dev) * 0.05
+    sc = torch.ones(256, device=dev); sh = torch.zeros(256, device=dev)
+    w, sc = D.split_f16x3(w, sc)
+    if MODE == "f16x3dma":
+        w = D.pack_dma_f16x3(w)
+    elif MODE != "f16x3":
+        w = D.pack_bstream_f16x3(w)
+    out = torch.empty(B, 128, 128, 512, device=dev)
+    for _ in range(3):
+        D.deconv2x2_nhwc(x, w, sc, sh, True, out=out, coff=256)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        D.deconv2x2_nhwc(x, w, sc, sh, True, out=out, coff=256)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    fl = 2.0 * B * 64 * 64 * 4 * 256 * 256
+    print(f"{MODE} B={B} deconv 2x2 256->256: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
