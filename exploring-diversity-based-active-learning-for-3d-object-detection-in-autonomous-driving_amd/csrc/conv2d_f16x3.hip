@@ -1567,25 +1567,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_dma2_kernel(ConvF3Params 
     const char* wsrc = reinterpret_cast<const char*>(p.wgt) +
                        ((int64_t)nblk * wtaps + tap0) * kchunks * 8192 + wave * 2048 + lane * 16;
     int ltap = 0, lchunk = 0;                          // cursor of the next stage to request
+    // the pixel part of a lane's two source addresses changes only with the tap: recomputed when a tap starts
+    // (wave-uniform branch), then one 64-bit multiply-add per request.  Out-of-image pixels: zero row, stride 0.
+    const char* abase[2];
+    unsigned ainc[2];
     auto issue = [&](int stage) {
-        const int ky = MODE == 0 ? ltap / p.ksize : 0, kx = MODE == 0 ? ltap - ky * p.ksize : 0;
+        if (lchunk == 0) {
+            const int ky = MODE == 0 ? ltap / p.ksize : 0, kx = MODE == 0 ? ltap - ky * p.ksize : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int iy, ix;
+                if (MODE == 0) { iy = py[i] * p.stride - p.pad + ky; ix = px[i] * p.stride - p.pad + kx; }
+                else { iy = py[i]; ix = px[i]; }
+                const bool ok = py[i] < MH && px[i] < MW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                // 32-bit element index (the entry checks B*H*W*Cin < 2^31)
+                const unsigned idx = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + cg[i]);
+                abase[i] = reinterpret_cast<const char*>(ok ? p.in + idx : g_dma_zero + cg[i]);
+                ainc[i] = ok ? 4u * F3_BK : 0u;
+            }
+        }
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + stage * DG_STAGE + wave * 2048);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int iy, ix;
-            if (MODE == 0) { iy = py[i] * p.stride - p.pad + ky; ix = px[i] * p.stride - p.pad + kx; }
-            else { iy = py[i]; ix = px[i]; }
-            const bool ok = py[i] < MH && px[i] < MW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            // 32-bit element index (the entry checks B*H*W*Cin < 2^31): keeps the select a pair of v_cndmask, no branch
-            const unsigned idx = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + lchunk * F3_BK + cg[i]);
-            const float* src = ok ? p.in + idx : g_dma_zero + cg[i];
-            __builtin_amdgcn_global_load_lds((dg_gbl_void*)src, (dg_lds_void*)(size_t)(dst + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((dg_gbl_void*)(abase[i] + (size_t)lchunk * ainc[i]),
+                                             (dg_lds_void*)(size_t)(dst + i * 1024), 16, 0, 0);
         const char* ws = wsrc + ((int64_t)ltap * kchunks + lchunk) * 8192;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((dg_gbl_void*)(ws + i * 1024), (dg_lds_void*)(size_t)(dst + DG_BOFF + i * 1024),
                                              16, 0, 0);
+        // steps past the end re-fetch the last one (into a free stage): the DMA count per step stays 4
         if (ltap * kchunks + lchunk + 1 < total) { if (++lchunk == kchunks) { lchunk = 0; ++ltap; } }
     };
 

@@ -33,105 +33,8 @@
 // Arithmetic and summation order are EXACTLY sp_conv_wave2_kernel's (taps ascending, channel groups
 // ascending, al*wd then ah*wl then ah*wh into one fp32 accumulator): outputs are bit-identical, which
 // is what tests/test_detector_gpu.py::test_sparse_conv_glds_kernel_is_bit_identical checks.
-#include "al3d_common.h"
-#include <stdlib.h>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 gl_f16x2 __attribute__((ext_vector_type(2)));
-typedef float gl_f32x2 __attribute__((ext_vector_type(2)));
-typedef float gl_f32x4 __attribute__((ext_vector_type(4)));     // native vectors: inline-asm register operands
-typedef int gl_i32x4 __attribute__((ext_vector_type(4)));
-typedef int gl_i32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-__device__ __attribute__((aligned(256))) float g_glds_zero[128];     // stays zero: source of masked gathers
-__device__ __attribute__((aligned(256))) int g_glds_neg1[64] = {      // "no neighbour": index source of items past the end
-    -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
-    -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-
-template <int I> struct gl_int { static constexpr int value = I; };
-template <int N, int I = 0, class F> __device__ __forceinline__ void gl_static_for(F&& f)
-{
-    if constexpr (I < N) {
-        f(gl_int<I>{});
-        gl_static_for<N, I + 1>(f);
-    }
-}
-
-// ---- the f16x3 pieces, the same operations as spconv_wave.hip (bit-identical results)
-__device__ __forceinline__ void gl_split8_f16(const gl_f32x4& lo, const gl_f32x4& hi, f16x8& ph, f16x8& pl)
-{
-    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const gl_f32x2 x = {v[2 * e], v[2 * e + 1]};
-        const gl_f16x2 xh = __builtin_convertvector(x, gl_f16x2);
-        const gl_f32x2 r = {__builtin_fmaf((float)xh[0], -2048.0f, x[0] * 2048.0f),
-                            __builtin_fmaf((float)xh[1], -2048.0f, x[1] * 2048.0f)};
-        h[e] = __builtin_bit_cast(unsigned, xh);
-        l[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gl_f16x2));
-    }
-    ph = __builtin_bit_cast(f16x8, make_uint4(h[0], h[1], h[2], h[3]));
-    pl = __builtin_bit_cast(f16x8, make_uint4(l[0], l[1], l[2], l[3]));
-}
-__device__ __forceinline__ f16x8 gl_lift_down(const f16x8& wh)        // wh * 2^-11 (packed multiplies)
-{
-    return wh * (_Float16)0.00048828125f;
-}
-
-// ---- raw instructions the compiler must not reason about.  Every LDS read of the main loop is ONE asm block
-// that also contains its `s_waitcnt lgkmcnt(0)`: with the wait in a separate statement hipcc is free to copy a
-// destination register between the two (it did, merging the two arms of a branch) -- before the data arrived.
-__device__ __forceinline__ void gl_lds_read_idx(gl_i32x4& d, unsigned addr)
-{
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d) : "v"(addr) : "memory");
-}
-__device__ __forceinline__ void gl_lds_read_idx(gl_i32x2& d, unsigned addr)
-{
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d) : "v"(addr) : "memory");
-}
-// A fragment only (the B fragments of this (tap, chunk) are already in registers)
-__device__ __forceinline__ void gl_lds_read_a(gl_f32x4& lo, gl_f32x4& hi, unsigned a0, unsigned a1)
-{
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
-}
-// A fragment + the B fragments (wh, wl planes) of TN 32-column tiles; OFF = byte offset of the unit in the slab,
-// PL = byte distance of the two planes, 32 rows of a plane = 1 KiB
-template <int TN, int OFF, int PL>
-__device__ __forceinline__ void gl_lds_read_ab(gl_f32x4& lo, gl_f32x4& hi, f16x8 (&wh)[TN], f16x8 (&wl)[TN], unsigned a0,
-                                               unsigned a1, unsigned b)
-{
-    static_assert(TN == 1 || TN == 2 || TN == 4, "tile counts of the supported channel pairs");
-    if constexpr (TN == 1)
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\t"
-                     "ds_read_b128 %2, %6 offset:%7\n\tds_read_b128 %3, %6 offset:%8\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(lo), "=&v"(hi), "=&v"(wh[0]), "=&v"(wl[0])
-                     : "v"(a0), "v"(a1), "v"(b), "n"(OFF), "n"(OFF + PL) : "memory");
-    else if constexpr (TN == 2)
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\t"
-                     "ds_read_b128 %2, %8 offset:%9\n\tds_read_b128 %3, %8 offset:%10\n\t"
-                     "ds_read_b128 %4, %8 offset:%11\n\tds_read_b128 %5, %8 offset:%12\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(lo), "=&v"(hi), "=&v"(wh[0]), "=&v"(wl[0]), "=&v"(wh[1]), "=&v"(wl[1])
-                     : "v"(a0), "v"(a1), "v"(b), "n"(OFF), "n"(OFF + PL), "n"(OFF + 1024), "n"(OFF + PL + 1024) : "memory");
-    else
-        asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %11\n\t"
-                     "ds_read_b128 %2, %12 offset:%13\n\tds_read_b128 %3, %12 offset:%14\n\t"
-                     "ds_read_b128 %4, %12 offset:%15\n\tds_read_b128 %5, %12 offset:%16\n\t"
-                     "ds_read_b128 %6, %12 offset:%17\n\tds_read_b128 %7, %12 offset:%18\n\t"
-                     "ds_read_b128 %8, %12 offset:%19\n\tds_read_b128 %9, %12 offset:%20\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(lo), "=&v"(hi), "=&v"(wh[0]), "=&v"(wl[0]), "=&v"(wh[1]), "=&v"(wl[1]), "=&v"(wh[2]), "=&v"(wl[2]),
-                       "=&v"(wh[3]), "=&v"(wl[3])
-                     : "v"(a0), "v"(a1), "v"(b), "n"(OFF), "n"(OFF + PL), "n"(OFF + 1024), "n"(OFF + PL + 1024),
-                       "n"(OFF + 2048), "n"(OFF + PL + 2048), "n"(OFF + 3072), "n"(OFF + PL + 3072) : "memory");
-}
-template <int N> __device__ __forceinline__ void gl_wait_vm()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+#include "glds_common.h"
+#include "sp_rows.h"
 
 template <int CIN, int COUT, int NW, int R, int UPS, int P, int NB>
 struct GldsCfg {
@@ -187,7 +90,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void sp_conv_glds_kernel(const float
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
                                                                     const float* __restrict__ residual, int relu,
-                                                                    float* __restrict__ fout, int n_out)
+                                                                    float* __restrict__ fout, int n_out, int io)
 {
     using C = GldsCfg<CIN, COUT, NW, R, UPS, P, NB>;
     constexpr int KG = C::KG, CH = C::CH, UA = C::UA, NCC = C::NCC, TN = C::TN, NROWS = C::NROWS;
@@ -398,7 +301,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void sp_conv_glds_kernel(const float
                     else
                         gl_lds_read_a(lo, hi, sA + offA[ua][0], sA + offA[ua][1]);
                     f16x8 ah, al;
-                    gl_split8_f16(lo, hi, ah, al);
+                    if (io & SP_IO_IN_PAIR) {                                  // pair rows: the fragment IS the operand pair
+                        ah = __builtin_bit_cast(f16x8, lo);
+                        al = __builtin_bit_cast(f16x8, hi);
+                    } else {
+                        gl_split8_f16(lo, hi, ah, al);
+                    }
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn) {
                         const f16x8 wd = gl_lift_down(wh[ua][jn]);
@@ -425,36 +333,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void sp_conv_glds_kernel(const float
         if (wrow0 >= n_out) break;                                           // wave-uniform
 #pragma unroll
         for (int j2 = 0; j2 < TN; ++j2) {
-            const int live = COUT - j2 * 32 < 32 ? COUT - j2 * 32 : 32;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 scr[((e & 3) + 8 * (e >> 2) + 4 * fh) * EP_PITCH + fr] = acc[r][j2][e];
             __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
-            const int q = live / 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = lane + 64 * i;
-                if (idx >= 32 * q) continue;
-                const int rl = idx / q, c4 = (idx - rl * q) * 4;
-                const int row = wrow0 + rl;
-                if (row >= n_out) continue;
-                const int n = j2 * 32 + c4;
-                float4 v = *reinterpret_cast<const float4*>(scr + rl * EP_PITCH + c4);
-                const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-                const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                const int64_t o = (int64_t)row * COUT + n;
-                if (residual) {
-                    const float4 rs = *reinterpret_cast<const float4*>(residual + o);
-                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-                }
-                if (relu) {                                                  // NaN propagates, like torch.relu
-                    v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
-                    v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
-                }
-                *reinterpret_cast<float4*>(fout + o) = v;
-            }
+            sp_store_tile<COUT, EP_PITCH>(scr, lane, j2, wrow0, n_out, scale, shift, residual, relu, fout, io);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -504,15 +388,37 @@ extern "C" int al3d_sp_pack_glds_f16x3(const void* planes_f16x2, int cout, int K
     if (cin == CI && cout == CO) {                                                                      \
         hipLaunchKernelGGL((sp_conv_glds_kernel<CI, CO, NW, R, UPS, P, NB, ABL>),                       \
                            dim3((unsigned)al3d_cdiv(ntiles, NW * R)), dim3(64 * (NW + 1)), 0, s, fin, nbr, nbr_pitch, \
-                           tile_mask, ntiles, (const unsigned char*)wgt_image, scale, shift, residual, relu, fout, n_out); \
+                           tile_mask, ntiles, (const unsigned char*)wgt_image, scale, shift, residual, relu, fout, n_out, io); \
         AL3D_CHECK_LAUNCH("sp_conv_glds_kernel");                                                       \
         return AL3D_OK;                                                                                 \
     }
 #define GLDS_DISPATCH(CI, CO, NW, R, UPS, P, NB) GLDS_DISPATCH_ABL(CI, CO, NW, R, UPS, P, NB, 0)
 
+static int sp_conv_glds_impl(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                             const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
+                             const float* residual, int relu, float* fout, int n_out, int io, void* stream);
+
 extern "C" int al3d_sp_conv_glds_f16x3(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
                                        const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
                                        const float* residual, int relu, float* fout, int n_out, void* stream)
+{
+    return sp_conv_glds_impl(fin, nbr, nbr_pitch, tile_mask, K, wgt_image, cin, cout, scale, shift, residual, relu, fout, n_out,
+                             0, stream);
+}
+
+// ... with the row formats of sp_rows.h: io bit 0 = input pair rows, bit 1 = write pair rows, bit 2 = residual pair rows
+extern "C" int al3d_sp_conv_glds_f16x3_io(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                                          const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
+                                          const float* residual, int relu, float* fout, int n_out, int io, void* stream)
+{
+    AL3D_REQUIRE(io >= 0 && io < 8 && cout % 8 == 0, "al3d_sp_conv_glds_f16x3_io: bad io flags / channels");
+    return sp_conv_glds_impl(fin, nbr, nbr_pitch, tile_mask, K, wgt_image, cin, cout, scale, shift, residual, relu, fout, n_out,
+                             io, stream);
+}
+
+static int sp_conv_glds_impl(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                             const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
+                             const float* residual, int relu, float* fout, int n_out, int io, void* stream)
 {
     AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_glds_f16x3: bad sizes");
     if (n_out == 0) return AL3D_OK;

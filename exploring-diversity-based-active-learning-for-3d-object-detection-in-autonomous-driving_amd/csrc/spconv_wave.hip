@@ -11,6 +11,7 @@
 // are empty for their own 32 rows and otherwise run unsynchronised, so gather latency is hidden
 // by the other waves on the SIMD instead of by a software pipeline.
 #include "al3d_common.h"
+#include "sp_rows.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -243,9 +244,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ residual, int relu,
                                                             float* __restrict__ fout, int n_out,
-                                                            int64_t pitch, const unsigned* __restrict__ tmask)
+                                                            int64_t pitch, const unsigned* __restrict__ tmask, int io)
 {
-    // pitch: row pitch of the tap-major table (n_out for the plain rulebook, al3d_sp_table_pitch(n_out) for the tiled
+    // io: row formats (sp_rows.h; f16x3 only).  pitch: row pitch of the tap-major table (n_out for the plain rulebook, al3d_sp_table_pitch(n_out) for the tiled
     // one); tmask: per-32-row-tile tap masks of a tiled rulebook (or null: the masks are scanned from the table)
     constexpr int KG = CIN / 16;
     constexpr int TN = (COUT + 31) / 32;
@@ -431,7 +432,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
                         }
                     } else {
                         f16x8 ah, al;
-                        sw_split8_f16(dlo[slot], dhi[slot], ah, al);
+                        if (io & SP_IO_IN_PAIR) {                              // pair rows: the fragment IS the operand pair
+                            ah = __builtin_bit_cast(f16x8, dlo[slot]);
+                            al = __builtin_bit_cast(f16x8, dhi[slot]);
+                        } else {
+                            sw_split8_f16(dlo[slot], dhi[slot], ah, al);
+                        }
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             const int n = j * 32 + fr;
@@ -478,36 +484,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
         if (wave / EP_WAVES != round) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int live = COUT - j * 32 < 32 ? COUT - j * 32 : 32;    // live columns of this tile (compile-time)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 scr[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP_PITCH + fr] = acc[j][r];
             __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the tile is in LDS (wave-private)
             __builtin_amdgcn_wave_barrier();
-            const int q = live / 4;                                   // float4s per row
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = lane + 64 * i;
-                if (idx >= 32 * q) continue;
-                const int rl = idx / q, c4 = (idx - rl * q) * 4;
-                const int row = wrow0 + rl;
-                if (row >= n_out) continue;
-                const int n = j * 32 + c4;
-                float4 v = *reinterpret_cast<const float4*>(scr + rl * EP_PITCH + c4);
-                const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-                const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                const int64_t o = (int64_t)row * COUT + n;
-                if (residual) {
-                    const float4 rs = *reinterpret_cast<const float4*>(residual + o);
-                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-                }
-                if (relu) {                                           // NaN propagates, like torch.relu
-                    v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
-                    v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
-                }
-                *reinterpret_cast<float4*>(fout + o) = v;
-            }
+            sp_store_tile<COUT, EP_PITCH>(scr, lane, j, wrow0, n_out, scale, shift, residual, relu, fout, io);
             __builtin_amdgcn_wave_barrier();                          // scratch is rewritten by the next tile
         }
     }
@@ -518,7 +500,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 8)))
         hipLaunchKernelGGL((sp_conv_wave2_kernel<CI, CO, NW, UPS, P, NPL>),                           \
                            dim3((unsigned)al3d_cdiv(n_out, 32 * NW)), dim3(64 * NW), 0, s, fin, nbr, K, \
                            (const unsigned short*)wgt, scale, shift, residual, relu, fout, n_out,     \
-                           (int64_t)nbr_pitch, tile_mask);                                            \
+                           (int64_t)nbr_pitch, tile_mask, io);                                        \
         AL3D_CHECK_LAUNCH("sp_conv_wave2_kernel");                                                    \
         return AL3D_OK;                                                                               \
     }
@@ -533,7 +515,7 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
     AL3D_REQUIRE(fin && nbr && wgt_bf16x3 && fout, "al3d_sp_conv_wave2_bf16x6: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const void* wgt = wgt_bf16x3;
-    const int nbr_pitch = n_out;
+    const int nbr_pitch = n_out, io = 0;
     const unsigned* tile_mask = nullptr;
     SW2_DISPATCH(16, 16, 4, 4, 4, 3) SW2_DISPATCH(16, 32, 8, 2, 2, 3) SW2_DISPATCH(32, 32, 8, 2, 2, 3) SW2_DISPATCH(32, 64, 8, 4, 2, 3)
     SW2_DISPATCH(64, 64, 8, 4, 2, 3) SW2_DISPATCH(64, 128, 16, 2, 2, 3) SW2_DISPATCH(128, 128, 16, 2, 2, 3)
@@ -542,7 +524,7 @@ extern "C" int al3d_sp_conv_wave2_bf16x6(const float* fin, const int* nbr, int K
 
 static int sp_conv_wave2_f16x3_impl(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
                                     const void* wgt_f16x2, int cin, int cout, const float* scale, const float* shift,
-                                    const float* residual, int relu, float* fout, int n_out, void* stream);
+                                    const float* residual, int relu, float* fout, int n_out, int io, void* stream);
 
 extern "C" int al3d_sp_conv_wave2_f16x3(const float* fin, const int* nbr, int K, const void* wgt_f16x2,
                                         int cin, int cout, const float* scale, const float* shift,
@@ -550,7 +532,7 @@ extern "C" int al3d_sp_conv_wave2_f16x3(const float* fin, const int* nbr, int K,
                                         void* stream)
 {
     return sp_conv_wave2_f16x3_impl(fin, nbr, n_out, nullptr, K, wgt_f16x2, cin, cout, scale, shift, residual, relu, fout,
-                                    n_out, stream);
+                                    n_out, 0, stream);
 }
 
 // the same kernel on a tiled rulebook (al3d_sp_*_table_tiles): pitched table, per-tile tap masks read instead of scanned
@@ -562,12 +544,25 @@ extern "C" int al3d_sp_conv_wave2_f16x3_tiles(const float* fin, const int* nbr, 
     AL3D_REQUIRE(tile_mask && nbr_pitch >= n_out && nbr_pitch % 256 == 0,
                  "al3d_sp_conv_wave2_f16x3_tiles: needs a tiled rulebook (pitch = al3d_sp_table_pitch(n_out), tile masks)");
     return sp_conv_wave2_f16x3_impl(fin, nbr, nbr_pitch, tile_mask, K, wgt_f16x2, cin, cout, scale, shift, residual, relu,
-                                    fout, n_out, stream);
+                                    fout, n_out, 0, stream);
+}
+
+// ... with the row formats of sp_rows.h: io bit 0 = input pair rows, bit 1 = write pair rows, bit 2 = residual pair rows
+extern "C" int al3d_sp_conv_wave2_f16x3_tiles_io(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask,
+                                                 int K, const void* wgt_f16x2, int cin, int cout, const float* scale,
+                                                 const float* shift, const float* residual, int relu, float* fout, int n_out,
+                                                 int io, void* stream)
+{
+    AL3D_REQUIRE(tile_mask && nbr_pitch >= n_out && nbr_pitch % 256 == 0,
+                 "al3d_sp_conv_wave2_f16x3_tiles_io: needs a tiled rulebook (pitch = al3d_sp_table_pitch(n_out), tile masks)");
+    AL3D_REQUIRE(io >= 0 && io < 8 && cin % 8 == 0 && cout % 8 == 0, "al3d_sp_conv_wave2_f16x3_tiles_io: bad io flags / channels");
+    return sp_conv_wave2_f16x3_impl(fin, nbr, nbr_pitch, tile_mask, K, wgt_f16x2, cin, cout, scale, shift, residual, relu,
+                                    fout, n_out, io, stream);
 }
 
 static int sp_conv_wave2_f16x3_impl(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
                                     const void* wgt_f16x2, int cin, int cout, const float* scale, const float* shift,
-                                    const float* residual, int relu, float* fout, int n_out, void* stream)
+                                    const float* residual, int relu, float* fout, int n_out, int io, void* stream)
 {
     AL3D_REQUIRE(K >= 1 && K <= 27 && n_out >= 0, "al3d_sp_conv_wave2_f16x3: bad sizes");
     if (n_out == 0) return AL3D_OK;

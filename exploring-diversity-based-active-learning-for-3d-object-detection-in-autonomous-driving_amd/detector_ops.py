@@ -194,9 +194,10 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
     return w_packed, scale
 
 
-# sparse-conv structure.  f16x3: "auto" = per channel pair whichever of the two kernels measured faster on the real
-# rulebooks (GLDS_PAIRS: the LDS-DMA gather kernel, else the register-gather wave kernel), "glds" / "wave2" = one of
-# them everywhere (same bits either way).  bf16x6: "auto" = the software-pipelined wave kernel; "wave" (unpipelined
+# sparse-conv structure.  f16x3: "auto" = per channel pair whichever kernel measured fastest on the real rulebooks
+# (RNG_PAIRS: range-gather LDS-DMA kernel for the 27-tap submanifold layers; GLDS_PAIRS: per-tap LDS-DMA gather; else
+# the register-gather wave kernel), "glds" / "wave2" = one of those everywhere, "rng" = range gather wherever built
+# (same bits in all of them for Cin <= 32; see al3d_sp_conv_rng_f16x3 for Cin = 64).  bf16x6: "auto" = the software-pipelined wave kernel; "wave" (unpipelined
 # wave kernel) and "tile" (LDS-staged 128-row tile) give the same bits, for A/B
 SPCONV = _os.environ.get("AL3D_SPCONV", "auto")
 GLDS_PAIRS = {(32, 32), (64, 64)}
@@ -204,11 +205,43 @@ if _os.environ.get("AL3D_GLDS_PAIRS"):           # dev override, e.g. "32x32,64x
     GLDS_PAIRS = {tuple(int(v) for v in t.split("x")) for t in _os.environ["AL3D_GLDS_PAIRS"].split(",")}
 
 
-def sparse_glds(cin=None, cout=None):
-    """True when the f16x3 sparse layer cin -> cout runs on the LDS-DMA gather kernel (no arguments: any layer may)."""
-    if MATH != "f16x3" or SPCONV not in ("auto", "glds"):
+# row format of the f16x3 sparse encoder's activations between layers (csrc/sp_rows.h): "pair" = the two f16 planes
+# of the arithmetic, split once in the producer's epilogue; "f32" = plain rows, split per gathered (row, tap)
+SPROWS = _os.environ.get("AL3D_SPROWS", "pair")
+IO_IN_PAIR, IO_OUT_PAIR, IO_RES_PAIR = 1, 2, 4
+
+
+def rows_convert(x, to_pair):
+    """[n, C] f32 rows <-> pair rows (same shape and dtype; C % 8 == 0)."""
+    x = _dev(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    lib.call("al3d_sp_rows_convert_f16x3", _ptr(x), x.shape[0], x.shape[1], 1 if to_pair else 0, _ptr(out), _stream())
+    return out
+
+
+# the range-gather form of the LDS-DMA kernel (27-tap submanifold layers of these channel pairs; "rng" = wherever it
+# is built, "auto" = RNG_PAIRS, measured)
+RNG_BUILT = {(32, 32), (64, 64)}
+RNG_PAIRS = set()             # measured: the per-tap kernel stays ahead (DESIGN 5.6); AL3D_SPCONV=rng to run it
+if _os.environ.get("AL3D_RNG_PAIRS") is not None:   # dev override, e.g. "32x32,64x64" or "" for none
+    RNG_PAIRS = {tuple(int(v) for v in t.split("x")) for t in _os.environ["AL3D_RNG_PAIRS"].split(",") if t}
+
+
+def sparse_rng(cin, cout):
+    """True when the 27-tap submanifold f16x3 layer cin -> cout runs on the range-gather kernel."""
+    if MATH != "f16x3" or SPCONV not in ("auto", "rng"):
         return False
-    return SPCONV == "glds" or cin is None or (cin, cout) in GLDS_PAIRS
+    return (cin, cout) in (RNG_BUILT if SPCONV == "rng" else RNG_PAIRS & RNG_BUILT)
+
+
+def sparse_glds(cin=None, cout=None):
+    """True when the f16x3 sparse layer cin -> cout gets the LDS-DMA kernels' weight image (no arguments: any layer
+    may): the per-tap gather kernel, or the range-gather kernel where sparse_rng says so."""
+    if MATH != "f16x3" or SPCONV not in ("auto", "glds", "rng"):
+        return False
+    if cin is None or SPCONV == "glds":
+        return True
+    return (cin, cout) in GLDS_PAIRS or sparse_rng(cin, cout)
 
 
 # ------------------------------------------------------------------ kernels
@@ -413,7 +446,7 @@ MFMA_PAIRS = {(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128,
 
 
 def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad, subm,
-                      scale=None, shift=None, residual=None, relu=False, mfma=None):
+                      scale=None, shift=None, residual=None, relu=False, mfma=None, io=0):
     """One spconv layer on device (building block of the encoder, also used by the tests).
     feats [n,Cin] f32, coords [n,4] i32 (b,z,y,x), weight [kz,ky,kx,Cin,Cout].
     Returns (fout [n_out,Cout], coords_out [n_out,4], out_shape)."""
@@ -432,7 +465,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
     if mfma is None:
         mfma = (cin, cout) in MFMA_PAIRS and ({"bf16x6": "wave2", "f16x3": "glds_f16x3" if sparse_glds(cin, cout) else "wave2_f16x3"}
                                                .get(sparse_math(), True))
-    tiled = mfma in ("glds_f16x3", "wave2_f16x3_tiles")     # pitched table + per-tile tap masks (al3d_sp_*_table_tiles)
+    tiled = mfma in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3")     # pitched table + per-tile tap masks
     tmask = None
     if subm:
         if tiled:
@@ -469,15 +502,26 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
             lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
                      _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    if io and mfma not in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3"):
+        raise lib.Al3dError("sparse_conv_layer: pair rows exist for the tiled f16x3 kernels only")
     if mfma == "glds_f16x3":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
         pk = pack_glds_f16x3(w3)
-        lib.call("al3d_sp_conv_glds_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(pk.data), cin,
-                 cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+        lib.call("al3d_sp_conv_glds_f16x3_io", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(pk.data), cin,
+                 cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, io, st)
+    elif mfma == "rng_f16x3":
+        if not subm or K != 27:
+            raise lib.Al3dError("sparse_conv_layer: the range-gather kernel serves 27-tap submanifold layers")
+        w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
+        pk = pack_glds_f16x3(w3)
+        trng = torch.empty((nbr.shape[1] // 32, 9, 2), dtype=torch.int32, device=dev)
+        lib.call("al3d_sp_tile_ranges", _ptr(nbr), nbr.shape[1], K, n_out, _ptr(trng), st)
+        lib.call("al3d_sp_conv_rng_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), _ptr(trng), K,
+                 _ptr(pk.data), cin, cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, io, st)
     elif mfma == "wave2_f16x3_tiles":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
-        lib.call("al3d_sp_conv_wave2_f16x3_tiles", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(w3), cin,
-                 cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, st)
+        lib.call("al3d_sp_conv_wave2_f16x3_tiles_io", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(w3), cin,
+                 cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, io, st)
     elif mfma == "wave2_f16x3":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
         lib.call("al3d_sp_conv_wave2_f16x3", _ptr(feats), _ptr(nbr), K, _ptr(w3), cin, cout, _ptr(sc3),

@@ -82,6 +82,14 @@ SIGNATURES = {
     "al3d_sp_pack_glds_f16x3": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
     "al3d_sp_conv_glds_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
                                         c_p, c_int, c_p]),
+    "al3d_sp_tile_ranges": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p]),
+    "al3d_sp_conv_rng_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
+                                       c_p, c_int, c_int, c_p]),
+    "al3d_sp_rows_convert_f16x3": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p]),
+    "al3d_sp_conv_glds_f16x3_io": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
+                                           c_p, c_int, c_int, c_p]),
+    "al3d_sp_conv_wave2_f16x3_tiles_io": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
+                                                  c_p, c_int, c_int, c_p]),
     "al3d_sp_conv_wave2_f16x3_tiles": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
                                                c_p, c_int, c_p]),
     "al3d_sp_table_pitch": (c_int, [c_int]),

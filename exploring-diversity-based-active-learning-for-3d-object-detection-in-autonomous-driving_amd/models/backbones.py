@@ -63,10 +63,17 @@ class SparseBasicBlock(nn.Module):
 class SparseTensor:
     """Minimal stand-in for spconv.SparseConvTensor: features [N,C] f32, indices [N,4] i32."""
 
-    def __init__(self, features, indices, spatial_shape, batch_size):
-        self.features = features
+    def __init__(self, features, indices, spatial_shape, batch_size, pair_rows=False):
+        # pair_rows: ``features`` is in the f16x3 kernels' pair-row format (csrc/sp_rows.h); converted on first access
+        self._features, self._pair = features, pair_rows
         self.indices = indices
         self.spatial_shape, self.batch_size = list(spatial_shape), batch_size
+
+    @property
+    def features(self):
+        if self._pair:
+            self._features, self._pair = D.rows_convert(self._features, to_pair=False), False
+        return self._features
 
 
 def _bn(c):
@@ -152,23 +159,32 @@ class _SparseEncoderBase(nn.Module):
         return w.contiguous().to(device), scale
 
     @staticmethod
-    def _conv(m, feats, nbr, K, step, residual, out, n, st, tmask=None):
+    def _conv(m, feats, nbr, K, step, residual, out, n, st, tmask=None, trng=None, io=0):
         """One fused sparse layer (conv + folded BN + optional residual + ReLU)."""
         res_ptr = None if residual is None else _ptr(residual)
         cin = feats.shape[-1]                    # == m.in_channels, or 16 for a zero-padded narrow first layer
         mfma_pair = (cin, m.out_channels) in MFMA_PAIRS
+        if mfma_pair and isinstance(step["w"], D.GldsPacked) and trng is not None and m.subm and K == 27 and \
+                D.sparse_rng(cin, m.out_channels):
+            # f16x3 arithmetic, LDS-DMA range gather: one staged index range per (tile, kz, ky) serves three taps
+            lib.call("al3d_sp_conv_rng_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), _ptr(trng), K,
+                     _ptr(step["w"].data), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr,
+                     1, _ptr(out), n, io, st)
+            return
         if mfma_pair and isinstance(step["w"], D.GldsPacked):
             # f16x3 arithmetic, LDS-DMA row gather (full-line fetches) + producer-wave weight slabs
-            lib.call("al3d_sp_conv_glds_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K,
+            lib.call("al3d_sp_conv_glds_f16x3_io", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K,
                      _ptr(step["w"].data), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr,
-                     1, _ptr(out), n, st)
+                     1, _ptr(out), n, io, st)
             return
         if mfma_pair and step["w"].dtype == torch.float16 and tmask is not None:
             # f16x3 arithmetic, software-pipelined register-gather wave kernel on the tiled rulebook
-            lib.call("al3d_sp_conv_wave2_f16x3_tiles", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K,
+            lib.call("al3d_sp_conv_wave2_f16x3_tiles_io", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K,
                      _ptr(step["w"]), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1,
-                     _ptr(out), n, st)
+                     _ptr(out), n, io, st)
             return
+        if io:
+            raise lib.Al3dError("sparse encoder: pair rows reached a layer without a tiled f16x3 kernel")
         if mfma_pair and step["w"].dtype == torch.float16:
             fn = "al3d_sp_conv_wave2_f16x3"           # the same kernel on a plain table
         elif mfma_pair and step["w"].dtype == torch.bfloat16:
@@ -211,7 +227,7 @@ class _SparseEncoderBase(nn.Module):
         lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W, _ptr(lv.grid),
                  1, st)
         used = [(lv, coords, n)]
-        nbr, nbr_key = None, None
+        nbr, nbr_key, trng = None, None, None
         steps = []
         for step in self._plan:
             if step["kind"] == "stage_end":
@@ -236,7 +252,12 @@ class _SparseEncoderBase(nn.Module):
                         lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
                                  _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
                     nbr_key = key
-                steps.append(dict(nbr=nbr, n=n, K=K, tmask=tmask))
+                    trng = None
+                if tiled and trng is None and K == 27 and D.sparse_rng(self._pad_cin(m), m.out_channels):
+                    # (lo, len) of every (tile, kz, ky) group: once per table, shared by the level's layers
+                    trng = torch.empty((max(nbr.shape[1] // 32, 1), 9, 2), dtype=torch.int32, device=dev)
+                    lib.call("al3d_sp_tile_ranges", _ptr(nbr), nbr.shape[1], K, n, _ptr(trng), st)
+                steps.append(dict(nbr=nbr, n=n, K=K, tmask=tmask, trng=trng))
             else:
                 oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
                 olv = self._level(oshape, batch_size, dev)
@@ -281,20 +302,41 @@ class _SparseEncoderBase(nn.Module):
         st = _stream()
         feats = feats.float().contiguous()
         middle = []
-        identity = None
+        identity, identity_pair = None, False
+        # f16x3: between two layers that both run a tiled matrix-core kernel the rows travel as pair rows (the
+        # producer's epilogue splits once; csrc/sp_rows.h).  The first layer reads the VFE's f32 rows, the last one
+        # writes f32 rows for the dense scatter.
+        def pairable(step_, b_):
+            return (D.SPROWS == "pair" and step_["kind"] != "stage_end" and b_.get("tmask") is not None and
+                    (self._pad_cin(step_["mod"]), step_["mod"].out_channels) in MFMA_PAIRS and
+                    (isinstance(step_["w"], D.GldsPacked) or (isinstance(step_["w"], torch.Tensor) and
+                                                              step_["w"].dtype == torch.float16)))
+        convs = [(s_, b_) for s_, b_ in zip(self._plan, book["steps"]) if s_["kind"] != "stage_end"]
+        ci, pair = 0, False
         for step, b in zip(self._plan, book["steps"]):
             if step["kind"] == "stage_end":
-                middle.append(SparseTensor(feats, b["coords"], b["shape"], batch_size))
+                middle.append(SparseTensor(feats, b["coords"], b["shape"], batch_size, pair_rows=pair))
                 continue
             m = step["mod"]
             if feats.shape[-1] != self._pad_cin(m):
+                assert not pair
                 feats = torch.nn.functional.pad(feats, (0, self._pad_cin(m) - feats.shape[-1]))
             if step.get("block_start"):
-                identity = feats
+                identity, identity_pair = feats, pair
+            ok = pairable(step, b)
+            assert ok or not pair, "pair rows reached a layer that cannot read them"
+            # 16-channel rows stay f32: on the level-0 layers the pair-row epilogue costs more (+12 %) than the
+            # consumers gain (-3 %); from 32 channels on the consumers are the LDS-DMA kernels (-5..10 %)
+            out_pair = ok and ci + 1 < len(convs) and pairable(*convs[ci + 1]) and m.out_channels >= 32
+            res = identity if step.get("residual") else None
+            io = ((D.IO_IN_PAIR if pair else 0) | (D.IO_OUT_PAIR if out_pair else 0) |
+                  (D.IO_RES_PAIR if (res is not None and identity_pair) else 0))
             out = torch.empty((b["n"], m.out_channels), dtype=torch.float32, device=dev)
-            self._conv(m, feats, b["nbr"], b["K"], step, identity if step.get("residual") else None, out, b["n"], st,
-                       tmask=b.get("tmask"))
-            feats = out
+            self._conv(m, feats, b["nbr"], b["K"], step, res, out, b["n"], st,
+                       tmask=b.get("tmask"), trng=b.get("trng"), io=io)
+            feats, pair = out, out_pair
+            ci += 1
+        assert not pair
         last = middle[-1]
         return SparseTensor(feats, last.indices, last.spatial_shape, batch_size), middle
 

@@ -314,6 +314,33 @@ int al3d_sp_pack_glds_f16x3(const void* planes_f16x2, int cout, int K, int cin, 
 int al3d_sp_conv_glds_f16x3(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
                             const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
                             const float* residual, int relu, float* fout, int n_out, void* stream);
+
+/* Range-gather form of the same layer (27-tap submanifold only; csrc/spconv_rng.hip): the three kx taps of a
+ * (kz, ky) group share ONE staged index range [lo, lo + len) of input rows -- tile_rng [ceil(n_out/32)][9][2] =
+ * (lo, len) from al3d_sp_tile_ranges on the same tiled table (len 0: no neighbour; len > 48: the group is gathered
+ * row by row).  Same weight image, same contract otherwise; bit-identical to al3d_sp_conv_glds_f16x3 for Cin = 32
+ * (with more than one 32-channel chunk the chunks of a group are summed before the next group: last-bit differences,
+ * the same error class). */
+int al3d_sp_tile_ranges(const int* nbr, int64_t nbr_pitch, int K, int n_out, int* out_rng, void* stream);
+int al3d_sp_conv_rng_f16x3(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask,
+                           const int* tile_rng, int K, const void* wgt_image, int cin, int cout, const float* scale,
+                           const float* shift, const float* residual, int relu, float* fout, int n_out, int io,
+                           void* stream);
+
+/* Row formats of the sparse encoder's activations (csrc/sp_rows.h).  "pair rows" hold, per 8 channels, the two f16
+ * planes the f16x3 arithmetic multiplies with (16 B xh = f16(x), 16 B xl' = f16((x - xh) 2^11)) in the 32 bytes of
+ * the 8 floats: a consumer's fragment load is its MFMA operand pair and the split runs once, in the producer's
+ * epilogue, instead of once per gathered (row, tap).  io flags: bit 0 = fin is pair rows, bit 1 = write pair rows,
+ * bit 2 = residual is pair rows.  A layer fed pair rows gives the bits of the same layer fed the f32 rows they
+ * were split from; al3d_sp_rows_convert_f16x3 converts [n][channels] either way (channels % 8 == 0). */
+int al3d_sp_rows_convert_f16x3(const float* in, int64_t n, int channels, int to_pair, float* out, void* stream);
+int al3d_sp_conv_glds_f16x3_io(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,
+                               const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
+                               const float* residual, int relu, float* fout, int n_out, int io, void* stream);
+int al3d_sp_conv_wave2_f16x3_tiles_io(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask,
+                                      int K, const void* wgt_f16x2, int cin, int cout, const float* scale,
+                                      const float* shift, const float* residual, int relu, float* fout, int n_out,
+                                      int io, void* stream);
 /* al3d_sp_conv_wave2_f16x3 on a tiled rulebook: the offsets a wave needs come from tile_mask[tile] (one word) instead
  * of a scan of the tile's 27 x 32 table entries; same arithmetic, same bits. */
 int al3d_sp_conv_wave2_f16x3_tiles(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask, int K,

@@ -109,6 +109,94 @@ def test_sparse_conv_glds_kernel_is_bit_identical(cin, cout, geom):
     assert np.array_equal(a.view(np.int32), c.view(np.int32))
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64)])
+@pytest.mark.parametrize("order", ["raster", "random", "tiny"])
+def test_sparse_conv_range_gather_kernel(cin, cout, order):
+    """The range-gather LDS-DMA kernel (csrc/spconv_rng.hip): one staged index range per (tile, kz, ky) serves the
+    three kx taps.  Rows in raster order (the encoder's levels 1+): short ranges, the staged path; rows in random
+    order: every range is long, the per-row fallback inside the same kernel.  Cin = 32: the MFMA sequence per
+    output is sp_conv_wave2's -- same bits.  Cin = 64: the two 32-channel chunks of a group are summed before the
+    next group (another summation order): agreement to 2e-6 of the output scale, and run-to-run identical."""
+    from al3d import detector_ops as D
+    rng = np.random.default_rng(cin + len(order))
+    if order == "tiny":
+        shape, batch, n = [3, 5, 4], 1, 17
+    else:
+        shape, batch, n = [9, 40, 37], 3, 6001
+    feats, coords = random_sparse(rng, batch, shape, n, cin)
+    if order != "random":
+        key = ((coords[:, 0].astype(np.int64) * shape[0] + coords[:, 1]) * shape[1] + coords[:, 2]) * shape[2] + coords[:, 3]
+        perm = np.argsort(key, kind="stable")
+        feats, coords = feats[perm], coords[perm]
+    feats[::7] *= 1e-3
+    feats[5::11] *= 300.0
+    w = (rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.1, cout).astype(np.float32)
+    res = rng.normal(size=(feats.shape[0], cout)).astype(np.float32)
+    outs = {}
+    for mode in ("wave2_f16x3", "rng_f16x3", "rng_f16x3 again"):
+        got, _, _ = D.sparse_conv_layer(_t(feats), _t(coords), batch, shape, _t(w), (3, 3, 3), (1, 1, 1), (0, 0, 0), True,
+                                        scale=_t(scale), shift=_t(shift), residual=_t(res), relu=True,
+                                        mfma=mode.split()[0])
+        outs[mode] = got.cpu().numpy()
+    ref, got = outs["wave2_f16x3"], outs["rng_f16x3"]
+    assert np.isfinite(ref).all() and ref.shape == got.shape
+    assert np.array_equal(got.view(np.int32), outs["rng_f16x3 again"].view(np.int32))
+    if cin == 32:
+        assert np.array_equal(ref.view(np.int32), got.view(np.int32))
+    else:
+        assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("mode,cin,cout", [("wave2_f16x3_tiles", 16, 16), ("wave2_f16x3_tiles", 16, 32),
+                                           ("wave2_f16x3_tiles", 64, 128), ("wave2_f16x3_tiles", 128, 128),
+                                           ("glds_f16x3", 32, 32), ("glds_f16x3", 64, 64), ("rng_f16x3", 32, 32),
+                                           ("rng_f16x3", 64, 64)])
+def test_sparse_conv_pair_rows(mode, cin, cout):
+    """Pair rows (csrc/sp_rows.h): activations stored as the two f16 planes of the f16x3 arithmetic, split once
+    in the producer's epilogue.  (1) a layer fed pair rows gives the BITS of the layer fed the f32 rows they were
+    split from (the kernels only ever multiplied xh and xl'); (2) writing pair rows = splitting the f32 output;
+    (3) a pair-row residual adds xh + xl' 2^-11; (4) all three together compose.  Round trip error of the
+    format: <= 2^-22 relative (2^-36 absolute below f16's normal range)."""
+    from al3d import detector_ops as D
+    rng = np.random.default_rng(cin * 3 + cout)
+    shape, batch, n = [9, 40, 37], 3, 5003
+    feats, coords = random_sparse(rng, batch, shape, n, cin)
+    key = ((coords[:, 0].astype(np.int64) * shape[0] + coords[:, 1]) * shape[1] + coords[:, 2]) * shape[2] + coords[:, 3]
+    perm = np.argsort(key, kind="stable")
+    feats, coords = feats[perm], coords[perm]
+    feats[::7] *= 1e-3
+    feats[5::11] *= 300.0
+    w = (rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.1, cout).astype(np.float32)
+    res = rng.normal(size=(feats.shape[0], cout)).astype(np.float32)
+    x, r = _t(feats), _t(res)
+    xp, rp = D.rows_convert(x, True), D.rows_convert(r, True)
+    back = D.rows_convert(xp, False)
+    # 2^-22 relative in f16's normal range, 2^-36 absolute below it (hi piece subnormal: conv2d_f16x3.hip header)
+    assert bool(((back - x).abs() <= torch.maximum(x.abs() * 2.0 ** -22, torch.tensor(2.0 ** -35, device=x.device))).all())
+    r_rounded = D.rows_convert(rp, False)
+
+    def run(xin, resid, io):
+        got, _, _ = D.sparse_conv_layer(xin, _t(coords), batch, shape, _t(w), (3, 3, 3), (1, 1, 1), (0, 0, 0), True,
+                                        scale=_t(scale), shift=_t(shift), residual=resid, relu=True, mfma=mode, io=io)
+        return got
+
+    def same(a, b):
+        return bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+    base = run(x, r, 0)
+    assert same(run(xp, r, D.IO_IN_PAIR), base)                                           # (1)
+    assert same(D.rows_convert(run(x, r, D.IO_OUT_PAIR), False),
+                D.rows_convert(D.rows_convert(base, True), False))                        # (2)
+    base_rr = run(x, r_rounded, 0)
+    assert same(run(x, rp, D.IO_RES_PAIR), base_rr)                                       # (3)
+    allp = run(xp, rp, D.IO_IN_PAIR | D.IO_OUT_PAIR | D.IO_RES_PAIR)
+    assert same(allp, D.rows_convert(base_rr, True))                                      # (4)
+    assert same(run(xp, None, D.IO_IN_PAIR | D.IO_OUT_PAIR), D.rows_convert(run(x, None, 0), True))
+
+
 @pytest.mark.parametrize("k,s,p,subm", [((1, 1, 3), (1, 1, 2), (0, 0, 0), False),     # BEVFusion-style conv_out
                                         ((3, 3, 1), (1, 1, 1), (0, 0, 0), True),
                                         ((1, 3, 3), (1, 2, 2), (0, 1, 1), False),

@@ -29,16 +29,16 @@ pool = PoolFrames.from_synthetic(bs, dev, num_base=8)
 ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=bs, device=dev)))
 calls = []
 orig = B._SparseEncoderBase._conv
-def rec(m, feats, nbr, K, step, residual, out, n, st, tmask=None):
-    calls.append((m, feats, nbr, K, step, residual, n))
-    return orig(m, feats, nbr, K, step, residual, out, n, st, tmask=tmask)
+def rec(m, feats, nbr, K, step, residual, out, n, st, tmask=None, trng=None, io=0):
+    calls.append((m, feats, nbr, K, step, residual, n, io))
+    return orig(m, feats, nbr, K, step, residual, out, n, st, tmask=tmask, trng=trng, io=io)
 B._SparseEncoderBase._conv = staticmethod(rec)
 with torch.no_grad():
     model.backbone(ex["voxel_features"], ex["coordinates"], bs, ex["shape"][0])
 torch.cuda.synchronize()
 tot = {f: 0.0 for f in fns}
 tiled_cache = {}
-for (m, feats, nbr, K, step, residual, n) in calls:
+for (m, feats, nbr, K, step, residual, n, io) in calls:
     if step["w"].dtype not in (torch.bfloat16, torch.float16):
         continue
     ci, co = m.in_channels, m.out_channels
@@ -48,19 +48,33 @@ for (m, feats, nbr, K, step, residual, n) in calls:
     ci = feats.shape[-1]                                    # 16 for the zero-padded first layer
     plain = nbr if nbr.shape[1] == n else nbr[:, :n].contiguous()      # the encoder records pitched (tiled) tables
     tiled = None
-    if any("glds" in f for f in fns):                       # the tiled form of this table: pitch + tile masks
+    if True:                                                # the tiled form of this table: pitch + tile masks (+ ranges)
         key = nbr.data_ptr()
         if key not in tiled_cache:
             pitch = lib.load().al3d_sp_table_pitch(n)
             tn = torch.full((K, pitch), -1, dtype=torch.int32, device=dev)
             tn[:, :n] = nbr[:, :n]
             tm = ((tn.view(K, pitch // 32, 32) >= 0).any(-1).to(torch.int64) << torch.arange(K, device=dev)[:, None]).sum(0).to(torch.int32)
-            tiled_cache[key] = (tn, tm.contiguous(), pitch)
+            tr = torch.zeros((pitch // 32, 9, 2), dtype=torch.int32, device=dev)
+            if K == 27:
+                lib.call("al3d_sp_tile_ranges", _ptr(tn), pitch, K, n, _ptr(tr), _stream())
+            tiled_cache[key] = (tn, tm.contiguous(), pitch, tr)
         tiled = tiled_cache[key]
     for f in fns:
         out = torch.empty((n, co), device=dev)
-        w = D.pack_glds_f16x3(step["w"]).data if "glds" in f else step["w"]
+        w = D.pack_glds_f16x3(step["w"]).data if ("glds" in f or "rng" in f) else step["w"]
         def call():
+            if "rng" in f:
+                if not m.subm:
+                    raise lib.Al3dError("submanifold only")
+                lib.call(f, _ptr(feats), _ptr(tiled[0]), tiled[2], _ptr(tiled[1]), _ptr(tiled[3]), K, _ptr(w), ci, co,
+                         _ptr(step["scale"]), _ptr(step["shift"]), None if residual is None else _ptr(residual), 1, _ptr(out),
+                         n, io, _stream())
+                return
+            if f.endswith("_io"):                           # glds / wave2-on-tiles with the recorded row formats
+                lib.call(f, _ptr(feats), _ptr(tiled[0]), tiled[2], _ptr(tiled[1]), K, _ptr(w), ci, co, _ptr(step["scale"]),
+                         _ptr(step["shift"]), None if residual is None else _ptr(residual), 1, _ptr(out), n, io, _stream())
+                return
             if "glds" in f:
                 lib.call(f, _ptr(feats), _ptr(tiled[0]), tiled[2], _ptr(tiled[1]), K, _ptr(w), ci, co, _ptr(step["scale"]),
                          _ptr(step["shift"]), None if residual is None else _ptr(residual), 1, _ptr(out), n, _stream())

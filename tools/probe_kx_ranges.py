@@ -28,29 +28,25 @@ B._SparseEncoderBase._conv = staticmethod(rec)
 with torch.no_grad():
     model.backbone(ex["voxel_features"], ex["coordinates"], bs, ex["shape"][0])
 seen = set()
+# variant: 32-row tiles, groups of the three kx taps of one (kz, ky): contiguous range [lo, hi] of their valid neighbours
 for (m, nbr, K, n) in calls:
     key = (m.in_channels, m.out_channels, K, n, m.subm)
     if key in seen or K != 27 or not m.subm:
         continue
     seen.add(key)
     t = nbr[:, :n] if nbr.dim() == 2 else nbr.view(K, -1)[:, :n]
-    mono = 0
-    for k in (0, 13, 26):
-        v = t[k][t[k] >= 0]
-        mono += int((v[1:] < v[:-1]).sum())
-    for R in (64, 128, 256):
-        nt = (n + R - 1) // R
-        pad = nt * R - n
-        tt = torch.nn.functional.pad(t, (0, pad), value=-1).view(27, nt, R)
-        tot = torch.zeros(nt, dtype=torch.int64, device=dev)
-        for g in range(3):
-            grp = tt[9 * g:9 * g + 9]                                  # [9, nt, R]
-            valid = grp >= 0
-            lo = torch.where(valid, grp, torch.full_like(grp, 2 ** 30)).amin(dim=(0, 2))
-            hi = torch.where(valid, grp, torch.full_like(grp, -1)).amax(dim=(0, 2))
-            tot += torch.clamp(hi - lo + 1, min=0) * (hi >= 0)
-        refs = (tt >= 0).sum(dim=(0, 2)).float()
-        q = torch.quantile(tot.float(), torch.tensor([0.5, 0.9, 0.99, 0.999], device=dev))
-        print(f"{m.in_channels:3d}->{m.out_channels:3d} n={n:7d} R={R:3d}: staged rows/tile median {q[0]:.0f} p90 {q[1]:.0f} "
-              f"p99 {q[2]:.0f} p99.9 {q[3]:.0f} max {int(tot.max())}  refs/tile {refs.mean():.0f}  "
-              f"frac tiles <= 1.5R+64: {(tot <= 1.5 * R + 64).float().mean():.3f}  <= 3R+48: {(tot <= 3 * R + 48).float().mean():.3f}  non-monotone steps {mono}")
+    R = 32
+    nt = (n + R - 1) // R
+    tt = torch.nn.functional.pad(t, (0, nt * R - n), value=-1).view(9, 3, nt, R)
+    valid = tt >= 0
+    lo = torch.where(valid, tt, torch.full_like(tt, 2 ** 30)).amin(dim=(1, 3))          # [9, nt]
+    hi = torch.where(valid, tt, torch.full_like(tt, -1)).amax(dim=(1, 3))
+    live = hi >= 0
+    L = torch.clamp(hi - lo + 1, min=0)[live].float()
+    refs = valid.sum(dim=(1, 3))[live].float()
+    taps_live = valid.any(dim=3).sum(dim=1)[live].float()                                # live taps per live group
+    q = torch.quantile(L, torch.tensor([0.5, 0.9, 0.99], device=dev))
+    print(f"{m.in_channels:3d}->{m.out_channels:3d} n={n:7d}: live groups {live.float().mean():.3f}  L median {q[0]:.0f} p90 {q[1]:.0f} "
+          f"p99 {q[2]:.0f} mean {L.mean():.1f}  <=32 {(L <= 32).float().mean():.3f} <=48 {(L <= 48).float().mean():.3f} "
+          f"<=64 {(L <= 64).float().mean():.3f}  refs/group {refs.mean():.1f}  live taps/group {taps_live.mean():.2f}  "
+          f"rows now (32 x live taps) {32 * taps_live.mean():.0f}")
