@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scenes", type=int, default=None,
                     help="scenes per rank (default 64 at N=1 = configs[1]; 88 at N>1 = configs[2] per rank)")
-    ap.add_argument("--batch", type=int, default=64, help="frames per detector launch")
+    ap.add_argument("--batch", type=int, default=128, help="frames per detector launch")
     ap.add_argument("--budget", type=int, default=None,
                     help="cost budget (default 600; scaled down for pools under 64 scenes, whose "
                          "total labelling cost is below 600)")
@@ -111,7 +111,7 @@ class ConvTimer:
             # fp32-class arithmetic on the f16 matrix cores: every algorithmic MAC executes as three
             # f16 MFMA products (the f16 and bf16 dense peaks are equal), so peak/3 bounds it.
             out.update(kernel="conv3x3_f16x3_frag_kernel",
-                       kernel_family="conv3x3_f16x3_frag_kernel (11 of 15 launches) + conv2d_f16x3_kernel "
+                       kernel_family="conv3x3_f16x3_frag_kernel (11 of 15 launches) + conv2d_f16x3_dma2_kernel "
                                      "(stride-2, 1x1, deconv, fused head)",
                        peak=round(MFMA_BF16_PEAK_TFLOPS / 3, 1),
                        peak_basis="2500 TFLOP/s dense f16 MFMA / 3 f16 products per fp32-class MAC",

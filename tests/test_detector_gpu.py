@@ -608,10 +608,10 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
         D.DENSE = saved_dense
 
 
-def test_batch_64_equals_batch_8_at_full_size():
-    """The bench's default batch (64 frames per launch) puts 2.7e9 cells into the level-0 index grid
-    and the voxelizer's first-index grid -- beyond int32.  Embeddings must be the same bits as with
-    8 frames per launch (64-bit cell indexing everywhere)."""
+def test_batch_128_equals_batch_8_at_full_size():
+    """The bench's default batch (128 frames per launch; 64 until round 2) puts 5.5e9 cells into the level-0 index
+    grid and the voxelizer's first-index grid -- beyond int32 (already at 64: 2.7e9).  Embeddings must be the same
+    bits as with 8 frames per launch (64-bit cell indexing everywhere), at 64 and at 128."""
     from al3d import sweep as S, synthetic
     from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
     from al3d.models import build_detector
@@ -622,15 +622,19 @@ def test_batch_64_equals_batch_8_at_full_size():
     synthetic.seeded_init_(model, seed=0)
     model = model.to(DEV).eval()
     anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
-    pool = PoolFrames.from_synthetic(64, DEV, num_base=4, seed=3)
+    pool = PoolFrames.from_synthetic(128, DEV, num_base=4, seed=3)
 
     def run(batch):
         return S.sweep_embeddings(model, DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch, device=DEV),
                                   DEV, len(pool))
-    big = run(64)
-    assert big.shape == (64, 512) and torch.isfinite(big).all()
-    assert torch.equal(big, run(8))
-    assert not torch.equal(big[0], big[1])          # frames differ (the last frame is not a copy of the first)
+    small = run(8)
+    for batch in (64, 128):
+        big = run(batch)
+        assert big.shape == (128, 512) and torch.isfinite(big).all()
+        assert torch.equal(big, small), batch
+    assert not torch.equal(small[0], small[1])      # frames differ (the last frame is not a copy of the first)
+    del pool
+    torch.cuda.empty_cache()
 
 
 def test_sweep_with_an_empty_frame_in_the_batch():

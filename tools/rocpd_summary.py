@@ -44,6 +44,12 @@ def per_kernel(db, counter):
     return acc
 
 
+# Kernels whose global loads fetch 64-byte segments (16 f32 channels of a pixel / of a 16-channel row): FETCH_SIZE
+# tallies those correctly.  Everything else issues fully coalesced 16 B/lane loads or LDS-DMA, whose 128-byte
+# requests gfx950 tallies at 64 B (MI355X_MICROARCH.md): FETCH_SIZE x 2.
+NO_X2 = ("conv3x3_f16x3", "conv2d_f16x3_kernel", "conv2d_f16x3_bstream", "sp_conv_wave2_kernel<16,")
+
+
 def hbm(fdb, wdb, out, note):
     fetch, write = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     res = {}
@@ -51,12 +57,17 @@ def hbm(fdb, wdb, out, note):
         wn, wkb = write.get(k, (0, 0.0))
         f_avg = kb / n
         w_avg = wkb / wn if wn else 0.0
+        x2 = not k.startswith(NO_X2)
         res[k] = {"launches": n, "fetch_kb_raw": f_avg, "write_kb": w_avg,
                   "fetch_mb_raw": f_avg * 1024 / 1e6, "fetch_mb_x2": 2.0 * f_avg * 1024 / 1e6,
                   "write_mb": w_avg * 1024 / 1e6,
-                  "hbm_mb_corrected": (2.0 * f_avg + w_avg) * 1024 / 1e6,
-                  "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md: gfx950 tallies the 128-byte requests of 16 B/lane "
-                                "loads at 64 B); WRITE_SIZE as counted",
+                  "hbm_mb_corrected": ((2.0 if x2 else 1.0) * f_avg + w_avg) * 1024 / 1e6,
+                  "x2_applies": x2,
+                  "correction": ("FETCH_SIZE x 2 (MI355X_MICROARCH.md: gfx950 tallies the 128-byte requests of fully "
+                                 "coalesced 16 B/lane loads and LDS-DMA at 64 B); WRITE_SIZE as counted") if x2 else
+                                ("none: this kernel's loads fetch 64-byte segments (16 f32 channels per pixel / row unit), "
+                                 "which FETCH_SIZE tallies correctly -- raw FETCH_SIZE + WRITE_SIZE equals the algorithmic "
+                                 "bytes of the launch mix"),
                   "note": note}
     res = dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_mb_corrected"] * kv[1]["launches"]))
     with open(out, "w") as f:
