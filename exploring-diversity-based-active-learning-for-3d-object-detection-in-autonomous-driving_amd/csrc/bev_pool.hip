@@ -305,3 +305,77 @@ extern "C" int al3d_lss_geometry_f32(const float* frustum, int64_t points_per_ca
     AL3D_CHECK_LAUNCH("lss_geometry_kernel");
     return AL3D_OK;
 }
+
+// ------------------------------------------------------------------ lidar depth image of the depth-aware LSS transform
+// BaseDepthTransform.forward (bevfusion/mmdet3d/models/vtransforms/base.py:225-262): every lidar point of a sample is
+// taken back through the lidar augmentation, projected into each camera (lidar2image), through the image
+// augmentation, truncated to a pixel, and its depth written to depth[b, cam, 0, row, col]; points that land on one
+// pixel overwrite each other in point order (the reference's indexed assignment on the CPU keeps the LAST point).
+// One thread per (camera, point); the overwrite order is made deterministic with a 64-bit atomicMax on
+// (point index + 1) << 32 | depth bits, resolved by a second pass.  Dot products as ((a0 x + a1 y) + a2 z), no
+// contraction.  cam_rows [N][24]: lidar2image[:3,:3] (9) | lidar2image[:3,3] (3) | img_aug[:3,:3] (9) | img_aug[:3,3] (3);
+// aug [12]: inverse(lidar_aug[:3,:3]) (9) | lidar_aug[:3,3] (3).
+__global__ void lss_depth_scatter_kernel(const float* __restrict__ pts, int64_t npts, int stride, const float* __restrict__ cam_rows,
+                                         int ncam, const float* __restrict__ aug, int iH, int iW,
+                                         unsigned long long* __restrict__ keys)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npts * ncam) return;
+    const int c = (int)(t / npts);
+    const int64_t i = t % npts;
+    const float* p = pts + i * stride;
+    float x = p[0] - aug[9], y = p[1] - aug[10], z = p[2] - aug[11];
+    const float ux = (aug[0] * x + aug[1] * y) + aug[2] * z;
+    const float uy = (aug[3] * x + aug[4] * y) + aug[5] * z;
+    const float uz = (aug[6] * x + aug[7] * y) + aug[8] * z;
+    const float* m = cam_rows + 24 * c;
+    float qx = ((m[0] * ux + m[1] * uy) + m[2] * uz) + m[9];
+    float qy = ((m[3] * ux + m[4] * uy) + m[5] * uz) + m[10];
+    float qz = ((m[6] * ux + m[7] * uy) + m[8] * uz) + m[11];
+    const float dist = qz;
+    qz = fminf(fmaxf(qz, 1e-5f), 1e5f);
+    qx = qx / qz; qy = qy / qz;
+    const float* a = m + 12;
+    const float vx = ((a[0] * qx + a[1] * qy) + a[2] * qz) + a[9];
+    const float vy = ((a[3] * qx + a[4] * qy) + a[5] * qz) + a[10];
+    // the reference swaps to (row, col) = (vy, vx) and keeps 0 <= row < iH, 0 <= col < iW, then truncates
+    if (!(vy < (float)iH && vy >= 0.f && vx < (float)iW && vx >= 0.f)) return;
+    const int row = (int)vy, col = (int)vx;
+    const unsigned long long key = ((unsigned long long)(i + 1) << 32) | (unsigned long long)__float_as_uint(dist);
+    atomicMax(&keys[((int64_t)c * iH + row) * iW + col], key);
+}
+
+__global__ void lss_depth_resolve_kernel(const unsigned long long* __restrict__ keys, int64_t n, float* __restrict__ depth)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const unsigned long long k = keys[t];
+    depth[t] = k ? __uint_as_float((unsigned)(k & 0xffffffffull)) : 0.f;
+}
+
+extern "C" int64_t al3d_lss_depth_image_workspace_bytes(int ncam, int iH, int iW)
+{
+    return al3d_align((int64_t)(ncam > 0 ? ncam : 1) * iH * iW * 8, 256);
+}
+
+// depth [ncam][iH][iW] of ONE sample; points [npts][stride >= 3] f32
+extern "C" int al3d_lss_depth_image_f32(const float* points, int64_t npts, int stride, const float* cam_rows, int ncam,
+                                        const float* aug_rows, int iH, int iW, float* depth, void* workspace, void* stream)
+{
+    AL3D_REQUIRE(cam_rows && aug_rows && depth && workspace && ncam >= 1 && iH >= 1 && iW >= 1 && npts >= 0 && stride >= 3,
+                 "al3d_lss_depth_image_f32: bad arguments");
+    AL3D_REQUIRE(npts == 0 || points, "al3d_lss_depth_image_f32: null points");
+    AL3D_REQUIRE(npts < ((int64_t)1 << 31), "al3d_lss_depth_image_f32: too many points");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)ncam * iH * iW;
+    if (hipMemsetAsync(workspace, 0, (size_t)n * 8, s) != hipSuccess) return al3d_fail(AL3D_ELAUNCH, "al3d_lss_depth_image_f32: memset failed");
+    if (npts > 0) {
+        hipLaunchKernelGGL(lss_depth_scatter_kernel, dim3((unsigned)al3d_cdiv(npts * ncam, 256)), dim3(256), 0, s, points, npts,
+                           stride, cam_rows, ncam, aug_rows, iH, iW, (unsigned long long*)workspace);
+        AL3D_CHECK_LAUNCH("lss_depth_scatter_kernel");
+    }
+    hipLaunchKernelGGL(lss_depth_resolve_kernel, dim3((unsigned)al3d_cdiv(n, 256)), dim3(256), 0, s,
+                       (const unsigned long long*)workspace, n, depth);
+    AL3D_CHECK_LAUNCH("lss_depth_resolve_kernel");
+    return AL3D_OK;
+}

@@ -3,9 +3,9 @@ section 8 row f4): Lift-Splat view transform (frustum geometry -> BEV pooling ->
 ``ConvFuser`` that merges camera and lidar BEV maps.
 
 Reference: bevfusion/mmdet3d/models/vtransforms/base.py:16-163 (``BaseTransform``: frustum, geometry, bev_pool),
-vtransforms/depth_lss.py:58-102 (downsample, outer product), fusers/conv.py:11-25 (``ConvFuser``).  The image
-backbone (Swin-T), the FPN neck and the depth net that produce ``depth`` / ``ctx`` are NOT built (mmcv / mmdet absent,
-no checkpoints offline): this module takes their outputs.  Parameter names follow the reference
+vtransforms/depth_lss.py:14-102 (``DepthLSSTransform``: dtransform, depthnet, outer product, downsample),
+necks/generalized_lss.py:13-110 (``GeneralizedLSSFPN``), fusers/conv.py:11-25 (``ConvFuser``).  The image backbone
+(Swin-T) is NOT built (mmcv / mmdet absent, no checkpoints offline): the FPN takes its feature maps as input.  Parameter names follow the reference
 (``downsample.{0,1,3,4,6,7}``; fuser ``0``/``1``) so its state dicts load; maps are channels-last with this build's
 [H=y, W=x] orientation handled by the caller as in ``bevfusion_compat`` (BEV maps here come out [B, nx0, nx1, C], i.e.
 the reference's [H=x, W=y]).
@@ -121,10 +121,10 @@ class LSSViewTransform(nn.Module):
         points = combine.view(B, N, 1, 1, 1, 3, 3).matmul(points).squeeze(-1)
         points += camera2lidar_trans.view(B, N, 1, 1, 1, 3)
         if "extra_rots" in kwargs:
-            points = kwargs["extra_rots"].view(B, 1, 1, 1, 1, 3, 3).repeat(1, N, 1, 1, 1, 1, 1) \
+            points = kwargs["extra_rots"].reshape(B, 1, 1, 1, 1, 3, 3).repeat(1, N, 1, 1, 1, 1, 1) \
                 .matmul(points.unsqueeze(-1)).squeeze(-1)
         if "extra_trans" in kwargs:
-            points += kwargs["extra_trans"].view(B, 1, 1, 1, 1, 3).repeat(1, N, 1, 1, 1, 1)
+            points += kwargs["extra_trans"].reshape(B, 1, 1, 1, 1, 3).repeat(1, N, 1, 1, 1, 1)
         return points
 
     def geometry_device(self, camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs):
@@ -138,10 +138,10 @@ class LSSViewTransform(nn.Module):
         rows[:, 12:21] = camera2lidar_rots.matmul(torch.inverse(intrins)).reshape(B * N, 9)
         rows[:, 21:24] = camera2lidar_trans.reshape(B * N, 3)
         if "extra_rots" in kwargs:
-            rows[:, 24:33] = kwargs["extra_rots"].view(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)
+            rows[:, 24:33] = kwargs["extra_rots"].reshape(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)
             rows[:, 36] = 1.0
         if "extra_trans" in kwargs:
-            rows[:, 33:36] = kwargs["extra_trans"].view(B, 1, 3).expand(B, N, 3).reshape(B * N, 3)
+            rows[:, 33:36] = kwargs["extra_trans"].reshape(B, 1, 3).expand(B, N, 3).reshape(B * N, 3)
             rows[:, 37] = 1.0
         Dd, fH, fW, _ = self.frustum.shape
         geom = torch.empty((B, N, Dd, fH, fW, 3), dtype=torch.float32, device=dev)
@@ -173,3 +173,157 @@ class ConvFuser(nn.Sequential):
     def forward(self, inputs):
         assert [t.shape[-1] for t in inputs] == list(self.in_channels)
         return self._run(torch.cat(inputs, dim=-1).contiguous())
+
+
+class _ConvAffine(nn.Module):
+    """Conv2d (+ bias) [+ BatchNorm2d] [+ ReLU] on channels-last maps through the dense conv kernels.  Input channels
+    are zero-padded to a multiple of 16 (weights too), which the matrix-core kernels need; any Cout."""
+
+    def __init__(self, conv, bn=None, relu=True):
+        super().__init__()
+        self.conv, self.bn, self.relu = conv, bn, relu
+        self._packed = None
+
+    def forward(self, x):
+        key = (x.device, D.MATH, D.DENSE)
+        conv = self.conv
+        cin = conv.in_channels
+        cpad = (cin + 15) // 16 * 16
+        if self._packed is None or self._packed[0] != key:
+            if self.bn is not None:
+                scale, shift = D.fold_bn(self.bn)
+                scale, shift = scale.cpu(), shift.cpu()
+            else:
+                scale = torch.ones(conv.out_channels)
+                shift = torch.zeros(conv.out_channels)
+            if conv.bias is not None:                                    # (x + b) * s + t
+                shift = shift + conv.bias.detach().float().cpu() * scale
+            w = conv.weight.detach().float()
+            if cpad != cin:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cpad - cin))
+            k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            wp, scale = D.pack_dense(D.pack_conv_weight(w).to(x.device), scale.to(x.device), k, s, p)
+            self._packed = (key, wp, scale, shift.to(x.device))
+        _, wp, scale, shift = self._packed
+        if cpad != cin:
+            x = torch.nn.functional.pad(x, (0, cpad - cin))
+        return D.conv2d_nhwc(x.contiguous(), wp, scale, shift, conv.kernel_size[0], conv.stride[0], conv.padding[0],
+                             self.relu)
+
+
+class _ConvModule(nn.Module):
+    """mmcv ``ConvModule`` (conv -> bn -> ReLU) with its parameter names (``conv.weight``, ``bn.*``)."""
+
+    def __init__(self, cin, cout, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+        object.__setattr__(self, "_run", _ConvAffine(self.conv, self.bn, True))     # not a submodule: no duplicate keys
+
+    def forward(self, x):
+        return self._run(x)
+
+
+class GeneralizedLSSFPN(nn.Module):
+    """bevfusion/mmdet3d/models/necks/generalized_lss.py:13-110: top-down path of upsample (bilinear,
+    align_corners=True) -> concat -> 1x1 ConvModule -> 3x3 ConvModule per level.  Channels-last maps
+    [BN, H_l, W_l, C_l] in, tuple of the ``used_backbone_levels`` outputs out.  The interpolation is a torch op (a
+    gather with four weights per pixel on maps of a few MB); the convolutions run on the dense conv kernels."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
+        self.num_ins = len(in_channels)
+        self.backbone_end_level = self.num_ins - 1 if end_level == -1 else end_level
+        if end_level != -1:
+            assert end_level <= len(in_channels) and num_outs == end_level - start_level
+        self.start_level = start_level
+        self.lateral_convs, self.fpn_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            extra = in_channels[i + 1] if i == self.backbone_end_level - 1 else out_channels
+            self.lateral_convs.append(_ConvModule(in_channels[i] + extra, out_channels, 1))
+            self.fpn_convs.append(_ConvModule(out_channels, out_channels, 3, padding=1))
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [inputs[i + self.start_level] for i in range(len(inputs))]
+        used = len(laterals) - 1
+        for i in range(used - 1, -1, -1):
+            up = torch.nn.functional.interpolate(laterals[i + 1].permute(0, 3, 1, 2), size=laterals[i].shape[1:3],
+                                                 mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+            x = torch.cat([laterals[i], up], dim=-1).contiguous()
+            laterals[i] = self.fpn_convs[i](self.lateral_convs[i](x))
+        return tuple(laterals[i] for i in range(used))
+
+
+class DepthLSSTransform(LSSViewTransform):
+    """vtransforms/depth_lss.py:14-102 + ``BaseDepthTransform.forward`` (base.py:196-262): the depth-aware Lift-Splat
+    transform of the camera+lidar configs.  The lidar points are rasterised into a per-camera depth image
+    (``al3d_lss_depth_image_f32``), ``dtransform`` (1x1, 5x5/s4, 5x5/s2) brings it to the feature resolution, ``depthnet``
+    (3x3, 3x3, 1x1 on [depth features | image features]) predicts D depth logits + C context channels, softmax over D,
+    and the fused Lift-Splat pooling (``al3d_bev_pool_lss_f32``) never materialises the [B,N,D,fH,fW,C] product.
+
+    forward(img [B,N,fH,fW,in_channels] channels-last image features (the FPN output), points (list of [P,>=3]),
+    lidar2image [B,N,4,4], cam_intrinsic [B,N,4,4], camera2lidar [B,N,4,4], img_aug_matrix [B,N,4,4],
+    lidar_aug_matrix [B,4,4]) -> BEV map [B, nx0/ds, nx1/ds, C]."""
+
+    def __init__(self, in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound, downsample=1):
+        super().__init__(out_channels, image_size, feature_size, xbound, ybound, zbound, dbound, downsample)
+        self.in_channels = in_channels
+        self.dtransform = nn.Sequential(
+            nn.Conv2d(1, 8, 1), nn.BatchNorm2d(8), nn.ReLU(True),
+            nn.Conv2d(8, 32, 5, stride=4, padding=2), nn.BatchNorm2d(32), nn.ReLU(True),
+            nn.Conv2d(32, 64, 5, stride=2, padding=2), nn.BatchNorm2d(64), nn.ReLU(True))
+        self.depthnet = nn.Sequential(
+            nn.Conv2d(in_channels + 64, in_channels, 3, padding=1), nn.BatchNorm2d(in_channels), nn.ReLU(True),
+            nn.Conv2d(in_channels, in_channels, 3, padding=1), nn.BatchNorm2d(in_channels), nn.ReLU(True),
+            nn.Conv2d(in_channels, self.D + self.C, 1))
+        self._dt = [_ConvAffine(self.dtransform[i], self.dtransform[i + 1], True) for i in (0, 3, 6)]
+        self._dn = [_ConvAffine(self.depthnet[0], self.depthnet[1], True), _ConvAffine(self.depthnet[3], self.depthnet[4], True),
+                    _ConvAffine(self.depthnet[6], None, False)]
+
+    def depth_image(self, points, lidar2image, img_aug_matrix, lidar_aug_matrix):
+        """-> [B, N, iH, iW] f32: depth of the last lidar point (in point order) on every pixel, 0 where none."""
+        B, N = lidar2image.shape[:2]
+        iH, iW = self.image_size
+        dev = self.frustum.device
+        out = torch.empty((B, N, iH, iW), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.load().al3d_lss_depth_image_workspace_bytes(N, iH, iW), dtype=torch.uint8, device=dev)
+        for b in range(B):
+            pts = _dev(points[b].float().contiguous(), torch.float32, "points")
+            rows = torch.empty((N, 24), dtype=torch.float32, device=dev)
+            rows[:, 0:9] = lidar2image[b, :, :3, :3].reshape(N, 9)
+            rows[:, 9:12] = lidar2image[b, :, :3, 3]
+            rows[:, 12:21] = img_aug_matrix[b, :, :3, :3].reshape(N, 9)
+            rows[:, 21:24] = img_aug_matrix[b, :, :3, 3]
+            aug = torch.empty((12,), dtype=torch.float32, device=dev)
+            aug[0:9] = torch.inverse(lidar_aug_matrix[b, :3, :3]).reshape(9)
+            aug[9:12] = lidar_aug_matrix[b, :3, 3]
+            lib.call("al3d_lss_depth_image_f32", _ptr(pts), pts.shape[0], pts.shape[1], _ptr(rows), N, _ptr(aug), iH, iW,
+                     _ptr(out[b]), _ptr(ws), _stream())
+        return out
+
+    def get_cam_feats(self, x, d):
+        """x [B,N,fH,fW,Cin], d [B,N,iH,iW] -> (depth probabilities [B*N,D,fH,fW], context [B*N,fH,fW,C])."""
+        B, N, fH, fW, Cin = x.shape
+        d = d.reshape(B * N, *d.shape[2:]).unsqueeze(-1)
+        for layer in self._dt:
+            d = layer(d)
+        assert d.shape[1:3] == (fH, fW), (d.shape, fH, fW)
+        y = torch.cat([d, x.reshape(B * N, fH, fW, Cin)], dim=-1).contiguous()
+        for layer in self._dn:
+            y = layer(y)
+        depth = torch.softmax(y[..., :self.D], dim=-1).permute(0, 3, 1, 2).contiguous()
+        return depth, y[..., self.D:self.D + self.C].contiguous()
+
+    def forward(self, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix):
+        B, N, fH, fW, _ = img.shape
+        d = self.depth_image(points, lidar2image, img_aug_matrix, lidar_aug_matrix)
+        depth, ctx = self.get_cam_feats(img, d)
+        geom = self.geometry_device(camera2lidar[..., :3, :3], camera2lidar[..., :3, 3], cam_intrinsic[..., :3, :3],
+                                    img_aug_matrix[..., :3, :3], img_aug_matrix[..., :3, 3],
+                                    extra_rots=lidar_aug_matrix[..., :3, :3], extra_trans=lidar_aug_matrix[..., :3, 3])
+        x = bev_pool(ctx, geom, B, self.dx.cpu().numpy(), self.bx.cpu().numpy(), self.nx.cpu().numpy(), depth=depth)
+        for layer in self._ds:
+            x = layer(x)
+        return x

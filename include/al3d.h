@@ -484,6 +484,16 @@ int al3d_gap_nhwc_f32(const float* x, int B, int H, int W, int C, float* out, vo
 int64_t al3d_lss_geometry_workspace_bytes(int BN);
 int al3d_lss_geometry_f32(const float* frustum, int64_t points_per_camera, const float* cam_rows, int BN, float* geom,
                           void* workspace, void* stream);
+
+/* Lidar depth image of the depth-aware LSS transform (vtransforms/base.py:225-262, BaseDepthTransform.forward): the
+ * points of one sample, taken back through the lidar augmentation, projected into every camera and through the image
+ * augmentation, write their depth to depth [ncam][iH][iW] at the truncated pixel; of several points on one pixel the
+ * LAST in point order stays (the reference's indexed assignment on the CPU).  cam_rows [ncam][24] = lidar2image[:3,:3]
+ * | lidar2image[:3,3] | img_aug[:3,:3] | img_aug[:3,3]; aug_rows [12] = inverse(lidar_aug[:3,:3]) | lidar_aug[:3,3]
+ * (device memory).  workspace: al3d_lss_depth_image_workspace_bytes. */
+int64_t al3d_lss_depth_image_workspace_bytes(int ncam, int iH, int iW);
+int al3d_lss_depth_image_f32(const float* points, int64_t npts, int stride, const float* cam_rows, int ncam,
+                             const float* aug_rows, int iH, int iW, float* depth, void* workspace, void* stream);
 int64_t al3d_bev_pool_workspace_bytes(int64_t n_points, int64_t n_cells);
 int al3d_bev_pool_f32(const float* x, const float* geom, int64_t n_points, int C, int B, const float* lo,
                       const float* dx, const int* nx, float* out, void* workspace, void* stream);
