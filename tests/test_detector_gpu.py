@@ -600,6 +600,17 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
             D.DENSE = mode
             assert torch.equal(run(4), ref), "dense " + mode
         D.DENSE = saved_dense
+        if D.MATH == "f16x3":
+            # row format between sparse layers: pair rows (default) store xh + xl' 2^-11 instead of the f32 value;
+            # the products are the same, the residual adds see the rounded value -> same embedding to ~1e-6
+            saved_rows = D.SPROWS
+            try:
+                D.SPROWS = "f32"
+                plain = run(4)
+            finally:
+                D.SPROWS = saved_rows
+            assert float((plain - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+            assert not torch.equal(plain, ref)          # the knob does something
         for mode in (None, "ahead", "split"):
             S.PIPELINE = mode
             assert torch.equal(run(2), ref), mode
