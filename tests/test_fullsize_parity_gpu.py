@@ -83,6 +83,13 @@ def _device_frame(cfg, model, pts, anchors):
     with torch.no_grad():
         bev, _ = model.sparse_stage(ex)
         fused = model.bbox_head(model.neck(bev))[0]["_fused"]               # [1,128,128,CH]
+        # the device orders the fused channels [all box | all cls]; the CPU chain interleaves per task [box_t | cls_t]
+        head = model.bbox_head
+        order = []
+        for t, task in enumerate(head.tasks):
+            order += list(range(head._box_off[t], head._box_off[t] + task.conv_box.out_channels))
+            order += list(range(head._cls_off[t], head._cls_off[t] + task.conv_cls.out_channels))
+        fused = fused[..., torch.tensor(order, device=fused.device)].contiguous()
         preds, middle = model(ex, return_loss=False, estimate=True)      # the selectors' call contract
         emb = middle[-1].mean(-1).mean(-1)
     p = preds[0]
