@@ -19,6 +19,7 @@ from torch import nn
 from .. import detector_ops as D
 from .. import lib
 from ..selector_ops import _dev, _ptr, _stream
+from .registry import NECKS
 
 
 def gen_dx_bx(xbound, ybound, zbound):
@@ -224,6 +225,7 @@ class _ConvModule(nn.Module):
         return self._run(x)
 
 
+@NECKS.register_module
 class GeneralizedLSSFPN(nn.Module):
     """bevfusion/mmdet3d/models/necks/generalized_lss.py:13-110: top-down path of upsample (bilinear,
     align_corners=True) -> concat -> 1x1 ConvModule -> 3x3 ConvModule per level.  Channels-last maps
