@@ -9,6 +9,7 @@ from .detectors import FPNVoxelNet, VoxelNet
 from .box_coder import GroundBox3dCoderTorch, build_box_coder
 from .bevfusion_camera import ConvFuser, DepthLSSTransform, GeneralizedLSSFPN, LSSViewTransform
 from .transfusion_head import TransFusionHead
+from .swin import SwinTransformer
 
 __all__ = ["READERS", "BACKBONES", "NECKS", "HEADS", "DETECTORS", "build_detector",
            "build_reader", "build_backbone", "build_neck", "build_head", "build_box_coder"]
