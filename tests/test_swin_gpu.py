@@ -92,3 +92,38 @@ def test_swin_t_levels_and_camera_branch_end_to_end():
         bev = vt(fpn[0].view(B, N, 32, 88, 256), [p.to(DEV) for p in points], lidar2image.to(DEV), K.to(DEV),
                  cam2lidar.to(DEV), img_aug.to(DEV), lidar_aug.to(DEV))
     assert tuple(bev.shape) == (1, 180, 180, 80) and bool(torch.isfinite(bev).all()) and float(bev.abs().max()) > 0
+
+
+def test_assembled_camera_lidar_model_runs_and_is_deterministic():
+    """``BEVFusionCameraLidar`` (fusion_models/bevfusion.py:207-305 restated on this build's modules): one synthetic
+    sample through camera encoder, lidar encoder, fuser, decoder, embedding tap and TransFusionHead; shapes, finiteness,
+    run-to-run identical embedding, and the camera map's [x, y] -> [H=y, W=x] transposition (a camera-only change must
+    move the embedding, a lidar-only change too)."""
+    import os
+    from al3d import synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames
+    from al3d.models import build_detector
+    from al3d.models.bevfusion_model import BEVFusionCameraLidar, transfusion_head_for
+    from al3d.utils import Config
+    from test_camera_branch_gpu import _camera_setup, _seed_
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "examples", "active", "bevfusion_lidar_spatial_temporal_feature.py"))
+    lidar = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(lidar, seed=0)
+    model = BEVFusionCameraLidar(lidar, head=transfusion_head_for())
+    for i, m in enumerate((model.camera_backbone, model.camera_neck, model.vtransform, model.fuser, model.head)):
+        _seed_(m, 40 + i)
+    model = model.to(DEV).eval()
+    pool = PoolFrames.from_synthetic(2, DEV, num_base=2, seed=1)
+    ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, None, 1, device=DEV)))
+    K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = _camera_setup(1, 6, 9, (256, 704))
+    img = torch.randn(1, 6, 256, 704, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+    mats = (lidar2image.to(DEV), K.to(DEV), cam2lidar.to(DEV), img_aug.to(DEV), lidar_aug.to(DEV))
+    with torch.no_grad():
+        emb, dec, preds = model(ex, img, [pool.frames[0]], *mats)
+        emb2, _, _ = model(ex, img, [pool.frames[0]], *mats)
+        emb_cam, _, _ = model(ex, img.flip(3), [pool.frames[0]], *mats)           # mirrored images only
+    assert tuple(emb.shape) == (1, 512) and tuple(dec.shape) == (1, 180, 180, 512) and bool(torch.isfinite(emb).all())
+    assert torch.equal(emb, emb2)
+    assert not torch.equal(emb, emb_cam)
+    assert len(preds) == 1 and preds[0]["bboxes"].shape[1] == 9 and len(preds[0]["scores"]) > 0
