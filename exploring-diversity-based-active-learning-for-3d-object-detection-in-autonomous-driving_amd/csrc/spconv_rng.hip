@@ -5,17 +5,17 @@
 // rows, shifted by one site.  From level 1 on the rows of a level are in raster order (z, y, x), so the
 // neighbours of 32 consecutive output rows under the three kx taps of a (kz, ky) GROUP lie in one short
 // contiguous index range [lo, lo + L): measured on the real rulebooks (tools/probe_kx_ranges.py) L has median
-// 33-34 and is <= 48 for 96-97 % of the live (tile, group) pairs, against 3 x 32 = 96 rows gathered per group by
-// the per-tap scheme.  Here a group item stages rows lo .. lo + 47 ONCE -- six fully coalesced 1 KiB DMA pieces,
-// no per-row address, no dependence on the neighbour indices -- and the three taps read their A fragments from
-// it at LDS row (index - lo); rows without a neighbour read a shared zero row.  The (lo, L) table comes with the
-// rulebook (al3d_sp_tile_ranges, one pass over the level's table, shared by its SubM layers).  The 3-4 % of
-// groups with L > 48 (tiles straddling a z plane or a long gap) fall back, inside the same item, to a per-row
-// gather of each tap into the same slot (drains the DMA queue: correct, slower, rare).
+// 33-34, p90 37-39 and is <= 48 for 96-97 % of the live (tile, group) pairs, against 3 x 32 = 96 rows gathered per
+// group by the per-tap scheme.  Here a group item stages rows lo .. lo + CAP - 1 ONCE -- CAP / 8 fully coalesced
+// 1 KiB DMA pieces, no per-row address, no dependence on the neighbour indices -- and the three taps read their A
+// fragments from it at LDS row (index - lo); rows without a neighbour read a shared zero row.  The (lo, L) table
+// comes with the rulebook (al3d_sp_tile_ranges, one pass over the level's table, shared by its SubM layers).
+// Groups with L > CAP (tiles straddling a z plane or a long gap; ~7 % at the shipped CAP = 40) fall back, inside
+// the same item, to a per-row gather of each tap into the same slot (drains the DMA queue: correct, slower).
 //
 // Everything else is the LDS-DMA kernel's: a producer wave streams weight slabs (one slab = the 3 taps x 2
 // sixteen-channel units of a group item) through a ring of two LDS buffers, one raw s_barrier per slab; consumer
-// waves own one tile each, keep P slots of 48 rows and run P-1 items ahead; all main-loop LDS reads are asm
+// waves own one tile each, keep P slots of CAP rows and run P-1 items ahead; all main-loop LDS reads are asm
 // blocks fused with their waits; counted s_waitcnt vmcnt.  Swizzle: chunk c of staged row r sits at position
 // c ^ ((r >> 1) & 7) (applied on the source side of the DMA), conflict-free for the b128 lane groups whenever
 // the 32 rows of a fragment are consecutive.
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void sp_conv_rng_kernel(const float*
     //     G(0) | X(0) G(1) | X(1) G(2) | ... | X(P-2) G(P-1)   ||   X(2)... wait for item t: everything up to X(t), G(t)
     // After G(t) follow (P-1) NV operations, after X(t) follow NPC + NV: waiting for vmcnt <= WAITN = the smaller of
     // the two retires both (operations retire in order).
-    static_assert(P >= 3, "the index ring has two entries: X runs two items ahead, G at least as far");
+    static_assert(P >= 2, "the index ring has two entries: X runs two items ahead, G at least as far");
 #pragma unroll
     for (int u = -P; u < 0; ++u) {
         if (u + 2 >= 0 && u + 2 < 2) issue_x(u + 2);
@@ -454,8 +454,11 @@ extern "C" int al3d_sp_conv_rng_f16x3(const float* fin, const int* nbr, int nbr_
     AL3D_REQUIRE(nbr_pitch >= n_out && nbr_pitch % 256 == 0, "al3d_sp_conv_rng_f16x3: nbr_pitch must be al3d_sp_table_pitch(n_out)");
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (int)al3d_cdiv(n_out, 32);
-    RNG_DISPATCH(32, 32, 7, 3, 48)
-    RNG_DISPATCH(64, 64, 5, 3, 48)
+    // shapes: as many consumer waves as the LDS holds with two slots each -- the kernel is bound by the latency chain
+    // of a wave's item times the resident waves (7 -> 10 -> 12 waves: 968 -> 852 -> 795 us on the 32 -> 32 layers),
+    // so the range cap is 40 rows (5 KB slots; ~7 % of the groups take the per-row path) rather than 48
+    RNG_DISPATCH(32, 32, 12, 2, 40)
+    RNG_DISPATCH(64, 64, 10, 2, 40)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_rng_f16x3: no kernel for Cin=%d Cout=%d", cin, cout);
 }
 

@@ -222,7 +222,7 @@ def rows_convert(x, to_pair):
 # the range-gather form of the LDS-DMA kernel (27-tap submanifold layers of these channel pairs; "rng" = wherever it
 # is built, "auto" = RNG_PAIRS, measured)
 RNG_BUILT = {(32, 32), (64, 64)}
-RNG_PAIRS = set()             # measured: the per-tap kernel stays ahead; AL3D_SPCONV=rng to run it
+RNG_PAIRS = {(32, 32)}        # measured: ahead of the per-tap kernel at 32 channels, behind at 64
 if _os.environ.get("AL3D_RNG_PAIRS") is not None:   # dev override, e.g. "32x32,64x64" or "" for none
     RNG_PAIRS = {tuple(int(v) for v in t.split("x")) for t in _os.environ["AL3D_RNG_PAIRS"].split(",") if t}
 
