@@ -173,3 +173,12 @@ def test_depth_lss_transform_matches_torch_restatement():
     assert got.shape == ref.shape == (B, 90, 90, C)
     assert float(ref.abs().max()) > 0
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-5
+
+
+def test_depth_image_without_points_is_all_zero():
+    from al3d.models.bevfusion_camera import DepthLSSTransform
+    vt = DepthLSSTransform(32, 16, (64, 176), (8, 22), [-54.0, 54.0, 0.6], [-54.0, 54.0, 0.6], [-10.0, 10.0, 20.0],
+                           [1.0, 60.0, 1.0], downsample=2).to(DEV)
+    K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = _camera_setup(1, 6, 3, (64, 176))
+    d = vt.depth_image([torch.zeros((0, 5), device=DEV)], lidar2image.to(DEV), img_aug.to(DEV), lidar_aug.to(DEV))
+    assert d.shape == (1, 6, 64, 176) and float(d.abs().max()) == 0.0

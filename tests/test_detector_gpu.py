@@ -786,3 +786,33 @@ def test_uncertainty_sweeps_compose(oracle, tmp_path):
     es = build_selector(dict(type="EntropySelector", dataloader=loader(), buffer_path="", **common))
     es.select_samples(local_rank=0)
     assert es.selected_index["2"][-1] == 2 and len(es.selected_index["2"]) >= 2
+
+
+def test_round2_sparse_entry_points_accept_empty_inputs():
+    """Edge cases of the round-2 C entry points: zero rows (an empty level) must be a no-op, not a launch with a zero
+    grid; bad io flags / channel counts are rejected with a message."""
+    from al3d import detector_ops as D, lib
+    from al3d.selector_ops import _ptr, _stream
+    st = _stream()
+    dummy = torch.zeros(8, device=DEV)
+    idummy = torch.zeros(8, dtype=torch.int32, device=DEV)
+    lib.call("al3d_sp_tile_ranges", _ptr(idummy), 0, 27, 0, _ptr(idummy), st)
+    lib.call("al3d_sp_conv_rng_f16x3", _ptr(dummy), _ptr(idummy), 0, _ptr(idummy), _ptr(idummy), 27, _ptr(dummy), 32, 32,
+             _ptr(dummy), None, None, 1, _ptr(dummy), 0, 0, st)
+    lib.call("al3d_sp_conv_glds_f16x3_io", _ptr(dummy), _ptr(idummy), 0, _ptr(idummy), 27, _ptr(dummy), 32, 32, _ptr(dummy),
+             None, None, 1, _ptr(dummy), 0, 3, st)
+    assert D.rows_convert(torch.zeros((0, 32), device=DEV), True).shape == (0, 32)
+    with pytest.raises(lib.Al3dError, match="multiple of 8"):
+        D.rows_convert(torch.zeros((4, 12), device=DEV), True)
+    with pytest.raises(lib.Al3dError, match="io flags"):
+        lib.call("al3d_sp_conv_rng_f16x3", _ptr(dummy), _ptr(idummy), 256, _ptr(idummy), _ptr(idummy), 27, _ptr(dummy), 32, 32,
+                 _ptr(dummy), None, None, 1, _ptr(dummy), 4, 9, st)
+    with pytest.raises(lib.Al3dError, match="27-tap"):
+        lib.call("al3d_sp_conv_rng_f16x3", _ptr(dummy), _ptr(idummy), 256, _ptr(idummy), _ptr(idummy), 3, _ptr(dummy), 32, 32,
+                 _ptr(dummy), None, None, 1, _ptr(dummy), 4, 0, st)
+    # pair rows survive a round trip through the module-level accessor
+    from al3d.models.backbones import SparseTensor
+    x = torch.randn(64, 32, device=DEV)
+    sp = SparseTensor(D.rows_convert(x, True), torch.zeros((64, 4), dtype=torch.int32, device=DEV), [1, 8, 8], 1, pair_rows=True)
+    assert float((sp.features - x).abs().max()) <= 2.0 ** -21 * float(x.abs().max())
+    assert sp.features is sp.features                                  # converted once
