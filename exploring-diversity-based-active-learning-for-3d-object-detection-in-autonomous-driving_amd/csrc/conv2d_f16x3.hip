@@ -37,6 +37,7 @@
 //   conv2d_f16x3_bstream_kernel   any geometry, activation tile in LDS, weights streamed       (>= 24 steps)
 //   conv2d_f16x3_kernel           any geometry, both tiles through LDS                         (short launches, deconv)
 #include "al3d_common.h"
+#include "sp_rows.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -64,6 +65,7 @@ struct ConvF3Params {
     int64_t plane;          // elements per weight plane = Cout * taps * Cin
     float* gap;             // optional [B][gap_parts][ldc]: per-workgroup channel sums of the stored values (fused GAP)
     int gap_parts;
+    int io = 0;             // row formats of in / out (sp_rows.h: bit 0 = in pair pixels, bit 1 = write pair pixels); DMA kernel only
 };
 
 // 1-D grid -> (pixel tile, column block).  Blocks with equal blockIdx % 8 share an XCD and its L2,
@@ -505,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(ConvF3Params
 // previous chunk -- and one after its last store), and the four waves drift freely in between.
 // LDS traffic per step and CU: 83 KB -> 35 KB; L2 -> CU traffic doubles (both M-waves of a block
 // load the same weights: 32 KB per step and CU, ~40 % of the vector L1's 64 B/clk).
+template <int IO = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char Ah[2][2][G3_HP * F3_LDB];      // [chunk parity][plane] 39.2 KB
@@ -653,6 +656,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
         chunk_body(F3_IC(1), chunk0 + 1);
     }
 
+    if constexpr (IO != 1) {
+        // Each image row of the wave's tile (32 pixels x 64 channels) goes through a wave-private scratch in the halo
+        // storage so that a lane holds 8 consecutive channels of a pixel and stores 32 contiguous bytes with two
+        // 16-byte stores (-3 % against one dword per lane and C register straight from the fragment layout; IO = 1
+        // keeps that form for A/B).  IO = 2: pair pixels out (sp_rows.h; the consumers are the DMA-fed generic
+        // launches, which then skip their split): the lane splits its 8 values once and stores xh[8] | xl'[8].
+        __syncthreads();                               // every wave is done reading the halo buffers
+        constexpr int SP = 68;
+        float* scr = reinterpret_cast<float*>(&Ah[0][0][0]) + wave * (32 * SP);
+        static_assert(4 * 32 * SP * 4 <= (int)sizeof(Ah), "scratch must fit the halo storage");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int y = ty_ * G3_TH + 2 * wm + i;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + fr;
+                const float sc = p.scale[n];
+                const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (p.relu) v = v <= 0.f ? 0.f : v;
+                    scr[((r & 3) + 8 * (r >> 2) + 4 * fh) * SP + j * 32 + fr] = v;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = lane + 64 * q, pl = t >> 3, g = t & 7;
+                const int x = tx_ * G3_TW + pl;
+                if (y >= p.OH || x >= p.OW) continue;
+                const float4 a = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8);
+                const float4 b4 = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8 + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+                float* o = p.out + (((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n0 + wn * 64 + g * 8;
+                if constexpr ((IO & SP_IO_OUT_PAIR) != 0) {
+                    uint4 hi, lo;
+                    sp_split8(v, hi, lo);
+                    *reinterpret_cast<uint4*>(o) = hi;
+                    *reinterpret_cast<uint4*>(o + 4) = lo;
+                } else {
+                    *reinterpret_cast<float4*>(o) = a;
+                    *reinterpret_cast<float4*>(o + 4) = b4;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + fr;
@@ -1179,9 +1232,28 @@ extern "C" int al3d_conv3x3_nhwc_f16x3_frag16(const float* in, const void* wgt_f
     return AL3D_OK;
 }
 
+static int conv3x3_frag_impl(const float* in, const void* wgt_frag, const float* scale, const float* shift, float* out,
+                             int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu, int io, void* stream);
+
 extern "C" int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_frag, const float* scale,
                                             const float* shift, float* out, int B, int H, int W, int Cin,
                                             int Cout, int ldc, int coff, int relu, void* stream)
+{
+    return conv3x3_frag_impl(in, wgt_frag, scale, shift, out, B, H, W, Cin, Cout, ldc, coff, relu, 0, stream);
+}
+
+// ... writing pair pixels (io = 2, csrc/sp_rows.h) for a consumer on the LDS-DMA kernel; io = 0: as above
+extern "C" int al3d_conv3x3_nhwc_f16x3_frag_io(const float* in, const void* wgt_frag, const float* scale,
+                                               const float* shift, float* out, int B, int H, int W, int Cin,
+                                               int Cout, int ldc, int coff, int relu, int io, void* stream)
+{
+    AL3D_REQUIRE(io == 0 || (io == 2 && ldc % 8 == 0 && coff % 8 == 0),
+                 "al3d_conv3x3_nhwc_f16x3_frag_io: io must be 0 or 2 (pair output; ldc, coff multiples of 8)");
+    return conv3x3_frag_impl(in, wgt_frag, scale, shift, out, B, H, W, Cin, Cout, ldc, coff, relu, io, stream);
+}
+
+static int conv3x3_frag_impl(const float* in, const void* wgt_frag, const float* scale, const float* shift, float* out,
+                             int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu, int io, void* stream)
 {
     ConvF3Params p;
     p.gap = nullptr; p.gap_parts = 0;
@@ -1200,7 +1272,12 @@ extern "C" int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_fra
     p.tiles_x = (int)al3d_cdiv(p.OW, G3_TW);
     p.tiles_y = (int)al3d_cdiv(p.OH, G3_TH);
     p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = Cout / F3_BN;
-    hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    static int direct = -1;                            // AL3D_FRAG_EPI=direct: the untransposed f32 epilogue, for A/B
+    if (direct < 0) { const char* e = getenv("AL3D_FRAG_EPI"); direct = e && e[0] == 'd'; }
+    const bool vec_ok = ldc % 4 == 0 && coff % 4 == 0 && ((uintptr_t)out & 15) == 0;
+    if (io & SP_IO_OUT_PAIR) hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel<2>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (direct || !vec_ok) hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel<1>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel<0>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("conv3x3_f16x3_frag_kernel");
     return AL3D_OK;
 }
@@ -1534,7 +1611,7 @@ struct DgOps {
     f16x8 ah[2], al[2], wh[2], wl[2], wd[2];
 };
 
-template <int MODE, int NS>
+template <int MODE, int NS, int IO = 0>
 __global__ __launch_bounds__(256, 2) void conv2d_f16x3_dma2_kernel(ConvF3Params p)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * DG_STAGE];
@@ -1610,9 +1687,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_dma2_kernel(ConvF3Params 
     const unsigned offB = (unsigned)(DG_BOFF + (wn * 64 + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) * 16));
 
     DgOps A, B;
+    constexpr bool in_pair = (IO & SP_IO_IN_PAIR) != 0;                      // row formats are compile-time: no branch in the loop
     auto finish = [&](DgOps& o, const dg_f32x4& r0l, const dg_f32x4& r0h, const dg_f32x4& r1l, const dg_f32x4& r1h) {
-        dg_split8(r0l, r0h, o.ah[0], o.al[0]);
-        dg_split8(r1l, r1h, o.ah[1], o.al[1]);
+        if constexpr (in_pair) {                         // pair pixels: the 32 bytes of a fragment ARE (xh[8], xl'[8])
+            o.ah[0] = __builtin_bit_cast(f16x8, r0l); o.al[0] = __builtin_bit_cast(f16x8, r0h);
+            o.ah[1] = __builtin_bit_cast(f16x8, r1l); o.al[1] = __builtin_bit_cast(f16x8, r1h);
+        } else {
+            dg_split8(r0l, r0h, o.ah[0], o.al[0]);
+            dg_split8(r1l, r1h, o.ah[1], o.al[1]);
+        }
         o.wd[0] = lift_down(o.wh[0]);
         o.wd[1] = lift_down(o.wh[1]);
     };
@@ -1685,6 +1768,70 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_dma2_kernel(ConvF3Params 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the VALU reads them
 
     const f32x16* accp[2][2] = {{&c00, &c01}, {&c10, &c11}};
+    if constexpr ((IO & SP_IO_OUT_PAIR) != 0) {
+        // pair pixels out (sp_rows.h): BN / ReLU / GAP sums in the C layout as below, then each 32-pixel x 64-channel
+        // half of the wave's tile goes through a wave-private LDS scratch (the stage ring, free after the barrier) so
+        // that a lane holds 8 consecutive channels of a pixel, splits them once and stores xh[8] | xl'[8]
+        __syncthreads();                               // every wave is done reading the stage ring
+        constexpr int SP = 68;                         // floats per scratch row (64 + 4: conflict-free b128 reads)
+        float* scr = reinterpret_cast<float*>(smem) + wave * (32 * SP);
+        float gs[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + fr;
+                const bool nok = n < p.Cout;
+                const float sc = nok ? p.scale[n] : 0.f;
+                const float sh = (nok && p.shift) ? p.shift[n] : 0.0f;
+                const f32x16& acc = *accp[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int m = wm * 64 + i * 32 + ml;
+                    const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                    float v = acc[r] * sc + sh;
+                    if (p.relu) v = v <= 0.f ? 0.f : v;
+                    scr[ml * SP + j * 32 + fr] = v;
+                    if (y < MH && x < MW) gs[j] += v;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = lane + 64 * q, pl = t >> 3, g = t & 7;
+                const int m = wm * 64 + i * 32 + pl;
+                const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                const int n = n0 + wn * 64 + g * 8;
+                if (y >= MH || x >= MW || n >= p.Cout) continue;
+                const float4 a = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8);
+                const float4 b4 = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8 + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+                uint4 hi, lo;
+                sp_split8(v, hi, lo);
+                int oy = y, ox = x;
+                if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
+                float* o = p.out + (((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n;
+                *reinterpret_cast<uint4*>(o) = hi;
+                *reinterpret_cast<uint4*>(o + 4) = lo;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (p.gap) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + fr;
+                float gsum = gs[j];
+                gsum += __shfl_xor(gsum, 32);
+                if (fh == 0 && n < p.Cout) {
+                    const int part = (((ty_ * p.tiles_x + tx_) * (MODE == 1 ? 4 : 1) + tap0) << 1) + wm;
+                    p.gap[((int64_t)b * p.gap_parts + part) * p.ldc + p.coff + n] = gsum;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + fr;
@@ -1773,6 +1920,12 @@ static int dma_pipe()
 
 template <int MODE> static void launch_dma(const ConvF3Params& p, dim3 grid, hipStream_t s)
 {
+    if (dma_pipe() && p.io) {                          // pair pixels: three-stage shape only
+        if (p.io == 1) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 1>), grid, dim3(256), 0, s, p);
+        else if (p.io == 2) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 3>), grid, dim3(256), 0, s, p);
+        return;
+    }
     if (dma_pipe()) {
         if (dma_stages() == 5) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 5>), grid, dim3(256), 0, s, p);
         else if (dma_stages() == 4) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 4>), grid, dim3(256), 0, s, p);
@@ -1790,10 +1943,13 @@ template <int MODE> static void launch_dma(const ConvF3Params& p, dim3 grid, hip
 extern "C" int al3d_conv2d_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale,
                                           const float* shift, float* out, int B, int H, int W, int Cin,
                                           int Cout, int ksize, int stride, int pad, int ldc, int coff,
-                                          int relu, float* gap_part, int gap_parts, void* stream)
+                                          int relu, float* gap_part, int gap_parts, int io, void* stream)
 {
     ConvF3Params p;
-    p.gap = gap_part; p.gap_parts = gap_parts;
+    p.gap = gap_part; p.gap_parts = gap_parts; p.io = io;
+    AL3D_REQUIRE(io >= 0 && io < 4 && (!(io & 2) || (Cout % 8 == 0 && ldc % 8 == 0 && coff % 8 == 0)),
+                 "al3d_conv2d_nhwc_f16x3_dma: bad io flags (pair output needs Cout, ldc, coff multiples of 8)");
+    AL3D_REQUIRE(io == 0 || dma_pipe(), "al3d_conv2d_nhwc_f16x3_dma: pair pixels need the pipelined kernel (AL3D_DMA_PIPE=1)");
     p.in = in; p.wgt = (const _Float16*)wgt_image; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.ldc = ldc; p.coff = coff; p.relu = relu;
@@ -1818,10 +1974,13 @@ extern "C" int al3d_conv2d_nhwc_f16x3_dma(const float* in, const void* wgt_image
 extern "C" int al3d_deconv2x2_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale,
                                              const float* shift, float* out, int B, int H, int W, int Cin,
                                              int Cout, int ldc, int coff, int relu, float* gap_part, int gap_parts,
-                                             void* stream)
+                                             int io, void* stream)
 {
     ConvF3Params p;
-    p.gap = gap_part; p.gap_parts = gap_parts;
+    p.gap = gap_part; p.gap_parts = gap_parts; p.io = io;
+    AL3D_REQUIRE(io >= 0 && io < 4 && (!(io & 2) || (Cout % 8 == 0 && ldc % 8 == 0 && coff % 8 == 0)),
+                 "al3d_deconv2x2_nhwc_f16x3_dma: bad io flags (pair output needs Cout, ldc, coff multiples of 8)");
+    AL3D_REQUIRE(io == 0 || dma_pipe(), "al3d_deconv2x2_nhwc_f16x3_dma: pair pixels need the pipelined kernel (AL3D_DMA_PIPE=1)");
     p.in = in; p.wgt = (const _Float16*)wgt_image; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = 2; p.stride = 2; p.pad = 0; p.ldc = ldc; p.coff = coff; p.relu = relu;

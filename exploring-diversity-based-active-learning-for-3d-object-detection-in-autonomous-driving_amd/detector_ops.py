@@ -208,6 +208,9 @@ if _os.environ.get("AL3D_GLDS_PAIRS"):           # dev override, e.g. "32x32,64x
 # row format of the f16x3 sparse encoder's activations between layers (csrc/sp_rows.h): "pair" = the two f16 planes
 # of the arithmetic, split once in the producer's epilogue; "f32" = plain rows, split per gathered (row, tap)
 SPROWS = _os.environ.get("AL3D_SPROWS", "pair")
+# the same format for the dense neck's maps where the consumer is the LDS-DMA kernel (block outputs -> stride-2 conv /
+# deblocks, concat map -> fused head): "pair" | "f32"
+DPIX = _os.environ.get("AL3D_DPIX", "pair")
 IO_IN_PAIR, IO_OUT_PAIR, IO_RES_PAIR = 1, 2, 4
 
 
@@ -256,7 +259,7 @@ def gap_fusable(w_packed):
     return isinstance(w_packed, torch.Tensor) and w_packed.dtype == torch.float16
 
 
-def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, coff=0, gap=None):
+def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, coff=0, gap=None, io=0):
     """gap: optional [B, parts, ldc] f32 buffer (parts = al3d_gap_parts_count): the launch also writes its
     workgroups' channel sums there (f16x3 planes only, see gap_fusable)."""
     x = _dev(x, torch.float32, "x")
@@ -275,23 +278,30 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
         if out is None:
             out = torch.empty((B, OH, OW, pk.cout), dtype=torch.float32, device=x.device)
         assert out.shape[:3] == (B, OH, OW) and out.is_contiguous()
+        if pk.kind == "frag3x3":
+            if io not in (0, IO_OUT_PAIR):
+                raise lib.Al3dError("conv2d_nhwc: the streamed 3x3 kernel reads f32 pixels (it may write pair pixels)")
+            if gap is not None:
+                raise lib.Al3dError("conv2d_nhwc: this weight format has no fused GAP (see gap_fusable)")
+            lib.call("al3d_conv3x3_nhwc_f16x3_frag_io", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
+                     B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, io, _stream())
+            return out
+        if pk.kind == "dma":
+            lib.call("al3d_conv2d_nhwc_f16x3_dma", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
+                     B, H, W, Cin, pk.cout, ksize, stride, pad, out.shape[3], coff, 1 if relu else 0,
+                     _ptr(gap), 0 if gap is None else gap.shape[1], io, _stream())
+            return out
+        if io:
+            raise lib.Al3dError("conv2d_nhwc: pair pixels exist for the streamed 3x3 (output) and LDS-DMA kernels only")
+        if gap is not None:
+            raise lib.Al3dError("conv2d_nhwc: this weight format has no fused GAP (see gap_fusable)")
         if pk.kind == "frag16":
             lib.call("al3d_conv3x3_nhwc_f16x3_frag16", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
                      B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
-        elif pk.kind == "frag3x3":
-            lib.call("al3d_conv3x3_nhwc_f16x3_frag", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
-                     B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, _stream())
-        elif pk.kind == "dma":
-            lib.call("al3d_conv2d_nhwc_f16x3_dma", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
-                     B, H, W, Cin, pk.cout, ksize, stride, pad, out.shape[3], coff, 1 if relu else 0,
-                     _ptr(gap), 0 if gap is None else gap.shape[1], _stream())
-            return out
         else:
             lib.call("al3d_conv2d_nhwc_f16x3_bstream", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift),
                      _ptr(out), B, H, W, Cin, pk.cout, ksize, stride, pad, out.shape[3], coff,
                      1 if relu else 0, _stream())
-        if gap is not None:
-            raise lib.Al3dError("conv2d_nhwc: this weight format has no fused GAP (see gap_fusable)")
         return out
     w_packed = _dev(w_packed, w_packed.dtype, "w")
     wshape = w_packed.shape[1:] if kind != "f32" else w_packed.shape
@@ -303,6 +313,8 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
     if out is None:
         out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, OH, OW) and out.is_contiguous()
+    if io:
+        raise lib.Al3dError("conv2d_nhwc: pair pixels need fragment-ordered / LDS-DMA weights (pack_dense)")
     if gap is not None:
         if not gap_fusable(w_packed):
             raise lib.Al3dError("conv2d_nhwc: the fused GAP needs plain f16x3 planes")
@@ -315,7 +327,7 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
     return out
 
 
-def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0, gap=None):
+def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0, gap=None, io=0):
     x = _dev(x, torch.float32, "x")
     B, H, W, Cin = x.shape
     kind = _DENSE_KIND[w_packed.dtype]
@@ -331,8 +343,10 @@ def deconv2x2_nhwc(x, w_packed, scale, shift, relu, out=None, coff=0, gap=None):
         if pk.kind == "dma":
             lib.call("al3d_deconv2x2_nhwc_f16x3_dma", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
                      B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0,
-                     _ptr(gap), 0 if gap is None else gap.shape[1], _stream())
+                     _ptr(gap), 0 if gap is None else gap.shape[1], io, _stream())
             return out
+        if io:
+            raise lib.Al3dError("deconv2x2_nhwc: pair pixels exist for the LDS-DMA kernel only")
         if gap is not None:
             raise lib.Al3dError("deconv2x2_nhwc: this weight format has no fused GAP (see gap_fusable)")
         lib.call("al3d_deconv2x2_nhwc_f16x3_bstream", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift),

@@ -116,13 +116,14 @@ SIGNATURES = {
     "al3d_pack_f16x3_frag16": (c_int, [c_p, c_int, c_int, c_p, c_p]),
     "al3d_conv3x3_nhwc_f16x3_frag16": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_conv3x3_nhwc_f16x3_frag": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
+    "al3d_conv3x3_nhwc_f16x3_frag_io": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 9 + [c_p]),
     "al3d_pack_f16x3_bstream_elems": (c_i64, [c_int, c_int, c_int]),
     "al3d_pack_f16x3_bstream": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
     "al3d_conv2d_nhwc_f16x3_bstream": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p]),
     "al3d_deconv2x2_nhwc_f16x3_bstream": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "al3d_pack_f16x3_dma": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
-    "al3d_conv2d_nhwc_f16x3_dma": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p, c_int, c_p]),
-    "al3d_deconv2x2_nhwc_f16x3_dma": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p, c_int, c_p]),
+    "al3d_conv2d_nhwc_f16x3_dma": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p, c_int, c_int, c_p]),
+    "al3d_deconv2x2_nhwc_f16x3_dma": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p, c_int, c_int, c_p]),
     "al3d_stream_create_cu_mask": (c_int, [c_int, c_int, c_p]),
     "al3d_lss_geometry_workspace_bytes": (c_i64, [c_int]),
     "al3d_lss_geometry_f32": (c_int, [c_p, c_i64, c_p, c_int, c_p, c_p, c_p]),

@@ -143,12 +143,17 @@ class MultiGroupHead(nn.Module):
         self._b = torch.cat([b.detach() for b in bs]).float().contiguous().to(device)
         self._packed_dev = (device, D.MATH, D.DENSE)
 
-    def forward(self, x, finetune=False):
+    def accepts_pair(self, device):
+        """True when the fused head convolution runs on the LDS-DMA kernel and can read pair pixels."""
+        self._prepare(device)
+        return D.MATH == "f16x3" and D.DPIX == "pair" and getattr(self._w, "kind", None) == "dma"
+
+    def forward(self, x, finetune=False, in_pair=False):
         """x NHWC [B,H,W,512] -> list of per-task dicts with NHWC views
         (``box_preds [B,H,W,na*10]``, ``cls_preds [B,H,W,na*nc]``) like Head.forward
         (mg_head.py:222-231), plus the fused buffer under ``_fused``."""
         self._prepare(x.device)
-        fused = D.conv2d_nhwc(x, self._w, self._wscale, self._b, 1, 1, 0, False)
+        fused = D.conv2d_nhwc(x, self._w, self._wscale, self._b, 1, 1, 0, False, io=D.IO_IN_PAIR if in_pair else 0)
         rets = []
         for t, task in enumerate(self.tasks):
             b0, c0 = self._box_off[t], self._cls_off[t]

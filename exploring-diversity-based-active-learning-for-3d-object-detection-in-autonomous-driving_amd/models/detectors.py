@@ -17,18 +17,26 @@ from .registry import DETECTORS
 class NHWCFeature:
     """A ``[B,C,H,W]``-shaped view of an NHWC buffer for the selectors' embedding tap."""
 
-    def __init__(self, nhwc, embedding=None):
-        self.nhwc = nhwc
+    def __init__(self, nhwc, embedding=None, pair=False):
+        self._nhwc, self._pair = nhwc, pair   # pair: the buffer holds pair pixels (csrc/sp_rows.h), converted on access
         self._emb = embedding           # [B,C] global average the neck already produced (fused GAP), or None
         B, H, W, C = nhwc.shape
         self.shape = torch.Size((B, C, H, W))
         self.device = nhwc.device
         self._w_reduced = False
 
+    @property
+    def nhwc(self):
+        if self._pair:
+            C = self._nhwc.shape[-1]
+            self._nhwc, self._pair = D.rows_convert(self._nhwc.view(-1, C), False).view_as(self._nhwc), False
+        return self._nhwc
+
     def mean(self, dim=-1):
         if not self._w_reduced:
             r = NHWCFeature.__new__(NHWCFeature)
-            r.nhwc, r.shape, r.device, r._w_reduced, r._emb = self.nhwc, self.shape[:3], self.device, True, self._emb
+            r._nhwc, r._pair, r.shape, r.device, r._w_reduced, r._emb = \
+                self._nhwc, self._pair, self.shape[:3], self.device, True, self._emb
             return r
         if self._emb is not None:
             return self._emb                   # emitted by the neck's deblock launches (al3d_*_gap)
@@ -95,15 +103,21 @@ class FPNVoxelNet(SingleStageDetector):
         return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
 
     def dense_stage(self, example, x, middle, finetune=False, **kwargs):
+        pair = False
         if self.with_neck:
-            x = self.neck(x)
-            middle.append(NHWCFeature(x, getattr(self.neck, "embedding", None)))
+            want = self.bbox_head is not None and hasattr(self.bbox_head, "accepts_pair") and \
+                self.bbox_head.accepts_pair(x.device)
+            import inspect
+            want = want and "out_pair" in inspect.signature(self.neck.forward).parameters
+            x = self.neck(x, out_pair=True) if want else self.neck(x)
+            pair = bool(want and getattr(self.neck, "last_out_pair", False))
+            middle.append(NHWCFeature(x, getattr(self.neck, "embedding", None), pair=pair))
         if self.bbox_head is None:
             if not kwargs.get("estimate", False):
                 raise RuntimeError("this detector was built without a bbox_head: only the estimate=True "
                                    "embedding sweep is available")
             return [dict(metadata=m) for m in example.get("metadata", [None] * x.shape[0])], middle
-        preds = self.bbox_head(x, finetune=finetune)
+        preds = self.bbox_head(x, finetune=finetune, in_pair=True) if pair else self.bbox_head(x, finetune=finetune)
         if kwargs.get("get_preds", False):
             return preds
         out = self.bbox_head.predict(example, preds, self.test_cfg)

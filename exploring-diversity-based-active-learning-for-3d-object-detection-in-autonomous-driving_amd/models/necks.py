@@ -99,21 +99,49 @@ class RPN(nn.Module):
                                              k=up.kernel_size[0], s=up.stride[0]))
         self._packed_dev = (device, D.MATH, D.DENSE)
 
-    def forward(self, x):
-        """x NHWC [B,H,W,Cin] -> NHWC [B,H',W',sum(us_num_filters)]."""
+    def _kind(self, w):
+        return getattr(w, "kind", None)
+
+    def forward(self, x, out_pair=False):
+        """x NHWC [B,H,W,Cin] -> NHWC [B,H',W',sum(us_num_filters)].
+
+        Pair pixels (csrc/sp_rows.h, ``AL3D_DPIX``): a block's output whose consumers all run on the LDS-DMA kernel (the
+        next block's strided entry conv, the block's deblock) is written as pair pixels by the block's last 3x3 launch
+        and read without a split -- invisible outside.  ``out_pair=True`` asks for the concatenated map in that format
+        too (for a head on the LDS-DMA kernel); ``self.last_out_pair`` says whether it was granted (it needs the fused
+        GAP: the embedding is then taken from the f32 values inside the deblock launches)."""
         if self.training:
             raise RuntimeError("al3d RPN implements the eval() sweep only")
         self._prepare(x.device)
+        pairing = D.MATH == "f16x3" and D.DPIX == "pair"
         out, coff = None, 0
         ctot = sum(self._num_upsample_filters)
         # fused GAP: every deblock launch runs on the generic f16x3 kernel (plain planes) -> they can emit the
         # embedding's partial sums while they store the map (saves re-reading 33.5 MB per frame)
         fuse = D.GAP == "fused" and len(self._deblocks_p) == len(self._blocks_p) - self._upsample_start_idx and             all(D.gap_fusable(d["w"]) for d in self._deblocks_p)
         gap, self.embedding = None, None
+        out_pair = bool(out_pair and pairing and fuse and all(self._kind(d["w"]) == "dma" for d in self._deblocks_p))
+        self.last_out_pair = out_pair
+        x_pair = False
         for i, convs in enumerate(self._blocks_p):
-            for c in convs:
-                x = D.conv2d_nhwc(x, c["w"], c["scale"], c["shift"], c["k"], c["s"], c["p"], True)
             j = i - self._upsample_start_idx
+            # may this block's output be pair pixels?  every consumer must be an LDS-DMA launch
+            consumers = []
+            if j >= 0:
+                consumers.append(self._deblocks_p[j]["w"])
+            if i + 1 < len(self._blocks_p):
+                consumers.append(self._blocks_p[i + 1][0]["w"])
+            blk_pair = pairing and len(convs) > 1 and self._kind(convs[-1]["w"]) == "frag3x3" and \
+                convs[-1]["scale"].shape[0] % 8 == 0 and all(self._kind(w) == "dma" for w in consumers)
+            for ci, c in enumerate(convs):
+                io = 0
+                if ci == 0 and x_pair:
+                    io |= D.IO_IN_PAIR
+                if ci == len(convs) - 1 and blk_pair:
+                    io |= D.IO_OUT_PAIR
+                assert ci == 0 or not (io & D.IO_IN_PAIR)
+                x = D.conv2d_nhwc(x, c["w"], c["scale"], c["shift"], c["k"], c["s"], c["p"], True, io=io)
+            x_pair = blk_pair
             if j >= 0:
                 d = self._deblocks_p[j]
                 B, H, W, _ = x.shape
@@ -135,12 +163,17 @@ class RPN(nn.Module):
                             gap = (torch.zeros if len(set(all_parts)) > 1 else torch.empty)(
                                 (B, max(all_parts), ctot), dtype=torch.float32, device=x.device)
                         g = gap
+                dio = (D.IO_IN_PAIR if x_pair else 0) | (D.IO_OUT_PAIR if out_pair else 0)
                 if d["deconv"]:
-                    D.deconv2x2_nhwc(x, d["w"], d["scale"], d["shift"], True, out=out, coff=coff, gap=g)
+                    D.deconv2x2_nhwc(x, d["w"], d["scale"], d["shift"], True, out=out, coff=coff, gap=g, io=dio)
                 else:
                     D.conv2d_nhwc(x, d["w"], d["scale"], d["shift"], d["k"], d["s"], 0, True, out=out,
-                                  coff=coff, gap=g)
+                                  coff=coff, gap=g, io=dio)
                 coff += d["scale"].shape[0]
         if fuse and gap is not None and out is not None and coff == ctot:
             self.embedding = D.gap_reduce_parts(gap, out.shape[1] * out.shape[2])
+        if out_pair and self.embedding is None:          # the fused GAP was dropped on the way: hand out f32 after all
+            out = D.rows_convert(out.view(-1, ctot), False).view_as(out)
+            self.last_out_pair = False
+        assert out is not None or not x_pair
         return out if out is not None else x

@@ -417,6 +417,11 @@ int al3d_conv3x3_nhwc_f16x3_frag16(const float* in, const void* wgt_frag16, cons
 int al3d_conv3x3_nhwc_f16x3_frag(const float* in, const void* wgt_frag, const float* scale,
                                  const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
                                  int ldc, int coff, int relu, void* stream);
+/* ... writing pair pixels (io = 2; csrc/sp_rows.h, see al3d_conv2d_nhwc_f16x3_dma) for a consumer on the LDS-DMA kernel;
+ * io = 0: exactly the call above. */
+int al3d_conv3x3_nhwc_f16x3_frag_io(const float* in, const void* wgt_frag, const float* scale,
+                                    const float* shift, float* out, int B, int H, int W, int Cin, int Cout,
+                                    int ldc, int coff, int relu, int io, void* stream);
 /* Every other geometry (stride-2 block entry, 1x1 deblock, 2x2 deconvolution, fused 1x1 head:
  * rpn.py:66-113, mg_head.py:215-231) with the weights streamed the same way: activations staged
  * through LDS per (tap, 16-channel chunk), B fragments from al3d_pack_f16x3_bstream(): planes
@@ -438,14 +443,17 @@ int al3d_deconv2x2_nhwc_f16x3_bstream(const float* in, const void* wgt_frag, con
  * [2][Cout][taps][Cin] -> [ceil(Cout/128)][taps][Cin/16][2][128][16] f16 with the 16-byte halves of a row swizzled
  * (the LDS image of a step; al3d_pack_f16x3_bstream_elems() elements).  The activation split runs on the fragment.
  * gap_part may be NULL; otherwise as al3d_conv2d_nhwc_f16x3_gap.  Bit-identical to al3d_conv2d_nhwc_f16x3 /
- * al3d_deconv2x2_nhwc_f16x3 (and their _gap partials). */
+ * al3d_deconv2x2_nhwc_f16x3 (and their _gap partials).  io: pixel formats, as the sparse rows (csrc/sp_rows.h;
+ * al3d_sp_rows_convert_f16x3 converts [B*H*W][C] either way): bit 0 = `in` holds pair pixels (per 8 channels xh[8] |
+ * xl'[8]: the fragment is the operand pair, no split in the kernel), bit 1 = write pair pixels (needs Cout, ldc, coff
+ * multiples of 8); the GAP partials are always sums of the f32 values. */
 int al3d_pack_f16x3_dma(const void* planes_f16x2, int Cout, int taps, int Cin, void* out_image, void* stream);
 int al3d_conv2d_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale, const float* shift,
                                float* out, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
-                               int ldc, int coff, int relu, float* gap_part, int gap_parts, void* stream);
+                               int ldc, int coff, int relu, float* gap_part, int gap_parts, int io, void* stream);
 int al3d_deconv2x2_nhwc_f16x3_dma(const float* in, const void* wgt_image, const float* scale, const float* shift,
                                   float* out, int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu,
-                                  float* gap_part, int gap_parts, void* stream);
+                                  float* gap_part, int gap_parts, int io, void* stream);
 
 /* Fused global average pooling (feature_selector.py:68-71 tap): the two deblock launches of
  * the neck (1x1 conv and 2x2 transposed conv, rpn.py:124-142) can also emit, per workgroup and wave row, the channel

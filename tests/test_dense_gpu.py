@@ -303,3 +303,93 @@ def test_conv2d_f16x3_out_of_range_activation_is_not_silent():
     out = D.conv2d_nhwc(x.to(DEV), w3, sc3, None, 3, 1, 1, False).cpu()
     assert not torch.isfinite(out[0, 3, 3]).any()
     assert torch.isfinite(out[0, 7, 7]).all()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(2, 24, 40, 128, 256, 1, 1, 0), (1, 33, 20, 128, 256, 3, 2, 1),
+                                                  (2, 37, 21, 512, 236, 1, 1, 0), (1, 19, 50, 64, 40, 3, 1, 0)])
+def test_conv2d_dma_pair_pixels(B, H, W, Cin, Cout, k, s, p):
+    """Pair pixels on the LDS-DMA dense kernel (csrc/sp_rows.h format on NHWC maps): (1) a layer fed pair pixels
+    gives the bits of the layer fed the f32 map they were split from; (2) writing pair pixels = splitting the f32
+    output (untouched concat-window channels stay untouched); (3) the fused-GAP partials do not depend on the output
+    format; (4) both together compose."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(Cin + H + k)
+    x = (torch.randn(B, H, W, Cin, generator=g) * torch.exp(torch.randn(B, H, W, Cin, generator=g))).to(DEV)
+    w = (torch.randn(Cout, k * k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    w3, sc3 = D.split_f16x3(w, scale)
+    wd = D.pack_dma_f16x3(w3)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    xp = D.rows_convert(x.view(-1, Cin), True).view_as(x)
+    parts = D.gap_parts(OH, OW, False)
+    ldc = Cout + 24 if Cout % 8 == 0 else Cout
+
+    def run(xin, io, gap):
+        out = torch.full((B, OH, OW, ldc), -3.0, device=DEV)
+        D.conv2d_nhwc(xin, wd, sc3, shift, k, s, p, True, out=out, coff=ldc - Cout, gap=gap, io=io)
+        return out
+    g0 = torch.zeros(B, parts, ldc, device=DEV)
+    base = run(x, 0, g0)
+    g1 = torch.zeros_like(g0)
+    assert torch.equal(run(xp, D.IO_IN_PAIR, g1), base) and torch.equal(g1, g0)                  # (1)
+    if Cout % 8 == 0:
+        g2 = torch.zeros_like(g0)
+        outp = run(x, D.IO_OUT_PAIR, g2)
+        assert torch.equal(g2, g0)                                                               # (3)
+        assert torch.all(outp[..., :24] == -3.0)
+        want = D.rows_convert(base[..., 24:].reshape(-1, Cout).contiguous(), True)
+        assert torch.equal(outp[..., 24:].reshape(-1, Cout).view(torch.int32), want.view(torch.int32))      # (2)
+        both = run(xp, D.IO_IN_PAIR | D.IO_OUT_PAIR, torch.zeros_like(g0))
+        assert torch.equal(both.view(torch.int32), outp.view(torch.int32))                       # (4)
+    else:
+        with pytest.raises(Exception, match="multiples of 8"):
+            run(x, D.IO_OUT_PAIR, None)
+
+
+def test_deconv_dma_pair_pixels():
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 33, 20, 256, generator=g).to(DEV)
+    w = (torch.randn(256, 4, 256, generator=g) / 32.0).to(DEV)
+    scale = (torch.rand(256, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(256, generator=g) * 0.1).to(DEV)
+    w3, sc3 = D.split_f16x3(w, scale)
+    wd = D.pack_dma_f16x3(w3)
+    xp = D.rows_convert(x.view(-1, 256), True).view_as(x)
+    parts = D.gap_parts(66, 40, True)
+
+    def run(xin, io):
+        out = torch.full((2, 66, 40, 512), -3.0, device=DEV)
+        gap = torch.zeros(2, parts, 512, device=DEV)
+        D.deconv2x2_nhwc(xin, wd, sc3, shift, True, out=out, coff=256, gap=gap, io=io)
+        return out, gap
+    base, g0 = run(x, 0)
+    a, g1 = run(xp, D.IO_IN_PAIR)
+    assert torch.equal(a, base) and torch.equal(g1, g0)
+    b, g2 = run(xp, D.IO_IN_PAIR | D.IO_OUT_PAIR)
+    assert torch.equal(g2, g0) and torch.all(b[..., :256] == -3.0)
+    want = D.rows_convert(base[..., 256:].reshape(-1, 256).contiguous(), True)
+    assert torch.equal(b[..., 256:].reshape(-1, 256).view(torch.int32), want.view(torch.int32))
+
+
+def test_conv3x3_streamed_kernel_writes_pair_pixels():
+    """The streamed 3x3 kernel's pair-pixel epilogue (io = 2): the stored map is the split of the f32 output, the
+    channels outside the concat window stay untouched, ragged tiles included."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 37, 45, 64, generator=g).to(DEV)
+    w = (torch.randn(128, 9, 64, generator=g) / 24.0).to(DEV)
+    scale = (torch.rand(128, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(128, generator=g) * 0.1).to(DEV)
+    w3, sc3 = D.split_f16x3(w, scale)
+    wf = D.pack_frag_f16x3(w3)
+    a = torch.full((2, 37, 45, 160), -3.0, device=DEV)
+    b = torch.full((2, 37, 45, 160), -3.0, device=DEV)
+    D.conv2d_nhwc(x, wf, sc3, shift, 3, 1, 1, True, out=a, coff=32)
+    D.conv2d_nhwc(x, wf, sc3, shift, 3, 1, 1, True, out=b, coff=32, io=D.IO_OUT_PAIR)
+    assert torch.all(b[..., :32] == -3.0)
+    want = D.rows_convert(a[..., 32:].reshape(-1, 128).contiguous(), True)
+    assert torch.equal(b[..., 32:].reshape(-1, 128).view(torch.int32), want.view(torch.int32))
+    with pytest.raises(Exception, match="reads f32"):
+        D.conv2d_nhwc(x, wf, sc3, shift, 3, 1, 1, True, out=b, coff=32, io=D.IO_IN_PAIR)

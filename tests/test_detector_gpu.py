@@ -611,6 +611,14 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
                 D.SPROWS = saved_rows
             assert float((plain - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
             assert not torch.equal(plain, ref)          # the knob does something
+            # pair pixels inside the neck (block outputs -> stride-2 conv / deblocks, concat map -> head): products
+            # unchanged, the fused GAP sums the f32 values in both cases -> the SAME embedding bits
+            saved_pix = D.DPIX
+            try:
+                D.DPIX = "f32"
+                assert torch.equal(run(4), ref), "dense pair pixels changed the embedding"
+            finally:
+                D.DPIX = saved_pix
         for mode in (None, "ahead", "split"):
             S.PIPELINE = mode
             assert torch.equal(run(2), ref), mode

@@ -23,7 +23,13 @@ for (H, Cin, Cout, k, s, p) in shapes:
     if MODE == 'f16x3frag16':
         w, sc = D.split_f16x3(w, sc)
         w = D.pack_frag16_f16x3(w) if (D.frag_ok(Cout, Cin, k, s, p) and Cin % 64 == 0) else D.pack_bstream_f16x3(w)
-    if MODE == 'f16x3dma':
+    io = 0
+    if MODE == 'f16x3fragpair' and D.frag_ok(Cout, Cin, k, s, p):
+        io = D.IO_OUT_PAIR
+    if MODE == 'f16x3dmapair' and not D.frag_ok(Cout, Cin, k, s, p):
+        x = D.rows_convert(x.view(-1, Cin), True).view_as(x)
+        io = D.IO_IN_PAIR | (D.IO_OUT_PAIR if Cout % 8 == 0 else 0)
+    if MODE in ('f16x3dma', 'f16x3dmapair', 'f16x3fragpair'):
         w, sc = D.split_f16x3(w, sc)
         w = D.pack_frag_f16x3(w) if D.frag_ok(Cout, Cin, k, s, p) else D.pack_dma_f16x3(w)
     if MODE == 'f16x3frag':
@@ -32,13 +38,13 @@ for (H, Cin, Cout, k, s, p) in shapes:
     OH = (H + 2 * p - k) // s + 1
     out = torch.empty(B, OH, OH, Cout, device=dev)
     for _ in range(3):
-        D.conv2d_nhwc(x, w, sc, sh, k, s, p, True, out=out)
+        D.conv2d_nhwc(x, w, sc, sh, k, s, p, True, out=out, io=io)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 20
     e0.record()
     for _ in range(n):
-        D.conv2d_nhwc(x, w, sc, sh, k, s, p, True, out=out)
+        D.conv2d_nhwc(x, w, sc, sh, k, s, p, True, out=out, io=io)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * OH * OH * Cout * Cin * k * k
@@ -50,18 +56,22 @@ if MODE.startswith("f16x3"):
     w = torch.randn(256, 4, 256, device=dev) * 0.05
     sc = torch.ones(256, device=dev); sh = torch.zeros(256, device=dev)
     w, sc = D.split_f16x3(w, sc)
-    if MODE == "f16x3dma":
+    dio = 0
+    if MODE in ("f16x3dma", "f16x3dmapair"):
         w = D.pack_dma_f16x3(w)
+        if MODE == "f16x3dmapair":
+            x = D.rows_convert(x.view(-1, 256), True).view_as(x)
+            dio = D.IO_IN_PAIR | D.IO_OUT_PAIR
     elif MODE != "f16x3":
         w = D.pack_bstream_f16x3(w)
     out = torch.empty(B, 128, 128, 512, device=dev)
     for _ in range(3):
-        D.deconv2x2_nhwc(x, w, sc, sh, True, out=out, coff=256)
+        D.deconv2x2_nhwc(x, w, sc, sh, True, out=out, coff=256, io=dio)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        D.deconv2x2_nhwc(x, w, sc, sh, True, out=out, coff=256)
+        D.deconv2x2_nhwc(x, w, sc, sh, True, out=out, coff=256, io=dio)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     fl = 2.0 * B * 64 * 64 * 4 * 256 * 256
