@@ -1768,10 +1768,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_dma2_kernel(ConvF3Params 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the VALU reads them
 
     const f32x16* accp[2][2] = {{&c00, &c01}, {&c10, &c11}};
-    if constexpr ((IO & SP_IO_OUT_PAIR) != 0) {
-        // pair pixels out (sp_rows.h): BN / ReLU / GAP sums in the C layout as below, then each 32-pixel x 64-channel
-        // half of the wave's tile goes through a wave-private LDS scratch (the stage ring, free after the barrier) so
-        // that a lane holds 8 consecutive channels of a pixel, splits them once and stores xh[8] | xl'[8]
+    if constexpr ((IO & 4) == 0) {
+        // BN / ReLU / GAP sums in the C layout, then each 32-pixel x 64-channel half of the wave's tile goes through a
+        // wave-private LDS scratch (the stage ring, free after the barrier) so that a lane holds consecutive channels of
+        // a pixel and stores 16-byte pieces (IO & 4: the untransposed dword stores below, for layouts that are not
+        // 16-byte aligned).  Pair pixels out (IO & 2, sp_rows.h): 8 channels per lane, split once, xh[8] | xl'[8]
         __syncthreads();                               // every wave is done reading the stage ring
         constexpr int SP = 68;                         // floats per scratch row (64 + 4: conflict-free b128 reads)
         float* scr = reinterpret_cast<float*>(smem) + wave * (32 * SP);
@@ -1798,23 +1799,38 @@ __global__ __launch_bounds__(256, 2) void conv2d_f16x3_dma2_kernel(ConvF3Params 
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
+            if constexpr ((IO & SP_IO_OUT_PAIR) != 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = lane + 64 * q, pl = t >> 3, g = t & 7;
-                const int m = wm * 64 + i * 32 + pl;
-                const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
-                const int n = n0 + wn * 64 + g * 8;
-                if (y >= MH || x >= MW || n >= p.Cout) continue;
-                const float4 a = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8);
-                const float4 b4 = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8 + 4);
-                const float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
-                uint4 hi, lo;
-                sp_split8(v, hi, lo);
-                int oy = y, ox = x;
-                if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
-                float* o = p.out + (((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n;
-                *reinterpret_cast<uint4*>(o) = hi;
-                *reinterpret_cast<uint4*>(o + 4) = lo;
+                for (int q = 0; q < 4; ++q) {
+                    const int t = lane + 64 * q, pl = t >> 3, g = t & 7;
+                    const int m = wm * 64 + i * 32 + pl;
+                    const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                    const int n = n0 + wn * 64 + g * 8;
+                    if (y >= MH || x >= MW || n >= p.Cout) continue;
+                    const float4 a = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8);
+                    const float4 b4 = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8 + 4);
+                    const float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+                    uint4 hi, lo;
+                    sp_split8(v, hi, lo);
+                    int oy = y, ox = x;
+                    if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
+                    float* o = p.out + (((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n;
+                    *reinterpret_cast<uint4*>(o) = hi;
+                    *reinterpret_cast<uint4*>(o + 4) = lo;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {            // f32 pixels: one float4 per lane and trip (Cout % 4 == 0)
+                    const int t = lane + 64 * q, pl = t >> 4, g = t & 15;
+                    const int m = wm * 64 + i * 32 + pl;
+                    const int y = ty_ * F3_TH + m / F3_TW, x = tx_ * F3_TW + m % F3_TW;
+                    const int n = n0 + wn * 64 + g * 4;
+                    if (y >= MH || x >= MW || n >= p.Cout) continue;
+                    int oy = y, ox = x;
+                    if (MODE == 1) { oy = 2 * y + (tap0 >> 1); ox = 2 * x + (tap0 & 1); }
+                    *reinterpret_cast<float4*>(p.out + (((int64_t)b * p.OH + oy) * p.OW + ox) * p.ldc + p.coff + n) =
+                        *reinterpret_cast<const float4*>(scr + pl * SP + g * 4);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1920,16 +1936,25 @@ static int dma_pipe()
 
 template <int MODE> static void launch_dma(const ConvF3Params& p, dim3 grid, hipStream_t s)
 {
-    if (dma_pipe() && p.io) {                          // pair pixels: three-stage shape only
-        if (p.io == 1) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 1>), grid, dim3(256), 0, s, p);
-        else if (p.io == 2) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 2>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 3>), grid, dim3(256), 0, s, p);
+    // epilogue form: 16-byte stores through an LDS transposition need Cout, ldc, coff multiples of 4 and an aligned base
+    static int direct = -1;                            // AL3D_DMA_EPI=direct: untransposed dword stores everywhere, for A/B
+    if (direct < 0) { const char* e = getenv("AL3D_DMA_EPI"); direct = e && e[0] == 'd'; }
+    const bool vec_ok = p.Cout % 4 == 0 && p.ldc % 4 == 0 && p.coff % 4 == 0 && ((uintptr_t)p.out & 15) == 0;
+    if (dma_pipe() && dma_stages() == 3) {             // the shipped shape: all row / pixel format combinations
+        const int io = p.io | ((p.io & 2) == 0 && (direct || !vec_ok) ? 4 : 0);
+        switch (io) {
+        case 0: hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 0>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 1>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 2>), grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 3>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 4>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3, 5>), grid, dim3(256), 0, s, p); break;
+        }
         return;
     }
     if (dma_pipe()) {
-        if (dma_stages() == 5) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 5>), grid, dim3(256), 0, s, p);
-        else if (dma_stages() == 4) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 4>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 3>), grid, dim3(256), 0, s, p);
+        if (dma_stages() == 5) hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 5, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv2d_f16x3_dma2_kernel<MODE, 4, 4>), grid, dim3(256), 0, s, p);
         return;
     }
     switch (dma_stages()) {
@@ -1949,7 +1974,7 @@ extern "C" int al3d_conv2d_nhwc_f16x3_dma(const float* in, const void* wgt_image
     p.gap = gap_part; p.gap_parts = gap_parts; p.io = io;
     AL3D_REQUIRE(io >= 0 && io < 4 && (!(io & 2) || (Cout % 8 == 0 && ldc % 8 == 0 && coff % 8 == 0)),
                  "al3d_conv2d_nhwc_f16x3_dma: bad io flags (pair output needs Cout, ldc, coff multiples of 8)");
-    AL3D_REQUIRE(io == 0 || dma_pipe(), "al3d_conv2d_nhwc_f16x3_dma: pair pixels need the pipelined kernel (AL3D_DMA_PIPE=1)");
+    AL3D_REQUIRE(io == 0 || (dma_pipe() && dma_stages() == 3), "al3d_conv2d_nhwc_f16x3_dma: pair pixels need the shipped kernel shape (AL3D_DMA_PIPE=1, 3 stages)");
     p.in = in; p.wgt = (const _Float16*)wgt_image; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.ldc = ldc; p.coff = coff; p.relu = relu;
@@ -1980,7 +2005,7 @@ extern "C" int al3d_deconv2x2_nhwc_f16x3_dma(const float* in, const void* wgt_im
     p.gap = gap_part; p.gap_parts = gap_parts; p.io = io;
     AL3D_REQUIRE(io >= 0 && io < 4 && (!(io & 2) || (Cout % 8 == 0 && ldc % 8 == 0 && coff % 8 == 0)),
                  "al3d_deconv2x2_nhwc_f16x3_dma: bad io flags (pair output needs Cout, ldc, coff multiples of 8)");
-    AL3D_REQUIRE(io == 0 || dma_pipe(), "al3d_deconv2x2_nhwc_f16x3_dma: pair pixels need the pipelined kernel (AL3D_DMA_PIPE=1)");
+    AL3D_REQUIRE(io == 0 || (dma_pipe() && dma_stages() == 3), "al3d_deconv2x2_nhwc_f16x3_dma: pair pixels need the shipped kernel shape (AL3D_DMA_PIPE=1, 3 stages)");
     p.in = in; p.wgt = (const _Float16*)wgt_image; p.scale = scale; p.shift = shift; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ksize = 2; p.stride = 2; p.pad = 0; p.ldc = ldc; p.coff = coff; p.relu = relu;
