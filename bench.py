@@ -110,7 +110,7 @@ class ConvTimer:
         if D.MATH == "f16x3":
             # fp32-class arithmetic on the f16 matrix cores: every algorithmic MAC executes as three
             # f16 MFMA products (the f16 and bf16 dense peaks are equal), so peak/3 bounds it.
-            out.update(kernel="conv3x3_f16x3_frag_kernel",
+            out.update(kernel="conv3x3_f16x3_frag_kernel<0>",
                        kernel_family="conv3x3_f16x3_frag_kernel (11 of 15 launches) + conv2d_f16x3_dma2_kernel "
                                      "(stride-2, 1x1, deconv, fused head)",
                        peak=round(MFMA_BF16_PEAK_TFLOPS / 3, 1),
