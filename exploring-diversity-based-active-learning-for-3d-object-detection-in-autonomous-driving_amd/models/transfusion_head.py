@@ -102,26 +102,25 @@ class _ConvModule2d(nn.Module):
 
 
 def circle_nms(dets, thresh, post_max_size=83):
-    """box3d_nms.py:181-222 (host loop, as in the reference): keep a centre unless a higher-scored kept one lies
-    within sqrt(thresh)."""
-    x1, y1, scores = dets[:, 0], dets[:, 1], dets[:, 2]
-    order = scores.argsort()[::-1].astype(np.int32)
-    ndets = dets.shape[0]
-    suppressed = np.zeros((ndets), dtype=np.int32)
-    keep = []
-    for _i in range(ndets):
-        i = order[_i]
-        if suppressed[i] == 1:
+    """Greedy centre-distance suppression (the rule of box3d_nms.py:181-222): visit detections [x, y, score] by
+    descending score; a visited, unsuppressed one is kept and suppresses every later one whose squared BEV distance to
+    it is <= thresh.  Returns the kept indices in visiting order (at most post_max_size)."""
+    dets = np.asarray(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return []
+    rank = dets[:, 2].argsort()[::-1]                     # ties resolve as in the reference's reversed ascending sort
+    xy = dets[rank, :2]
+    alive = np.ones(n, dtype=bool)
+    kept = []
+    for pos in range(n):
+        if not alive[pos]:
             continue
-        keep.append(i)
-        for _j in range(_i + 1, ndets):
-            j = order[_j]
-            if suppressed[j] == 1:
-                continue
-            dist = (x1[i] - x1[j]) ** 2 + (y1[i] - y1[j]) ** 2
-            if dist <= thresh:
-                suppressed[j] = 1
-    return keep[:post_max_size]
+        kept.append(int(rank[pos]))
+        if pos + 1 < n:
+            d2 = (xy[pos + 1:, 0] - xy[pos, 0]) ** 2 + (xy[pos + 1:, 1] - xy[pos, 1]) ** 2
+            alive[pos + 1:] &= ~(d2 <= thresh)
+    return kept[:post_max_size]
 
 
 @HEADS.register_module
@@ -181,25 +180,7 @@ class TransFusionHead(nn.Module):
         lidar_feat_flatten = lidar_nhwc.reshape(B, H * W, -1).permute(0, 2, 1)   # [B,C,H*W] (a view: h-major like .view)
         dense_heatmap = dense_nhwc.permute(0, 3, 1, 2)                        # [B,num_classes,H,W]
         bev_pos = self.bev_pos.repeat(B, 1, 1).to(x.device)
-        heatmap = dense_heatmap.detach().sigmoid()
-        padding = self.nms_kernel_size // 2
-        local_max = torch.zeros_like(heatmap)
-        inner = F.max_pool2d(heatmap, kernel_size=self.nms_kernel_size, stride=1, padding=0)
-        if padding > 0:
-            local_max[:, :, padding:(-padding), padding:(-padding)] = inner
-        else:
-            local_max = inner
-        if self.test_cfg.get("dataset") == "nuScenes":                        # pedestrian / traffic cone: no suppression
-            local_max[:, 8] = heatmap[:, 8]
-            local_max[:, 9] = heatmap[:, 9]
-        elif self.test_cfg.get("dataset") == "Waymo":
-            local_max[:, 1] = heatmap[:, 1]
-            local_max[:, 2] = heatmap[:, 2]
-        heatmap = heatmap * (heatmap == local_max)
-        heatmap = heatmap.reshape(B, heatmap.shape[1], -1)
-        top = heatmap.reshape(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]
-        top_class = top // heatmap.shape[-1]
-        top_index = top % heatmap.shape[-1]
+        top_class, top_index, heatmap = self._proposals(dense_heatmap)
         query_feat = lidar_feat_flatten.gather(index=top_index[:, None, :].expand(-1, lidar_feat_flatten.shape[1], -1), dim=-1)
         self.query_labels = top_class
         one_hot = F.one_hot(top_class, num_classes=self.num_classes).permute(0, 2, 1)
@@ -224,6 +205,29 @@ class TransFusionHead(nn.Module):
             else:
                 new_res[key] = ret_dicts[0][key]
         return [new_res]
+
+    def _proposals(self, dense_heatmap):
+        """Query initialisation (transfusion.py:236-275): a cell proposes class c when its sigmoid score is the maximum
+        of its k x k neighbourhood -- evaluated on the interior only: the k//2-wide frame never proposes -- except for
+        the small-object classes (nuScenes pedestrian / traffic cone, Waymo pedestrian / cyclist), where every cell may;
+        the num_proposals best (class, cell) pairs over all classes win.  -> (class [B,P], cell [B,P], masked scores
+        [B,C,H*W])."""
+        score = dense_heatmap.detach().sigmoid()
+        B, C, H, W = score.shape
+        k = self.nms_kernel_size
+        r = k // 2
+        peak = torch.zeros_like(score, dtype=torch.bool)
+        if r > 0:
+            inner = score[:, :, r:H - r, r:W - r]
+            peak[:, :, r:H - r, r:W - r] = inner == F.max_pool2d(score, kernel_size=k, stride=1, padding=0)
+        else:
+            peak[:] = True
+        free = {"nuScenes": (8, 9), "Waymo": (1, 2)}.get(self.test_cfg.get("dataset"), ())
+        for c in free:
+            peak[:, c] = True
+        masked = (score * peak).reshape(B, C, H * W)
+        order = masked.reshape(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]
+        return order // (H * W), order % (H * W), masked
 
     # ---------------------------------------------------------------- decode
     def _decode(self, heatmap, rot, dim, center, height, vel):
