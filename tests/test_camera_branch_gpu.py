@@ -65,28 +65,29 @@ def test_generalized_lss_fpn_matches_torch_restatement():
 
 
 def _depth_image_reference(points, lidar2image, img_aug_matrix, lidar_aug_matrix, image_size):
-    """base.py:225-262, restated (CPU torch)."""
+    """What BaseDepthTransform.forward (base.py:225-262) rasterises, evaluated independently in float64 numpy: undo the
+    lidar augmentation, project with lidar2image, apply the image augmentation, keep points inside the image, and let
+    the LAST point (in point order) that lands on a pixel set its depth."""
+    iH, iW = image_size
     B, N = lidar2image.shape[:2]
-    depth = torch.zeros(B, N, 1, *image_size)
+    out = np.zeros((B, N, iH, iW), np.float32)
     for b in range(B):
-        cur = points[b][:, :3].clone()
-        cur -= lidar_aug_matrix[b][:3, 3]
-        cur = torch.inverse(lidar_aug_matrix[b][:3, :3]).matmul(cur.transpose(1, 0))
-        cur = lidar2image[b][:, :3, :3].matmul(cur)
-        cur += lidar2image[b][:, :3, 3].reshape(-1, 3, 1)
-        dist = cur[:, 2, :]
-        cur[:, 2, :] = torch.clamp(cur[:, 2, :], 1e-5, 1e5)
-        cur[:, :2, :] /= cur[:, 2:3, :]
-        cur = img_aug_matrix[b][:, :3, :3].matmul(cur)
-        cur += img_aug_matrix[b][:, :3, 3].reshape(-1, 3, 1)
-        cur = cur[:, :2, :].transpose(1, 2)[..., [1, 0]]
-        on = (cur[..., 0] < image_size[0]) & (cur[..., 0] >= 0) & (cur[..., 1] < image_size[1]) & (cur[..., 1] >= 0)
+        A = lidar_aug_matrix[b].double().numpy()
+        xyz = points[b][:, :3].double().numpy()
+        raw = (np.linalg.inv(A[:3, :3]) @ (xyz - A[:3, 3]).T)                 # [3, P] points before the lidar augmentation
         for c in range(N):
-            mc = cur[c, on[c]].long()
-            md = dist[c, on[c]]
-            for j in range(mc.shape[0]):                     # explicit loop: the LAST point on a pixel stays
-                depth[b, c, 0, mc[j, 0], mc[j, 1]] = md[j]
-    return depth[:, :, 0]
+            M = lidar2image[b, c].double().numpy()
+            G = img_aug_matrix[b, c].double().numpy()
+            cam = M[:3, :3] @ raw + M[:3, 3:4]
+            depth = cam[2].copy()
+            cam[2] = np.clip(cam[2], 1e-5, 1e5)
+            cam[:2] /= cam[2:3]
+            pix = G[:3, :3] @ cam + G[:3, 3:4]
+            col, row = pix[0], pix[1]
+            inside = (row >= 0) & (row < iH) & (col >= 0) & (col < iW)
+            for j in np.nonzero(inside)[0]:                                  # ascending point order: later points overwrite
+                out[b, c, int(row[j]), int(col[j])] = depth[j]
+    return torch.from_numpy(out)
 
 
 def _camera_setup(B, N, seed, image_size):
