@@ -332,8 +332,8 @@ __global__ void lss_depth_scatter_kernel(const float* __restrict__ pts, int64_t 
     float qx = ((m[0] * ux + m[1] * uy) + m[2] * uz) + m[9];
     float qy = ((m[3] * ux + m[4] * uy) + m[5] * uz) + m[10];
     float qz = ((m[6] * ux + m[7] * uy) + m[8] * uz) + m[11];
-    const float dist = qz;
     qz = fminf(fmaxf(qz, 1e-5f), 1e5f);
+    const float dist = qz;     // base.py:236-237: `dist` is a VIEW of the row the clamp then writes in place -> the clamped depth
     qx = qx / qz; qy = qy / qz;
     const float* a = m + 12;
     const float vx = ((a[0] * qx + a[1] * qy) + a[2] * qz) + a[9];

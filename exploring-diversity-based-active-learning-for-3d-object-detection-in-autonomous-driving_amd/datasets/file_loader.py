@@ -213,11 +213,21 @@ class FileSweepLoader:
     def __iter__(self):
         nb = len(self)
         staged = {}
-        for b in range(min(self.depth, nb)):
-            staged[b] = self._start(b)
-        for b in range(nb):
-            st = staged.pop(b)
-            ex = self._finish(st)
-            if b + self.depth < nb:
-                staged[b + self.depth] = self._start(b + self.depth)   # read ahead while batch b runs downstream
-            yield ex
+        try:
+            for b in range(min(self.depth, nb)):
+                staged[b] = self._start(b)
+            for b in range(nb):
+                st = staged.pop(b)
+                ex = self._finish(st)
+                if b + self.depth < nb:
+                    staged[b + self.depth] = self._start(b + self.depth)   # read ahead while batch b runs downstream
+                yield ex
+        finally:
+            # abandoned midway (exception downstream, break, a second iter()): the reads already submitted still
+            # write into pinned slots the next iteration will reuse -- wait them out before anyone can
+            for st in staged.values():
+                try:
+                    self.reader.wait(st.job)
+                except Exception:
+                    pass
+            staged.clear()

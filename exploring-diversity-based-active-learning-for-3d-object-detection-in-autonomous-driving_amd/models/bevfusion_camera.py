@@ -57,6 +57,18 @@ def bev_pool(x, geom, B, dx, bx, nx, depth=None, ctx_shape=None):
     return out
 
 
+def _versions(*mods):
+    """Version counters of every parameter / buffer of ``mods``: ``load_state_dict`` and in-place edits bump them, so a
+    packed-weight cache keyed on this is rebuilt after weights change."""
+    out = []
+    for m in mods:
+        if m is None:
+            continue
+        for t in list(m.parameters(recurse=False)) + list(m.buffers(recurse=False)):
+            out.append((t.data_ptr(), t._version))
+    return tuple(out)
+
+
 class _ConvBNReLU(nn.Module):
     """Conv2d(bias=False) + BatchNorm2d + ReLU on channels-last maps through the f16x3 / bf16x6 / f32 conv kernels."""
 
@@ -66,7 +78,7 @@ class _ConvBNReLU(nn.Module):
         self._packed = None
 
     def forward(self, x):
-        key = (x.device, D.MATH, D.DENSE)
+        key = (x.device, D.MATH, D.DENSE, _versions(self.conv, self.bn))
         if self._packed is None or self._packed[0] != key:
             scale, shift = D.fold_bn(self.bn)
             w, scale = D.pack_dense(D.pack_conv_weight(self.conv.weight).to(x.device), scale.to(x.device))
@@ -186,7 +198,7 @@ class _ConvAffine(nn.Module):
         self._packed = None
 
     def forward(self, x):
-        key = (x.device, D.MATH, D.DENSE)
+        key = (x.device, D.MATH, D.DENSE, _versions(self.conv, self.bn))
         conv = self.conv
         cin = conv.in_channels
         cpad = (cin + 15) // 16 * 16

@@ -269,8 +269,14 @@ class TransFusionHead(nn.Module):
             return temp
         if self.test_cfg["nms_type"] != "circle":
             raise NotImplementedError("only nms_type null / circle are built")
-        tasks = [dict(indices=[0, 1, 2, 3, 4, 5, 6, 7], radius=-1), dict(indices=[8], radius=0.175),
-                 dict(indices=[9], radius=0.175)]
+        dataset = self.test_cfg.get("dataset", "nuScenes")
+        if dataset == "nuScenes":                      # transfusion.py:751-771
+            tasks = [dict(indices=[0, 1, 2, 3, 4, 5, 6, 7], radius=-1), dict(indices=[8], radius=0.175),
+                     dict(indices=[9], radius=0.175)]
+        elif dataset == "Waymo":                       # transfusion.py:772-779
+            tasks = [dict(indices=[0], radius=0.7), dict(indices=[1], radius=0.7), dict(indices=[2], radius=0.7)]
+        else:
+            raise NotImplementedError(f"circle NMS task table for dataset {dataset!r} (the reference knows nuScenes, Waymo)")
         rets = []
         for t in temp:
             boxes3d, scores, labels = t["bboxes"], t["scores"], t["labels"]

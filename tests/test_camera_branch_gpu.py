@@ -79,8 +79,8 @@ def _depth_image_reference(points, lidar2image, img_aug_matrix, lidar_aug_matrix
             M = lidar2image[b, c].double().numpy()
             G = img_aug_matrix[b, c].double().numpy()
             cam = M[:3, :3] @ raw + M[:3, 3:4]
-            depth = cam[2].copy()
             cam[2] = np.clip(cam[2], 1e-5, 1e5)
+            depth = cam[2]                                                   # base.py:236-237: a view of the clamped row
             cam[:2] /= cam[2:3]
             pix = G[:3, :3] @ cam + G[:3, 3:4]
             col, row = pix[0], pix[1]
@@ -135,6 +135,24 @@ def test_lidar_depth_image_matches_reference_loop():
     agree = both & ((ref - got).abs() <= 1e-3 * ref.abs())
     n_hit = int(((ref > 0) | (got > 0)).sum())
     assert int(agree.sum()) >= 0.998 * n_hit, (int(agree.sum()), n_hit)
+
+
+def test_depth_image_stores_the_clamped_depth_for_points_behind_the_camera():
+    """base.py:236-237: ``dist`` aliases the row that ``torch.clamp`` then overwrites, so a point at or behind the camera
+    plane that still lands on a pixel is rasterised with depth 1e-5.  Identity projection: q = point."""
+    from al3d.models.bevfusion_camera import DepthLSSTransform
+    image_size, feature_size = (64, 176), (8, 22)
+    vt = DepthLSSTransform(32, 16, image_size, feature_size, [-54.0, 54.0, 0.6], [-54.0, 54.0, 0.6], [-10.0, 10.0, 20.0],
+                           [1.0, 60.0, 1.0], downsample=2).to(DEV)
+    eye = torch.eye(4).reshape(1, 1, 4, 4)
+    pts = torch.tensor([[3.05e-4, 2.05e-4, -1.0, 0.0, 0.0],       # behind: z -> 1e-5, pixel (row 20, col 30)
+                        [40.5, 10.5, 1.0, 0.0, 0.0],              # in front: depth 1, pixel (row 10, col 40)
+                        [5.05e-4, 4.05e-4, 0.0, 0.0, 0.0]])       # on the plane: z -> 1e-5, pixel (row 40, col 50)
+    ref = _depth_image_reference([pts], eye, eye, torch.eye(4).reshape(1, 4, 4), image_size)
+    got = vt.depth_image([pts.to(DEV)], eye.to(DEV), eye.to(DEV), torch.eye(4).reshape(1, 4, 4).to(DEV)).cpu()
+    got = got.reshape(ref.shape)
+    assert ref[0, 0, 20, 30] == np.float32(1e-5) and ref[0, 0, 40, 50] == np.float32(1e-5) and ref[0, 0, 10, 40] == 1.0
+    assert torch.equal(got, ref)
 
 
 def test_depth_lss_transform_matches_torch_restatement():
