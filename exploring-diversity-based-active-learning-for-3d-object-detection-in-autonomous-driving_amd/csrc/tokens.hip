@@ -1,0 +1,637 @@
+// Token-matrix kernels of the Swin-T image backbone (BASELINE configs[4]: BEVFusion camera+lidar,
+// bevfusion/configs/nuscenes/det/transfusion/secfpn/camera+lidar/swint_v0p075/default.yaml -- embed 96,
+// depths [2,2,6,2], heads [3,6,12,24], window 7; the module it configures is mmdet 2.20.0's SwinTransformer,
+// absent from the reference tree: the published algorithm is restated, parity unpinned).
+//
+// A Swin block is  x += proj(window_attention(LN1(x)));  x += fc2(gelu(fc1(LN2(x)))).  On the matrix cores that is
+// four skinny GEMMs over [tokens, C] matrices (K = 96 .. 3072) plus 49 x 49 attention per (window, head) -- here:
+//
+//   tok_layernorm_kernel         LayerNorm of token rows, optionally GATHERED through a row map (cyclic shift +
+//                                window partition + padding for LN1; the 2x2 neighbourhood for patch merging) and
+//                                written as "pair rows" (sp_rows.h): the f16 split (xh, xl') the f16x3 products
+//                                multiply with, done once per activation instead of once per consuming tile
+//   tok_linear_f16x3_kernel      [M, K] x [N, K]^T in fp32-class f16x3 arithmetic (conv2d_f16x3.hip: three f16
+//                                products per MAC into one fp32 accumulator), both operands by LDS-DMA through a
+//                                3-stage ring exactly as conv2d_f16x3_dma2_kernel, rows addressed directly;
+//                                epilogue: bias, exact (erf) GELU, residual, row SCATTER (window order -> token
+//                                order, padding rows dropped), f32 or pair rows out
+//   tok_window_attention_kernel  one wave per (window, head): S^T = K (Q scale)^T on the matrix cores with both
+//                                operands split (main + 2^-11 correction accumulators), + relative position bias
+//                                + shifted-window region mask computed from the window's position (no mask tensor),
+//                                softmax down the accumulator registers, O^T = V^T P^T with P taken straight from
+//                                the accumulators as the B operand (no LDS round trip), pair rows out
+//
+// Nothing here calls a BLAS / MIOpen routine.  gfx950 only.
+#include "al3d_common.h"
+#include "sp_rows.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float tk_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void tk_lds_void;
+typedef const __attribute__((address_space(1))) void tk_gbl_void;
+
+#define TK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define TK_STAGE 16384      // bytes per ring stage: A 8 KB (128 rows x 16 channels f32 / pair) + B 8 KB
+#define TK_BOFF 8192
+#define TK_NS 3
+
+__device__ __attribute__((aligned(256))) float g_tok_zero[64];     // stays zero: source of rows beyond M
+
+template <int N> __device__ __forceinline__ void tk_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ int tk_swz(int r) { return (r & 1) | (((r >> 3) & 1) << 1); }
+
+__device__ __forceinline__ void tk_split(float x, _Float16& h, _Float16& l)
+{
+    h = (_Float16)x;
+    l = (_Float16)__builtin_fmaf((float)h, -2048.0f, x * 2048.0f);   // (x - h) * 2^11 exactly
+}
+__device__ __forceinline__ void tk_split8(const float (&v)[8], f16x8& ph, f16x8& pl)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { _Float16 a, b; tk_split(v[e], a, b); ph[e] = a; pl[e] = b; }
+}
+__device__ __forceinline__ void tk_split8v(const tk_f32x4& lo, const tk_f32x4& hi, f16x8& ph, f16x8& pl)
+{
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    tk_split8(v, ph, pl);
+}
+__device__ __forceinline__ f16x8 tk_lift_down(const f16x8& wh) { return wh * (_Float16)0.00048828125f; }
+
+// ------------------------------------------------------------------ LayerNorm over gathered rows
+struct TokLnParams {
+    const float* x;         // [rows_in][C]
+    const int* rowmap;      // [rows_out * G] source row of each piece, -1 = absent; null = identity (row * G + piece)
+    const float* gamma;     // [G * C]
+    const float* beta;      // [G * C]
+    float* out;             // [rows_out][G * C] f32 or pair rows
+    int64_t rows_out;
+    int C, G, zero_out, pair;
+    float eps;
+};
+
+// LPR lanes per output row; a lane holds up to 3 groups of 8 consecutive channels in registers (G * C <= 24 * LPR).
+// Two-pass statistics in fp32 (mean, then the centred second moment), biased variance, as torch.nn.LayerNorm.
+// Absent pieces are zeros BEFORE the normalisation (patch merging pads the map, then normalises); with zero_out
+// (G == 1) an absent row is a zero OUTPUT row instead (the window padding is applied to the normalised map).
+template <int LPR>
+__global__ __launch_bounds__(256) void tok_layernorm_kernel(TokLnParams p)
+{
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < p.rows_out;
+    const int Wd = p.G * p.C, ng = Wd >> 3;
+    float v[3][8];
+    bool absent_row = false;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int g = sub + t * LPR;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
+        if (!live || g >= ng) continue;
+        const int ch = g << 3, piece = ch / p.C;
+        const int64_t src = p.rowmap ? (int64_t)p.rowmap[row * p.G + piece] : row * p.G + piece;
+        if (src < 0) { absent_row = true; continue; }
+        const float* s = p.x + src * p.C + (ch - piece * p.C);
+        const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+        v[t][0] = a.x; v[t][1] = a.y; v[t][2] = a.z; v[t][3] = a.w;
+        v[t][4] = b.x; v[t][5] = b.y; v[t][6] = b.z; v[t][7] = b.w;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[t][e];
+#pragma unroll
+    for (int o = LPR >> 1; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)Wd;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (sub + t * LPR >= ng) continue;                 // registers of groups beyond the row are not part of it
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[t][e] - mean; sq += d * d; }
+    }
+#pragma unroll
+    for (int o = LPR >> 1; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)Wd + p.eps);
+    if (!live) return;
+    const bool zero = p.zero_out && absent_row;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int g = sub + t * LPR;
+        if (g >= ng) continue;
+        const int ch = g << 3;
+        float y[8];
+        const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + ch), g1 = *reinterpret_cast<const float4*>(p.gamma + ch + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.beta + ch), b1 = *reinterpret_cast<const float4*>(p.beta + ch + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = zero ? 0.f : ((v[t][e] - mean) * rstd) * ga[e] + be[e];
+        float* o = p.out + row * Wd + ch;
+        if (p.pair) {
+            uint4 hi, lo;
+            sp_split8(y, hi, lo);
+            *reinterpret_cast<uint4*>(o) = hi;
+            *reinterpret_cast<uint4*>(o + 4) = lo;
+        } else {
+            *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+    }
+}
+
+extern "C" int al3d_tok_layernorm_f32(const float* x, const int* rowmap, int64_t rows_out, int C, int G, int zero_out,
+                                      const float* gamma, const float* beta, float eps, int out_pair, float* out,
+                                      void* stream)
+{
+    AL3D_REQUIRE(x && gamma && beta && out && rows_out >= 0, "al3d_tok_layernorm_f32: null pointer / negative rows");
+    AL3D_REQUIRE(C >= 8 && C % 8 == 0 && (G == 1 || G == 4) && G * C <= 1536,
+                 "al3d_tok_layernorm_f32: C=%d (multiple of 8), G=%d (1 or 4), G*C <= 1536", C, G);
+    AL3D_REQUIRE(!zero_out || G == 1, "al3d_tok_layernorm_f32: zero_out needs G == 1");
+    AL3D_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+                 "al3d_tok_layernorm_f32: pointers must be 16-byte aligned");
+    if (rows_out == 0) return AL3D_OK;
+    TokLnParams p{x, rowmap, gamma, beta, out, rows_out, C, G, zero_out, out_pair, eps};
+    if (G * C <= 384)
+        hipLaunchKernelGGL(tok_layernorm_kernel<16>, dim3((unsigned)al3d_cdiv(rows_out, 16)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(tok_layernorm_kernel<64>, dim3((unsigned)al3d_cdiv(rows_out, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("tok_layernorm_kernel");
+    return AL3D_OK;
+}
+
+// ------------------------------------------------------------------ token GEMM, f16x3, both operands by LDS-DMA
+struct TokGemmParams {
+    const float* a;         // [M][K] f32 rows or pair rows
+    const _Float16* wgt;    // al3d_pack_f16x3_dma image (taps = 1): [ceil(N/128)][K/16][2 planes][128][16]
+    const float* scale;     // [N]: 2^-s of the weight split (required)
+    const float* bias;      // [N] or null
+    const float* residual;  // [*][ldr] f32, indexed by OUTPUT row, or null
+    const int* rowmap;      // [M] output row of GEMM row m (-1: dropped) or null
+    float* out;             // [*][ldc]
+    int M, K, N, ldc, ldr, act;
+    int ntiles, nblocks;
+};
+
+// same XCD-aware (row tile, column block) order as conv2d_f16x3.hip's f3_tile_of_block
+__device__ __forceinline__ bool tk_tile_of_block(const TokGemmParams& p, int& tile, int& nblk)
+{
+    const int id = blockIdx.x, span = 8 * p.nblocks;
+    const int grp = id / span, rem = id - grp * span;
+    nblk = rem >> 3;
+    tile = grp * 8 + (rem & 7);
+    return tile < p.ntiles;
+}
+
+__device__ __forceinline__ float tk_gelu(float v)
+{
+    return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+struct TkOps {
+    f16x8 ah[2], al[2], wh[2], wl[2], wd[2];
+};
+
+// IO bit 0: A rows are pair rows; bit 1: write pair rows.  Tile 128 rows x 128 columns x 16 channels per step,
+// four waves of 64 x 64; ring, fragment offsets, asm block and product order of conv2d_f16x3_dma2_kernel.
+template <int IO>
+__global__ __launch_bounds__(256, 2) void tok_linear_f16x3_kernel(TokGemmParams p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[TK_NS * TK_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    int tile, nblk;
+    if (!tk_tile_of_block(p, tile, nblk)) return;      // padding block of the last group (uniform)
+    const int m0 = tile * 128, n0 = nblk * 128;
+    const int total = p.K >> 4;
+    const unsigned smem_base = (unsigned)(size_t)(tk_lds_void*)smem;
+
+    // DMA side: wave w fetches rows 32 w .. 32 w + 31 and quarter w of the weight tile; lane (jg, sg) of piece i
+    // fetches 16-byte chunk sg ^ f(r) of row r = 2 jg + i (source-side swizzle: the LDS side of a DMA is lane-linear)
+    const int jg = lane >> 2, sg = lane & 3;
+    const char* abase[2];
+    unsigned ainc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 2 * jg + i, m = m0 + 32 * wave + r;
+        const int cg = (sg ^ tk_swz(r)) * 4;
+        const bool ok = m < p.M;
+        abase[i] = reinterpret_cast<const char*>(ok ? p.a + (int64_t)m * p.K + cg : g_tok_zero + cg);
+        ainc[i] = ok ? 64u : 0u;
+    }
+    const char* wsrc = reinterpret_cast<const char*>(p.wgt) + (int64_t)nblk * total * 8192 + wave * 2048 + lane * 16;
+    int lchunk = 0;
+    auto issue = [&](int stage) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + stage * TK_STAGE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((tk_gbl_void*)(abase[i] + (size_t)lchunk * ainc[i]),
+                                             (tk_lds_void*)(size_t)(dst + i * 1024), 16, 0, 0);
+        const char* ws = wsrc + (int64_t)lchunk * 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((tk_gbl_void*)(ws + i * 1024), (tk_lds_void*)(size_t)(dst + TK_BOFF + i * 1024),
+                                             16, 0, 0);
+        if (lchunk + 1 < total) ++lchunk;              // steps past the end re-fetch the last one: 4 DMAs per step, always
+    };
+
+    f32x16 c00, c01, c10, c11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned offA0 = (unsigned)(wm * 4096 + (fr & 1) * 1024 + (fr >> 1) * 64 + (((2 * fh) ^ tk_swz(fr)) * 16));
+    const unsigned offA1 = (unsigned)(wm * 4096 + (fr & 1) * 1024 + (fr >> 1) * 64 + (((2 * fh + 1) ^ tk_swz(fr)) * 16));
+    const unsigned offB = (unsigned)(TK_BOFF + (wn * 64 + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) * 16));
+
+    TkOps A, B;
+    constexpr bool in_pair = (IO & 1) != 0;
+    auto finish = [&](TkOps& o, const tk_f32x4& r0l, const tk_f32x4& r0h, const tk_f32x4& r1l, const tk_f32x4& r1h) {
+        if constexpr (in_pair) {                         // the 32 bytes of a fragment ARE (xh[8], xl'[8])
+            o.ah[0] = __builtin_bit_cast(f16x8, r0l); o.al[0] = __builtin_bit_cast(f16x8, r0h);
+            o.ah[1] = __builtin_bit_cast(f16x8, r1l); o.al[1] = __builtin_bit_cast(f16x8, r1h);
+        } else {
+            tk_split8v(r0l, r0h, o.ah[0], o.al[0]);
+            tk_split8v(r1l, r1h, o.ah[1], o.al[1]);
+        }
+        o.wd[0] = tk_lift_down(o.wh[0]);
+        o.wd[1] = tk_lift_down(o.wh[1]);
+    };
+
+#pragma unroll
+    for (int s = 0; s < TK_NS; ++s) issue(s);
+    {
+        tk_wait_vm<4 * (TK_NS - 1)>();                 // stage 0
+        __builtin_amdgcn_s_barrier();
+        tk_f32x4 r0l, r0h, r1l, r1h;
+        asm volatile("ds_read_b128 %0, %8\n\t"
+                     "ds_read_b128 %1, %9\n\t"
+                     "ds_read_b128 %2, %8 offset:2048\n\t"
+                     "ds_read_b128 %3, %9 offset:2048\n\t"
+                     "ds_read_b128 %4, %10\n\t"
+                     "ds_read_b128 %5, %10 offset:4096\n\t"
+                     "ds_read_b128 %6, %10 offset:1024\n\t"
+                     "ds_read_b128 %7, %10 offset:5120\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0l), "=&v"(r0h), "=&v"(r1l), "=&v"(r1h), "=&v"(A.wh[0]), "=&v"(A.wl[0]), "=&v"(A.wh[1]),
+                       "=&v"(A.wl[1])
+                     : "v"(smem_base + offA0), "v"(smem_base + offA1), "v"(smem_base + offB) : "memory");
+        finish(A, r0l, r0h, r1l, r1h);
+    }
+    int nstage = 1 % TK_NS, fill = 0;
+    auto step = [&](TkOps& cur, TkOps& nxt) {
+        tk_wait_vm<4 * (TK_NS - 2)>();                 // this wave's share of the next stage has landed ...
+        __builtin_amdgcn_s_barrier();                  // ... everyone's has; every wave holds the current stage in registers
+        issue(fill);                                   // -> the current stage's buffer
+        const unsigned sb = smem_base + nstage * TK_STAGE;
+        tk_f32x4 r0l, r0h, r1l, r1h;
+        asm volatile("s_nop 1\n\t"
+                     "ds_read_b128 %0, %22\n\t"
+                     "ds_read_b128 %1, %23\n\t"
+                     "v_mfma_f32_32x32x16_f16 %8, %12, %16, %8\n\t"
+                     "v_mfma_f32_32x32x16_f16 %9, %12, %19, %9\n\t"
+                     "ds_read_b128 %2, %22 offset:2048\n\t"
+                     "ds_read_b128 %3, %23 offset:2048\n\t"
+                     "v_mfma_f32_32x32x16_f16 %10, %14, %16, %10\n\t"
+                     "v_mfma_f32_32x32x16_f16 %11, %14, %19, %11\n\t"
+                     "ds_read_b128 %4, %24\n\t"
+                     "ds_read_b128 %5, %24 offset:4096\n\t"
+                     "v_mfma_f32_32x32x16_f16 %8, %13, %17, %8\n\t"
+                     "v_mfma_f32_32x32x16_f16 %9, %13, %20, %9\n\t"
+                     "ds_read_b128 %6, %24 offset:1024\n\t"
+                     "ds_read_b128 %7, %24 offset:5120\n\t"
+                     "v_mfma_f32_32x32x16_f16 %10, %15, %17, %10\n\t"
+                     "v_mfma_f32_32x32x16_f16 %11, %15, %20, %11\n\t"
+                     "v_mfma_f32_32x32x16_f16 %8, %13, %18, %8\n\t"
+                     "v_mfma_f32_32x32x16_f16 %9, %13, %21, %9\n\t"
+                     "v_mfma_f32_32x32x16_f16 %10, %15, %18, %10\n\t"
+                     "v_mfma_f32_32x32x16_f16 %11, %15, %21, %11\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0l), "=&v"(r0h), "=&v"(r1l), "=&v"(r1h), "=&v"(nxt.wh[0]), "=&v"(nxt.wl[0]), "=&v"(nxt.wh[1]),
+                       "=&v"(nxt.wl[1]), "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
+                     : "v"(cur.al[0]), "v"(cur.ah[0]), "v"(cur.al[1]), "v"(cur.ah[1]),                    // 12..15
+                       "v"(cur.wd[0]), "v"(cur.wl[0]), "v"(cur.wh[0]), "v"(cur.wd[1]), "v"(cur.wl[1]), "v"(cur.wh[1]),   // 16..21
+                       "v"(sb + offA0), "v"(sb + offA1), "v"(sb + offB)                                   // 22..24
+                     : "memory");
+        finish(nxt, r0l, r0h, r1l, r1h);
+        nstage = nstage + 1 == TK_NS ? 0 : nstage + 1;
+        fill = fill + 1 == TK_NS ? 0 : fill + 1;
+    };
+    for (int s = 0; s < total; s += 2) {
+        step(A, B);
+        if (s + 1 < total) step(B, A);
+    }
+    tk_wait_vm<0>();                                   // the tail's dummy requests must not outlive the workgroup's LDS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the VALU reads them
+
+    // epilogue: scale / bias / GELU in the C layout, then each 32-row x 64-column half of the wave's tile goes
+    // through a wave-private LDS scratch (the ring, free after the barrier) so that a lane holds consecutive channels
+    // of a row: residual loads and stores are 16-byte pieces
+    const f32x16* accp[2][2] = {{&c00, &c01}, {&c10, &c11}};
+    __syncthreads();
+    constexpr int SP = 68;
+    float* scr = reinterpret_cast<float*>(smem) + wave * (32 * SP);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fr;
+            const bool nok = n < p.N;
+            const float sc = nok ? p.scale[n] : 0.f;
+            const float sh = (nok && p.bias) ? p.bias[n] : 0.0f;
+            const f32x16& acc = *accp[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float v = acc[r] * sc + sh;
+                if (p.act) v = tk_gelu(v);
+                scr[ml * SP + j * 32 + fr] = v;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if constexpr ((IO & 2) != 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = lane + 64 * q, pl = t >> 3, g = t & 7;
+                const int m = m0 + wm * 64 + i * 32 + pl;
+                const int n = n0 + wn * 64 + g * 8;
+                if (m >= p.M || n >= p.N) continue;
+                const int orow = p.rowmap ? p.rowmap[m] : m;
+                if (orow < 0) continue;
+                const float4 a = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8);
+                const float4 b4 = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8 + 4);
+                float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+                if (p.residual) {
+                    const float* rs = p.residual + (int64_t)orow * p.ldr + n;
+                    const float4 ra = *reinterpret_cast<const float4*>(rs), rb = *reinterpret_cast<const float4*>(rs + 4);
+                    v[0] += ra.x; v[1] += ra.y; v[2] += ra.z; v[3] += ra.w; v[4] += rb.x; v[5] += rb.y; v[6] += rb.z; v[7] += rb.w;
+                }
+                uint4 hi, lo;
+                sp_split8(v, hi, lo);
+                float* o = p.out + (int64_t)orow * p.ldc + n;
+                *reinterpret_cast<uint4*>(o) = hi;
+                *reinterpret_cast<uint4*>(o + 4) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int t = lane + 64 * q, pl = t >> 4, g = t & 15;
+                const int m = m0 + wm * 64 + i * 32 + pl;
+                const int n = n0 + wn * 64 + g * 4;
+                if (m >= p.M || n >= p.N) continue;
+                const int orow = p.rowmap ? p.rowmap[m] : m;
+                if (orow < 0) continue;
+                float4 v = *reinterpret_cast<const float4*>(scr + pl * SP + g * 4);
+                if (p.residual) {
+                    const float4 rs = *reinterpret_cast<const float4*>(p.residual + (int64_t)orow * p.ldr + n);
+                    v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                }
+                *reinterpret_cast<float4*>(p.out + (int64_t)orow * p.ldc + n) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt_image, const float* scale,
+                                     const float* bias, int64_t M, int K, int N, int act, const float* residual,
+                                     int ldr, const int* rowmap, float* out, int ldc, int out_pair, void* stream)
+{
+    AL3D_REQUIRE(a && wgt_image && scale && out, "al3d_tok_linear_f16x3: null pointer (scale carries the weight exponent and is required)");
+    AL3D_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) - 128 && K >= 16 && K % 16 == 0 && N >= 1, "al3d_tok_linear_f16x3: bad shape M=%lld K=%d N=%d",
+                 (long long)M, K, N);
+    const int q = out_pair ? 8 : 4;
+    AL3D_REQUIRE(N % q == 0 && ldc % q == 0 && ldc >= N, "al3d_tok_linear_f16x3: N=%d, ldc=%d must be multiples of %d, ldc >= N", N, ldc, q);
+    AL3D_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= N), "al3d_tok_linear_f16x3: ldr=%d must be a multiple of 4 and >= N", ldr);
+    AL3D_REQUIRE(act == 0 || act == 1, "al3d_tok_linear_f16x3: act = 0 (none) or 1 (GELU)");
+    AL3D_REQUIRE((((uintptr_t)a | (uintptr_t)wgt_image | (uintptr_t)out | (uintptr_t)residual) & 15) == 0,
+                 "al3d_tok_linear_f16x3: a / wgt / out / residual must be 16-byte aligned");
+    if (M == 0) return AL3D_OK;
+    TokGemmParams p;
+    p.a = a; p.wgt = (const _Float16*)wgt_image; p.scale = scale; p.bias = bias; p.residual = residual; p.rowmap = rowmap;
+    p.out = out; p.M = (int)M; p.K = K; p.N = N; p.ldc = ldc; p.ldr = ldr; p.act = act;
+    p.ntiles = (int)al3d_cdiv(M, 128); p.nblocks = (int)al3d_cdiv(N, 128);
+    const dim3 grid((unsigned)(al3d_cdiv(p.ntiles, 8) * 8 * p.nblocks));
+    hipStream_t s = (hipStream_t)stream;
+    switch ((a_pair ? 1 : 0) | (out_pair ? 2 : 0)) {
+    case 0: hipLaunchKernelGGL(tok_linear_f16x3_kernel<0>, grid, dim3(256), 0, s, p); break;
+    case 1: hipLaunchKernelGGL(tok_linear_f16x3_kernel<1>, grid, dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL(tok_linear_f16x3_kernel<2>, grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(tok_linear_f16x3_kernel<3>, grid, dim3(256), 0, s, p); break;
+    }
+    AL3D_CHECK_LAUNCH("tok_linear_f16x3_kernel");
+    return AL3D_OK;
+}
+
+// ------------------------------------------------------------------ 7 x 7 window attention, head dim 32
+struct TokAttnParams {
+    const float* qkv;       // [nwin * 49][3 C]: q | k | v, each [heads][32]
+    const float* table;     // [169][heads] relative position bias table
+    float* out;             // [nwin * 49][C] f32 or pair rows
+    int nwin, C, heads;
+    int nwy, nwx;           // windows per image (rows, columns)
+    int shift;              // cyclic shift of the block (0: no mask)
+    float scale;
+    int pair;
+};
+
+#define TK_WS 7
+#define TK_NT 49
+
+__device__ __forceinline__ int tk_region1(int v, int n, int shift)
+{
+    return (v >= n - TK_WS ? 1 : 0) + (v >= n - shift ? 1 : 0);
+}
+
+// One wave per (window, head).  C-layout of v_mfma_f32_32x32x16: column = lane & 31, rows in the 16 registers
+// (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); S^T puts the KEYS on the rows, so a query's softmax runs down a
+// lane's registers (+ one exchange with lane ^ 32), and P^T is already the B operand of O^T = V^T P^T: registers
+// 8 s .. 8 s + 7 of a tile are k-step s, in the order key = 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the V^T fragment
+// is loaded in that same order.  Both operands of both products are activations: each is split (xh, xl' = residual
+// x 2^11) and the product is  xh yh  +  2^-11 (xh yl' + xl' yh)  with the two brackets in separate accumulators.
+__global__ __launch_bounds__(256) void tok_window_attention_kernel(TokAttnParams p)
+{
+    __shared__ float tbl[4][176];
+    __shared__ int treg[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= p.nwin * p.heads) return;              // wave-uniform; the kernel has no workgroup barrier
+    const int win = item / p.heads, head = item - win * p.heads;
+    const int c = lane & 31, h = lane >> 5;
+    for (int t = lane; t < 169; t += 64) tbl[wave][t] = p.table[t * p.heads + head];
+    {
+        const int wi = win % (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
+        const int ty = lane / TK_WS, tx = lane - ty * TK_WS;
+        treg[wave][lane] = lane < TK_NT && p.shift > 0
+            ? tk_region1(wy * TK_WS + ty, p.nwy * TK_WS, p.shift) * 3 + tk_region1(wx * TK_WS + tx, p.nwx * TK_WS, p.shift)
+            : 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    const int ld = 3 * p.C;
+    const float* base = p.qkv + (int64_t)win * TK_NT * ld + head * 32;
+    f16x8 kh[2][2], kl[2][2], qh[2][2], ql[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 32 * i + c;
+        const bool ok = row < TK_NT;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float* kp = base + (int64_t)row * ld + p.C + 16 * s + 8 * h;
+            const float* qp = base + (int64_t)row * ld + 16 * s + 8 * h;
+            float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, q0 = k0, q1 = k0;
+            if (ok) {
+                k0 = *reinterpret_cast<const float4*>(kp); k1 = *reinterpret_cast<const float4*>(kp + 4);
+                q0 = *reinterpret_cast<const float4*>(qp); q1 = *reinterpret_cast<const float4*>(qp + 4);
+            }
+            const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+            const float qv[8] = {q0.x * p.scale, q0.y * p.scale, q0.z * p.scale, q0.w * p.scale,
+                                 q1.x * p.scale, q1.y * p.scale, q1.z * p.scale, q1.w * p.scale};
+            tk_split8(kv, kh[i][s], kl[i][s]);
+            tk_split8(qv, qh[i][s], ql[i][s]);
+        }
+    }
+    f32x16 sm[2][2], sc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sm[i][j][r] = 0.f; sc[i][j][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sc[i][j] = TK_MFMA(kl[i][s], qh[j][s], sc[i][j]);
+                sc[i][j] = TK_MFMA(kh[i][s], ql[j][s], sc[i][j]);
+                sm[i][j] = TK_MFMA(kh[i][s], qh[j][s], sm[i][j]);
+            }
+
+    // logits -> probabilities, in place in sm[i][j] (rows = keys, column = this lane's query of tile j)
+    const bool masked = p.shift > 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int query = 32 * j + c, qq = query < TK_NT ? query : TK_NT - 1;
+        const int qcode = qq + 6 * ((qq * 37) >> 8) + 84;           // 13 y + x + 84
+        const int qreg = treg[wave][qq];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = sm[i][j][r] + sc[i][j][r] * 0.00048828125f;
+                if (key < TK_NT) {
+                    v += tbl[wave][qcode - (key + 6 * ((key * 37) >> 8))];
+                    if (masked && treg[wave][key] != qreg) v += -100.0f;
+                } else {
+                    v = -INFINITY;
+                }
+                sm[i][j][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(sm[i][j][r] - mx);
+                sm[i][j][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[i][j][r] *= inv;
+    }
+
+    // O^T[d][query] = sum_key V[key][d] P[query][key]
+    f32x16 om[2], oc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { om[j][r] = 0.f; oc[j][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = 32 * i + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+                vv[e] = key < TK_NT ? base[(int64_t)key * ld + 2 * p.C + c] : 0.f;
+            }
+            f16x8 vh, vl;
+            tk_split8(vv, vh, vl);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = sm[i][j][8 * s + e];
+                f16x8 ph, pl;
+                tk_split8(pv, ph, pl);
+                oc[j] = TK_MFMA(vl, ph, oc[j]);
+                oc[j] = TK_MFMA(vh, pl, oc[j]);
+                om[j] = TK_MFMA(vh, ph, om[j]);
+            }
+        }
+
+    // rows of O^T are d = (r & 3) + 8 (r >> 2) + 4 h: four consecutive channels per register quad
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int query = 32 * j + c;
+        if (query >= TK_NT) continue;
+        float* orow = p.out + ((int64_t)win * TK_NT + query) * p.C + head * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = om[j][4 * g + e] + oc[j][4 * g + e] * 0.00048828125f;
+            if (p.pair) {                                // group g of the head: xh[8] | xl'[8]; this lane owns elements 4 h .. 4 h + 3
+                _Float16 hh[4], ll[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tk_split(y[e], hh[e], ll[e]);
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 vh4 = {hh[0], hh[1], hh[2], hh[3]}, vl4 = {ll[0], ll[1], ll[2], ll[3]};
+                char* o = reinterpret_cast<char*>(orow + 8 * g);
+                *reinterpret_cast<uint2*>(o + 8 * h) = __builtin_bit_cast(uint2, vh4);
+                *reinterpret_cast<uint2*>(o + 16 + 8 * h) = __builtin_bit_cast(uint2, vl4);
+            } else {
+                *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+}
+
+extern "C" int al3d_tok_window_attention_f32(const float* qkv, const float* table, int nwin, int C, int heads,
+                                             int win_rows, int win_cols, int shift, float scale, int out_pair,
+                                             float* out, void* stream)
+{
+    AL3D_REQUIRE(qkv && table && out, "al3d_tok_window_attention_f32: null pointer");
+    AL3D_REQUIRE(nwin >= 0 && heads >= 1 && C == heads * 32, "al3d_tok_window_attention_f32: C=%d must be heads (%d) x 32", C, heads);
+    AL3D_REQUIRE(win_rows >= 1 && win_cols >= 1 && nwin % (win_rows * win_cols) == 0,
+                 "al3d_tok_window_attention_f32: nwin=%d is not a whole number of %d x %d window grids", nwin, win_rows, win_cols);
+    AL3D_REQUIRE(shift >= 0 && shift < TK_WS, "al3d_tok_window_attention_f32: shift=%d outside [0, 7)", shift);
+    AL3D_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "al3d_tok_window_attention_f32: qkv / out must be 16-byte aligned");
+    if (nwin == 0) return AL3D_OK;
+    TokAttnParams p{qkv, table, out, nwin, C, heads, win_rows, win_cols, shift, scale, out_pair};
+    const int64_t items = (int64_t)nwin * heads;
+    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)al3d_cdiv(items, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("tok_window_attention_kernel");
+    return AL3D_OK;
+}

@@ -1,26 +1,48 @@
-"""Swin Transformer image backbone of BEVFusion's camera branch (BASELINE configs[4]).
+"""Swin Transformer image backbone of BEVFusion's camera branch (BASELINE configs[4]) on
+this build's token kernels (``csrc/tokens.hip``).
 
 The reference configures ``type: SwinTransformer`` from **mmdet 2.20.0** (``mmdet/models/backbones/swin.py``;
 bevfusion/configs/nuscenes/det/transfusion/secfpn/camera+lidar/swint_v0p075/default.yaml: embed_dims 96, depths
 [2, 2, 6, 2], num_heads [3, 6, 12, 24], window_size 7, mlp_ratio 4, qkv_bias, patch_norm, out_indices [1, 2, 3]).
-mmdet is not in the reference tree and not installed, so this restates the PUBLISHED algorithm (Liu et al., "Swin
+mmdet is not in the reference tree and not installed, so this implements the PUBLISHED algorithm (Liu et al., "Swin
 Transformer", ICCV 2021) with mmdet's module tree and conventions where they are observable from its checkpoints'
 key names: ``patch_embed.projection`` / ``.norm``; ``stages.<i>.blocks.<j>.{norm1, attn.w_msa.{qkv, proj,
 relative_position_bias_table}, norm2, ffn.layers.0.0, ffn.layers.1}``; ``stages.<i>.downsample.{norm, reduction}``
 with the ``nn.Unfold`` channel order (c * 4 + kh * 2 + kw); ``norm<i>`` on the output levels; the relative position
-index built by mmdet's ``double_step_seq``.  **Parity unpinned** (no source, no checkpoint, no fixture); the tests pin
-what can be pinned: the shifted-window attention against a dense attention with an independently built window mask,
-shapes and strides of the outputs.
+index built by mmdet's ``double_step_seq``.  **Parity unpinned** (no source, no checkpoint, no fixture).
 
-Implementation: token GEMMs, softmax and LayerNorm are torch ops (library GEMMs on 49-token windows); the 4x4/s4
-patch embedding runs on this build's conv kernel.  Eval only (no dropout / drop-path).
+How a block runs (seven launches, no torch op touches an activation):
+  LN1 gathered into (shifted) window order, padding rows zero, pair rows   al3d_tok_layernorm_f32
+  qkv projection                                                           al3d_tok_linear_f16x3
+  49 x 49 attention per (window, head) with bias + region mask, pair rows  al3d_tok_window_attention_f32
+  output projection + residual, scattered back to token order              al3d_tok_linear_f16x3
+  LN2, pair rows                                                           al3d_tok_layernorm_f32
+  fc1 + exact GELU, pair rows                                              al3d_tok_linear_f16x3
+  fc2 + residual                                                           al3d_tok_linear_f16x3
+Patch merging = LN over the gathered 2 x 2 neighbourhood + one GEMM (weights re-ordered once from mmdet's
+channel-major unfold order to piece-major); the patch embedding is a 4 x 4 / stride 4 convolution on the dense conv
+kernel.  The modules only hold parameters (state-dict compatible); ``tests/swin_torch.py`` is the torch restatement the
+kernels are checked against.  Eval only (no dropout / drop-path).
 """
 import torch
-import torch.nn.functional as F
 from torch import nn
 
-from .bevfusion_camera import _ConvAffine
+from .. import token_ops as T
+from .bevfusion_camera import _ConvAffine, _versions
 from .registry import BACKBONES
+
+
+class _Packed:
+    """Per-module cache of kernel-format weights, rebuilt when the device or a parameter changes."""
+
+    def __init__(self):
+        self._key, self._val = None, None
+
+    def get(self, device, mods, build):
+        key = (device, _versions(*mods))
+        if self._key != key:
+            self._val, self._key = build(), key
+        return self._val
 
 
 class WindowMSA(nn.Module):
@@ -30,7 +52,8 @@ class WindowMSA(nn.Module):
         self.scale = qk_scale or (embed_dims // num_heads) ** -0.5
         Wh, Ww = window_size
         self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * Wh - 1) * (2 * Ww - 1), num_heads))
-        # mmdet's construction of the (Wh*Ww, Wh*Ww) index into the table
+        # mmdet's construction of the (Wh*Ww, Wh*Ww) index into the table (kept for state dicts and the tests; the
+        # attention kernel evaluates the same index arithmetically)
         seq1 = torch.arange(0, (2 * Ww - 1) * Wh, 2 * Ww - 1)
         seq2 = torch.arange(0, Ww, 1)
         rel = (seq1[:, None] + seq2[None, :]).reshape(1, -1)
@@ -39,21 +62,12 @@ class WindowMSA(nn.Module):
         self.qkv = nn.Linear(embed_dims, embed_dims * 3, bias=qkv_bias)
         self.proj = nn.Linear(embed_dims, embed_dims)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        object.__setattr__(self, "_pk", _Packed())
 
-    def forward(self, x, mask=None):
-        """x [num_windows * B, N, C]; mask [num_windows, N, N] (0 / -100) or None."""
-        B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv[0], qkv[1], qkv[2]
-        attn = (q * self.scale) @ k.transpose(-2, -1)
-        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, -1)
-        attn = attn + bias.permute(2, 0, 1).contiguous().unsqueeze(0)
-        if mask is not None:
-            nW = mask.shape[0]
-            attn = attn.view(B // nW, nW, self.num_heads, N, N) + mask.unsqueeze(1).unsqueeze(0)
-            attn = attn.view(-1, self.num_heads, N, N)
-        attn = attn.softmax(dim=-1)
-        return self.proj((attn @ v).transpose(1, 2).reshape(B, N, C))
+    def packed(self, device):
+        return self._pk.get(device, (self, self.qkv, self.proj), lambda: (
+            T.PackedLinear(self.qkv.weight, self.qkv.bias), T.PackedLinear(self.proj.weight, self.proj.bias),
+            self.relative_position_bias_table.detach().float().contiguous()))
 
 
 class ShiftWindowMSA(nn.Module):
@@ -61,50 +75,9 @@ class ShiftWindowMSA(nn.Module):
         super().__init__()
         self.window_size, self.shift_size = window_size, shift_size
         assert 0 <= shift_size < window_size
+        if window_size != 7 or embed_dims != 32 * num_heads:
+            raise NotImplementedError("the attention kernel is built for 7 x 7 windows and 32-channel heads (Swin-T/S/B)")
         self.w_msa = WindowMSA(embed_dims, num_heads, (window_size, window_size), qkv_bias, qk_scale)
-
-    def window_partition(self, x):
-        B, H, W, C = x.shape
-        ws = self.window_size
-        x = x.view(B, H // ws, ws, W // ws, ws, C)
-        return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
-
-    def window_reverse(self, windows, H, W):
-        ws = self.window_size
-        B = int(windows.shape[0] / (H * W / ws / ws))
-        x = windows.view(B, H // ws, W // ws, ws, ws, -1)
-        return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
-
-    def forward(self, query, hw_shape):
-        B, L, C = query.shape
-        H, W = hw_shape
-        assert L == H * W
-        ws = self.window_size
-        query = query.view(B, H, W, C)
-        pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
-        query = F.pad(query, (0, 0, 0, pad_r, 0, pad_b))
-        Hp, Wp = query.shape[1], query.shape[2]
-        if self.shift_size > 0:
-            shifted = torch.roll(query, shifts=(-self.shift_size, -self.shift_size), dims=(1, 2))
-            img_mask = torch.zeros((1, Hp, Wp, 1), device=query.device)
-            slices = (slice(0, -ws), slice(-ws, -self.shift_size), slice(-self.shift_size, None))
-            cnt = 0
-            for h in slices:
-                for w in slices:
-                    img_mask[:, h, w, :] = cnt
-                    cnt += 1
-            mask_windows = self.window_partition(img_mask).view(-1, ws * ws)
-            attn_mask = mask_windows.unsqueeze(1) - mask_windows.unsqueeze(2)
-            attn_mask = attn_mask.masked_fill(attn_mask != 0, float(-100.0)).masked_fill(attn_mask == 0, float(0.0))
-        else:
-            shifted, attn_mask = query, None
-        windows = self.window_partition(shifted).view(-1, ws * ws, C)
-        attn_windows = self.w_msa(windows, mask=attn_mask).view(-1, ws, ws, C)
-        shifted = self.window_reverse(attn_windows, Hp, Wp)
-        x = torch.roll(shifted, shifts=(self.shift_size, self.shift_size), dims=(1, 2)) if self.shift_size > 0 else shifted
-        if pad_r > 0 or pad_b:
-            x = x[:, :H, :W, :].contiguous()
-        return x.view(B, H * W, C)
 
 
 class _FFN(nn.Module):
@@ -114,9 +87,12 @@ class _FFN(nn.Module):
         super().__init__()
         self.layers = nn.Sequential(nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.GELU(), nn.Identity()),
                                     nn.Linear(feedforward_channels, embed_dims), nn.Identity())
+        object.__setattr__(self, "_pk", _Packed())
 
-    def forward(self, x):
-        return self.layers(x)
+    def packed(self, device):
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        return self._pk.get(device, (fc1, fc2), lambda: (T.PackedLinear(fc1.weight, fc1.bias),
+                                                         T.PackedLinear(fc2.weight, fc2.bias)))
 
 
 class SwinBlock(nn.Module):
@@ -127,9 +103,21 @@ class SwinBlock(nn.Module):
         self.norm2 = nn.LayerNorm(embed_dims)
         self.ffn = _FFN(embed_dims, feedforward_channels)
 
-    def forward(self, x, hw_shape):
-        x = x + self.attn(self.norm1(x), hw_shape)
-        return x + self.ffn(self.norm2(x))
+    def forward(self, x, geom):
+        """x [B * H * W, C] f32 token rows, updated IN PLACE; geom = _Geometry of the stage."""
+        msa = self.attn.w_msa
+        rowmap, (nwy, nwx) = geom.window_map(self.attn.shift_size)
+        qkv_w, proj_w, table = msa.packed(x.device)
+        fc1_w, fc2_w = self.ffn.packed(x.device)
+        n1, n2 = self.norm1, self.norm2
+        xw = T.layernorm(x, n1.weight, n1.bias, n1.eps, rowmap=rowmap, zero_out=True, pair=True)
+        qkv = T.linear(xw, qkv_w, a_pair=True)
+        ao = T.window_attention(qkv, table, msa.num_heads, nwy, nwx, self.attn.shift_size, msa.scale, pair=True)
+        T.linear(ao, proj_w, a_pair=True, residual=x, rowmap=rowmap, out=x)
+        xn = T.layernorm(x, n2.weight, n2.bias, n2.eps, pair=True)
+        hid = T.linear(xn, fc1_w, a_pair=True, act="gelu", out_pair=True)
+        T.linear(hid, fc2_w, a_pair=True, residual=x, out=x)
+        return x
 
 
 class PatchMerging(nn.Module):
@@ -137,32 +125,72 @@ class PatchMerging(nn.Module):
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
+        self.in_channels = in_channels
         self.norm = nn.LayerNorm(4 * in_channels)
         self.reduction = nn.Linear(4 * in_channels, out_channels, bias=False)
+        object.__setattr__(self, "_pk", _Packed())
 
-    def forward(self, x, hw_shape):
-        B, L, C = x.shape
-        H, W = hw_shape
-        x = x.view(B, H, W, C).permute(0, 3, 1, 2)
-        x = F.pad(x, (0, W % 2, 0, H % 2))                                    # "corner" padding to even sizes
-        x = F.unfold(x, kernel_size=2, stride=2)                              # [B, C*4, L/4], index c*4 + kh*2 + kw
-        out_hw = ((H + 1) // 2, (W + 1) // 2)
-        x = self.reduction(self.norm(x.transpose(1, 2)))
-        return x, out_hw
+    def packed(self, device):
+        C = self.in_channels
+
+        def build():
+            # the gather concatenates whole tokens (piece-major, index j * C + c); mmdet's unfold order is c * 4 + j
+            w = self.reduction.weight.detach().float().view(-1, C, 4).permute(0, 2, 1).reshape(-1, 4 * C)
+            g = self.norm.weight.detach().float().view(C, 4).t().reshape(-1).contiguous()
+            b = self.norm.bias.detach().float().view(C, 4).t().reshape(-1).contiguous()
+            return T.PackedLinear(w, None), g, b
+        return self._pk.get(device, (self.norm, self.reduction), build)
+
+    def forward(self, x, geom):
+        rowmap, out_hw = geom.merge_map()
+        w, g, b = self.packed(x.device)
+        xm = T.layernorm(x, g, b, self.norm.eps, rowmap=rowmap, G=4, pair=True)
+        return T.linear(xm, w, a_pair=True), out_hw
+
+
+class _Geometry:
+    """Row maps of one stage's token grid (B maps of H x W), built on the host once per shape and kept on the device."""
+    _cache = {}
+
+    def __init__(self, B, H, W, ws, device):
+        self.B, self.H, self.W, self.ws, self.device = B, H, W, ws, device
+
+    @classmethod
+    def of(cls, B, H, W, ws, device):
+        key = (B, H, W, ws, str(device))
+        if key not in cls._cache:
+            cls._cache[key] = cls(B, H, W, ws, device)
+            cls._cache[key]._maps = {}
+        return cls._cache[key]
+
+    def window_map(self, shift):
+        k = ("win", shift)
+        if k not in self._maps:
+            m, grid = T.window_rowmap(self.B, self.H, self.W, self.ws, shift)
+            self._maps[k] = (torch.from_numpy(m).to(self.device), grid)
+        return self._maps[k]
+
+    def merge_map(self):
+        if "merge" not in self._maps:
+            m, hw = T.merge_rowmap(self.B, self.H, self.W)
+            self._maps["merge"] = (torch.from_numpy(m).to(self.device), hw)
+        return self._maps["merge"]
 
 
 class SwinBlockSequence(nn.Module):
     def __init__(self, embed_dims, num_heads, feedforward_channels, depth, window_size, qkv_bias, qk_scale, downsample):
         super().__init__()
+        self.window_size = window_size
         self.blocks = nn.ModuleList([SwinBlock(embed_dims, num_heads, feedforward_channels, window_size, i % 2 == 1,
                                                qkv_bias, qk_scale) for i in range(depth)])
         self.downsample = downsample
 
-    def forward(self, x, hw_shape):
+    def forward(self, x, B, hw_shape):
+        geom = _Geometry.of(B, hw_shape[0], hw_shape[1], self.window_size, x.device)
         for block in self.blocks:
-            x = block(x, hw_shape)
+            x = block(x, geom)
         if self.downsample is not None:
-            x_down, down_hw = self.downsample(x, hw_shape)
+            x_down, down_hw = self.downsample(x, geom)
             return x_down, down_hw, x, hw_shape
         return x, hw_shape, x, hw_shape
 
@@ -176,14 +204,17 @@ class _PatchEmbed(nn.Module):
         object.__setattr__(self, "_run", _ConvAffine(self.projection, None, False))
 
     def forward(self, x):
-        """x channels-last [B,H,W,3] -> tokens [B, H/4 * W/4, C], (H/4, W/4)."""
+        """x channels-last [B,H,W,3] -> token rows [B * H/4 * W/4, C], (H/4, W/4)."""
         ps = self.patch_size
         B, H, W, _ = x.shape
-        x = F.pad(x, (0, 0, 0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
+        if W % ps or H % ps:
+            x = torch.nn.functional.pad(x, (0, 0, 0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
         y = self._run(x)
         hw = (y.shape[1], y.shape[2])
-        y = y.reshape(B, hw[0] * hw[1], -1)
-        return (self.norm(y) if self.norm is not None else y), hw
+        y = y.reshape(B * hw[0] * hw[1], -1)
+        if self.norm is not None:
+            y = T.layernorm(y, self.norm.weight, self.norm.bias, self.norm.eps)
+        return y, hw
 
 
 @BACKBONES.register_module
@@ -211,11 +242,13 @@ class SwinTransformer(nn.Module):
     def forward(self, x):
         if self.training:
             raise RuntimeError("al3d SwinTransformer implements the eval() path only")
+        B = x.shape[0]
         x, hw_shape = self.patch_embed(x)
         outs = []
         for i, stage in enumerate(self.stages):
-            x, hw_shape, out, out_hw = stage(x, hw_shape)
+            x, hw_shape, out, out_hw = stage(x, B, hw_shape)
             if i in self.out_indices:
-                out = getattr(self, f"norm{i}")(out)
-                outs.append(out.view(-1, *out_hw, self.num_features[i]).contiguous())
+                n = getattr(self, f"norm{i}")
+                out = T.layernorm(out, n.weight, n.bias, n.eps)
+                outs.append(out.view(B, *out_hw, self.num_features[i]))
         return tuple(outs)

@@ -1,0 +1,107 @@
+"""Device-side token-matrix primitives of the Swin-T image backbone (csrc/tokens.hip behind include/al3d.h's
+``al3d_tok_*``): LayerNorm over gathered rows, the f16x3 token GEMM with its fused epilogues, and 7 x 7 window
+attention.  torch tensors in, HIP kernels underneath; no CPU fallback.
+
+Activations are row matrices ``[rows, C]`` float32; "pair rows" (``pair=True``) hold the same bytes per row as the
+two f16 planes the f16x3 products multiply with (csrc/sp_rows.h) and only ever travel from a producing kernel to the
+GEMM that consumes them.
+"""
+import numpy as np
+import torch
+
+from . import lib
+from .detector_ops import pack_dma_f16x3, split_f16x3
+from .selector_ops import _dev, _ptr, _stream
+
+
+class PackedLinear:
+    """``nn.Linear`` weights in the token GEMM's format: LDS-DMA image of the (wh, wl) f16 planes, the 2^-s scale of
+    the split, the bias."""
+
+    def __init__(self, weight, bias=None):
+        w = weight.detach().float().contiguous()
+        self.n, self.k = w.shape
+        if self.k % 16:
+            raise lib.Al3dError(f"PackedLinear: in_features={self.k} must be a multiple of 16")
+        planes, scale = split_f16x3(w.view(self.n, 1, self.k))
+        self.image = pack_dma_f16x3(planes).data
+        self.scale = scale
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+
+
+def layernorm(x, gamma, beta, eps, rowmap=None, G=1, zero_out=False, rows_out=None, pair=False):
+    """LN over ``G * C`` channels of (gathered) rows of ``x [rows, C]`` -> ``[rows_out, G * C]``; see
+    ``al3d_tok_layernorm_f32``."""
+    x = _dev(x, torch.float32, "x")
+    C = x.shape[-1]
+    if rowmap is None:
+        rows_out = x.shape[0] // G if rows_out is None else rows_out
+    else:
+        rowmap = _dev(rowmap, torch.int32, "rowmap")
+        rows_out = rowmap.numel() // G
+    out = torch.empty((rows_out, G * C), dtype=torch.float32, device=x.device)
+    lib.call("al3d_tok_layernorm_f32", _ptr(x), _ptr(rowmap), rows_out, C, G, int(zero_out),
+             _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")), float(eps), int(pair),
+             _ptr(out), _stream())
+    return out
+
+
+def linear(a, packed, a_pair=False, act=None, residual=None, rowmap=None, out=None, out_rows=None, out_pair=False):
+    """``out[rowmap[m]] = act(a[m] @ W^T + b) + residual[rowmap[m]]``; ``residual`` may be ``out`` itself."""
+    a = _dev(a, torch.float32, "a")
+    M, K = a.shape
+    if K != packed.k:
+        raise lib.Al3dError(f"linear: a has {K} columns, the weights {packed.k}")
+    if rowmap is not None:
+        rowmap = _dev(rowmap, torch.int32, "rowmap")
+        if rowmap.numel() != M:
+            raise lib.Al3dError("linear: rowmap needs one entry per row of a")
+    if out is None:
+        if residual is not None and rowmap is not None:
+            out = residual                                   # scatter-add back into the residual stream, in place
+        else:
+            out = torch.empty((M if out_rows is None else out_rows, packed.n), dtype=torch.float32, device=a.device)
+    if residual is not None:
+        residual = _dev(residual, torch.float32, "residual")
+    lib.call("al3d_tok_linear_f16x3", _ptr(a), int(a_pair), _ptr(packed.image), _ptr(packed.scale), _ptr(packed.bias),
+             M, K, packed.n, {None: 0, "gelu": 1}[act], _ptr(residual), 0 if residual is None else residual.shape[-1],
+             _ptr(rowmap), _ptr(out), out.shape[-1], int(out_pair), _stream())
+    return out
+
+
+def window_attention(qkv, table, heads, win_rows, win_cols, shift, scale, pair=True):
+    """qkv ``[nwin * 49, 3 C]`` in window order -> attention output ``[nwin * 49, C]`` (pair rows by default)."""
+    qkv = _dev(qkv, torch.float32, "qkv")
+    rows, c3 = qkv.shape
+    C = c3 // 3
+    nwin = rows // 49
+    out = torch.empty((rows, C), dtype=torch.float32, device=qkv.device)
+    lib.call("al3d_tok_window_attention_f32", _ptr(qkv), _ptr(_dev(table, torch.float32, "table")), nwin, C, heads,
+             win_rows, win_cols, int(shift), float(scale), int(pair), _ptr(out), _stream())
+    return out
+
+
+def window_rowmap(B, H, W, ws, shift):
+    """Row map of the (shifted) window partition of ``B`` maps of ``H x W`` tokens: entry ``((b * nwy + wy) * nwx + wx) *
+    ws^2 + ty * ws + tx`` = index of the token that the cyclic shift by ``-shift`` and the padding to multiples of
+    ``ws`` put at that window position, or -1 for padding.  The same map scatters the attention output back
+    (``window_reverse`` + the inverse roll + the crop).  numpy int32 + (nwy, nwx)."""
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    nwy, nwx = Hp // ws, Wp // ws
+    hs = (np.arange(Hp) + shift) % Hp                     # shifted[h] = padded[(h + shift) % Hp]
+    wsf = (np.arange(Wp) + shift) % Wp
+    src = np.where((hs[:, None] < H) & (wsf[None, :] < W), hs[:, None] * W + wsf[None, :], -1)      # [Hp, Wp]
+    src = src.reshape(nwy, ws, nwx, ws).transpose(0, 2, 1, 3).reshape(-1)
+    full = np.where(src[None, :] >= 0, src[None, :] + (np.arange(B) * H * W)[:, None], -1)
+    return full.reshape(-1).astype(np.int32), (nwy, nwx)
+
+
+def merge_rowmap(B, H, W):
+    """Row map of patch merging: output token (b, oy, ox), piece kh * 2 + kw <- token (2 oy + kh, 2 ox + kw), -1
+    where the map is padded to even sizes.  numpy int32 [B * OH * OW * 4] + (OH, OW)."""
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    oy, ox, kh, kw = np.meshgrid(np.arange(OH), np.arange(OW), np.arange(2), np.arange(2), indexing="ij")
+    y, x = 2 * oy + kh, 2 * ox + kw
+    src = np.where((y < H) & (x < W), y * W + x, -1).reshape(-1)
+    full = np.where(src[None, :] >= 0, src[None, :] + (np.arange(B) * H * W)[:, None], -1)
+    return full.reshape(-1).astype(np.int32), (OH, OW)

@@ -534,6 +534,33 @@ int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int n
                                 float min_distance, float* out, int64_t* out_frame_off, void* workspace,
                                 void* stream);
 
+/* ---------------------------------------------------------------- token matrices (Swin-T image backbone, BASELINE configs[4])
+ * The reference configures mmdet 2.20.0's SwinTransformer (bevfusion/configs/nuscenes/det/transfusion/secfpn/
+ * camera+lidar/swint_v0p075/default.yaml:  embed_dims 96, depths [2,2,6,2], num_heads [3,6,12,24], window_size 7),
+ * which is not in the reference tree: these entry points implement the published block
+ *     x += proj(W-MSA(LN(x)));  x += fc2(GELU(fc1(LN(x))))      (Liu et al., ICCV 2021)
+ * and replace, per call, what torch would run as nn.LayerNorm / nn.Linear / softmax / matmul / roll / window
+ * partition.  "pair rows" = the f16x3 operand format of csrc/sp_rows.h (same bytes per row as f32).
+ *
+ * al3d_tok_layernorm_f32: out[i] = LN(concat_{g<G} x[rowmap[i*G+g]]) * gamma + beta over G*C channels (biased variance,
+ *   eps inside the root).  rowmap null = identity; entry -1 = absent piece: zeros BEFORE the statistics (patch merging's
+ *   map padding), or with zero_out (G == 1) a zero OUTPUT row (the window padding follows norm1).  C % 8 == 0,
+ *   G in {1, 4}, G*C <= 1536.
+ * al3d_tok_linear_f16x3: out[rowmap[m]] = act((a[m] . W^T) * scale + bias) + residual[rowmap[m]] for m < M; W as
+ *   al3d_split_f16x3 planes [2][N][1][K] packed by al3d_pack_f16x3_dma; scale = 2^-s of the split; act 0 none / 1 exact
+ *   (erf) GELU; rowmap null = identity, -1 = row dropped; residual (f32 rows, pitch ldr) may alias out.  K % 16 == 0,
+ *   N % 4 == 0 (8 for pair output).
+ * al3d_tok_window_attention_f32: qkv [nwin*49][3C] (q | k | v, each [heads][32]) -> softmax(q scale k^T + B + mask) v,
+ *   [nwin*49][C]; B = table[(yq-yk+6)*13 + (xq-xk+6)][head]; mask = -100 between tokens of different shifted-window
+ *   regions, derived from the window's position in its win_rows x win_cols grid and `shift` (0 = none). */
+int al3d_tok_layernorm_f32(const float* x, const int* rowmap, int64_t rows_out, int C, int G, int zero_out,
+                           const float* gamma, const float* beta, float eps, int out_pair, float* out, void* stream);
+int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt_image, const float* scale, const float* bias,
+                          int64_t M, int K, int N, int act, const float* residual, int ldr, const int* rowmap,
+                          float* out, int ldc, int out_pair, void* stream);
+int al3d_tok_window_attention_f32(const float* qkv, const float* table, int nwin, int C, int heads, int win_rows,
+                                  int win_cols, int shift, float scale, int out_pair, float* out, void* stream);
+
 /* ---------------------------------------------------------------- runtime
  * A HIP stream restricted to n_cus compute units starting at first_cu (hipExtStreamCreateWithCUMask); the
  * reference has no analogue (its loader workers are host processes, det3d/datasets/loader/build_loader.py:23-59):

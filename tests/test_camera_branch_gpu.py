@@ -4,8 +4,8 @@ Lift-Splat pooling, downsample) against plain-torch restatements of the referenc
 
 Reference: bevfusion/mmdet3d/models/necks/generalized_lss.py:13-110, vtransforms/depth_lss.py:14-102,
 vtransforms/base.py:196-262.  mmcv / mmdet are not importable here and no checkpoint exists offline, so these are
-restatements with seeded weights (parity unpinned, like the rest of the BEVFusion rows); the image backbone (Swin-T)
-is not built -- the tests start from synthetic backbone feature maps.
+restatements with seeded weights (parity unpinned, like the rest of the BEVFusion rows); the tests of this file
+start from synthetic backbone feature maps (the Swin-T backbone: tests/test_swin_gpu.py).
 
 Tolerances (fp32-class f16x3 convolutions against torch fp32; stated per check)."""
 import numpy as np
@@ -18,20 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _seed_(mod, seed):
-    g = torch.Generator().manual_seed(seed)
-    for m in mod.modules():
-        if isinstance(m, nn.Conv2d):
-            fan = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
-            m.weight.data = torch.randn(m.weight.shape, generator=g) * (2.0 / fan) ** 0.5
-            if m.bias is not None:
-                m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.1
-        elif isinstance(m, nn.BatchNorm2d):
-            m.weight.data = torch.rand(m.weight.shape, generator=g) + 0.5
-            m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.1
-            m.running_mean.data = torch.randn(m.running_mean.shape, generator=g) * 0.1
-            m.running_var.data = torch.rand(m.running_var.shape, generator=g) + 0.5
-    return mod.eval()
+from al3d.synthetic import camera_setup as _camera_setup, seed_modules_ as _seed_  # noqa: E402
 
 
 def _nhwc(x):
@@ -88,36 +75,6 @@ def _depth_image_reference(points, lidar2image, img_aug_matrix, lidar_aug_matrix
             for j in np.nonzero(inside)[0]:                                  # ascending point order: later points overwrite
                 out[b, c, int(row[j]), int(col[j])] = depth[j]
     return torch.from_numpy(out)
-
-
-def _camera_setup(B, N, seed, image_size):
-    """Plausible nuScenes-like camera matrices: N cameras looking around the ego vehicle."""
-    g = torch.Generator().manual_seed(seed)
-    iH, iW = image_size
-    K = torch.eye(4).repeat(B, N, 1, 1)
-    K[..., 0, 0] = K[..., 1, 1] = 0.48 * iW
-    K[..., 0, 2], K[..., 1, 2] = iW / 2.0, iH / 2.0
-    cam2lidar = torch.eye(4).repeat(B, N, 1, 1)
-    for n in range(N):
-        yaw = 2 * np.pi * n / N
-        # camera axes (x right, y down, z forward) expressed in the lidar frame
-        fwd = torch.tensor([np.cos(yaw), np.sin(yaw), 0.0])
-        right = torch.tensor([np.sin(yaw), -np.cos(yaw), 0.0])
-        down = torch.tensor([0.0, 0.0, -1.0])
-        cam2lidar[:, n, :3, :3] = torch.stack([right, down, fwd], 1).float()
-        cam2lidar[:, n, :3, 3] = torch.tensor([0.5 * np.cos(yaw), 0.5 * np.sin(yaw), 1.5]).float()
-    lidar2cam = torch.inverse(cam2lidar)
-    lidar2image = K.matmul(lidar2cam)
-    img_aug = torch.eye(4).repeat(B, N, 1, 1)
-    img_aug[..., 0, 0] = img_aug[..., 1, 1] = 0.9
-    img_aug[..., 0, 3], img_aug[..., 1, 3] = 3.0, -2.0
-    lidar_aug = torch.eye(4).repeat(B, 1, 1)
-    ang = 0.05
-    lidar_aug[:, 0, 0], lidar_aug[:, 0, 1], lidar_aug[:, 1, 0], lidar_aug[:, 1, 1] = np.cos(ang), -np.sin(ang), np.sin(ang), np.cos(ang)
-    lidar_aug[:, :3, 3] = torch.tensor([0.3, -0.2, 0.05])
-    points = [torch.cat([(torch.rand(4000, 2, generator=g) - 0.5) * 90.0, torch.rand(4000, 1, generator=g) * 4.0 - 2.0,
-                         torch.rand(4000, 2, generator=g)], 1) for _ in range(B)]
-    return K, cam2lidar, lidar2image, img_aug, lidar_aug, points
 
 
 def test_lidar_depth_image_matches_reference_loop():

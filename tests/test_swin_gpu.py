@@ -1,12 +1,21 @@
-"""GPU suite: the Swin-T image backbone (al3d/models/swin.py; mmdet 2.20.0's ``SwinTransformer`` is not in the reference
-tree -- parity unpinned, see the module docstring).  What can be pinned without the source:
-  * the relative-position index built the mmdet way equals the published construction (coords_i - coords_j);
-  * shifted-window attention (roll + window partition + additive region mask) equals a DENSE attention over all padded
-    tokens with an independently derived "same window and same region" mask, for a map that needs padding;
-  * output levels / strides / channels for the BEVFusion configuration, and the whole camera branch Swin-T ->
-    GeneralizedLSSFPN -> DepthLSSTransform runs end to end on them (finite, right shapes)."""
+"""GPU suite: the Swin-T image backbone on the token kernels (al3d/models/swin.py, csrc/tokens.hip; mmdet 2.20.0's
+``SwinTransformer`` is not in the reference tree -- parity unpinned, see the module docstring).
+
+What is checked, kernel by kernel, through the C ABI:
+  * ``al3d_tok_layernorm_f32`` / ``al3d_tok_linear_f16x3`` / ``al3d_tok_window_attention_f32`` against the torch
+    restatement (tests/swin_torch.py) evaluated in float64, at the fp32-class bound of
+    ``test_conv2d_f16x3_is_fp32_class`` (error <= 1.5e-6 of sum|a b| for the GEMM) and against the same restatement in
+    float32 (the kernel must not be further from the float64 value than ~3x torch's own fp32 evaluation);
+  * the restatement itself: mmdet-style relative-position index == the published construction; shifted-window attention
+    (roll + window partition + additive region mask) == a DENSE attention over all padded tokens with an independently
+    derived "same window and same region" mask, on a map that needs padding;
+  * one Swin block, patch merging and the whole Swin-T against the restatement at small and full (6 x 256 x 704) size;
+    output levels / strides / channels for the BEVFusion configuration, and the camera branch Swin-T ->
+    GeneralizedLSSFPN -> DepthLSSTransform end to end."""
+import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -23,7 +32,10 @@ def test_relative_position_index_is_the_published_one():
     assert torch.equal(m.relative_position_index, rel.sum(-1))
 
 
-def test_shifted_window_attention_equals_dense_masked_attention():
+def test_restatement_shifted_window_attention_equals_dense_masked_attention():
+    """Pins the CHECKER (tests/swin_torch.py): its shifted-window attention equals a dense attention over all padded
+    tokens with an independently built window / region mask."""
+    import swin_torch as R
     from al3d.models.swin import ShiftWindowMSA
     torch.manual_seed(3)
     C, heads, ws, shift = 96, 3, 7, 3
@@ -32,8 +44,7 @@ def test_shifted_window_attention_equals_dense_masked_attention():
     H, W = 16, 23                                                   # padded to 21 x 28
     x = torch.randn(2, H * W, C, device=DEV)
     with torch.no_grad():
-        got = attn(x, (H, W))
-        # ---- dense restatement
+        got = R.shift_window_msa(attn, x, (H, W))
         Hp, Wp = 21, 28
         xp = torch.zeros(2, Hp, Wp, C, device=DEV)
         xp[:, :H, :W] = x.view(2, H, W, C)
@@ -62,14 +73,230 @@ def test_shifted_window_attention_equals_dense_masked_attention():
     assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+# ------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("rows,C,G", [(1000, 96, 1), (333, 192, 1), (77, 768, 1), (250, 96, 4), (61, 384, 4)])
+def test_layernorm_kernel_matches_float64(rows, C, G):
+    from al3d import detector_ops as D
+    from al3d import token_ops as T
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows * G, C, generator=g) * torch.exp(torch.randn(rows * G, 1, generator=g)) + 0.7).to(DEV)
+    gamma = (torch.rand(G * C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(G * C, generator=g) * 0.1).to(DEV)
+    ref = F.layer_norm(x.double().view(rows, G * C), (G * C,), gamma.double(), beta.double(), 1e-5)
+    got = T.layernorm(x, gamma, beta, 1e-5, G=G)
+    tol = 4e-6 * (1.0 + ref.abs())                     # a few fp32 roundings of the normalised value
+    assert bool(((got.double() - ref).abs() <= tol).all())
+    # pair rows hold the same values to 2^-22 relative (2^-36 absolute below f16's normal range)
+    pair = D.rows_convert(T.layernorm(x, gamma, beta, 1e-5, G=G, pair=True), False)
+    assert bool(((pair - got).abs() <= 2.0 ** -21 * got.abs() + 2.0 ** -35).all())
+
+
+def test_layernorm_gather_maps():
+    """Window order with zero OUTPUT rows for the padding (norm1 precedes the pad), and the 2 x 2 merge gather with zero
+    INPUT pieces (the pad precedes the norm), against explicit torch indexing."""
+    from al3d import token_ops as T
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 2, 9, 11, 96
+    x = torch.randn(B * H * W, C, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    m, (nwy, nwx) = T.window_rowmap(B, H, W, 7, 3)
+    assert (nwy, nwx) == (2, 2) and m.shape == (B * 4 * 49,) and sorted(m[m >= 0].tolist()) == list(range(B * H * W))
+    mt = torch.from_numpy(m).to(DEV)
+    got = T.layernorm(x, gamma, beta, 1e-5, rowmap=mt, zero_out=True)
+    ln = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    ref = torch.where((mt >= 0)[:, None], ln[mt.clamp(min=0).long()], torch.zeros((), device=DEV))
+    assert float((got - ref).abs().max()) <= 5e-6 * (1.0 + float(ref.abs().max())) and bool((got[mt < 0] == 0).all())
+    # the window map agrees with roll + pad + partition of an index image
+    idx = torch.arange(B * H * W, dtype=torch.float32).view(B, H, W, 1) + 1.0
+    pad = F.pad(idx, (0, 0, 0, 14 - W, 0, 14 - H))
+    sh = torch.roll(pad, (-3, -3), (1, 2)).view(B, 2, 7, 2, 7).permute(0, 1, 3, 2, 4).reshape(-1)
+    assert torch.equal(sh.long() - 1, torch.from_numpy(m).long())
+    # merge map: F.unfold of the padded index image, piece-major
+    mm, (OH, OW) = T.merge_rowmap(B, H, W)
+    un = F.unfold(F.pad(idx.permute(0, 3, 1, 2), (0, W % 2, 0, H % 2)), 2, stride=2)           # [B, 4, OH*OW], row kh*2+kw
+    assert (OH, OW) == (5, 6) and torch.equal(un.transpose(1, 2).reshape(-1).long() - 1, torch.from_numpy(mm).long())
+    g4, b4 = (torch.rand(4 * C, generator=g) + 0.5).to(DEV), torch.randn(4 * C, generator=g).to(DEV)
+    mmt = torch.from_numpy(mm).to(DEV)
+    got = T.layernorm(x, g4, b4, 1e-5, rowmap=mmt, G=4)
+    pieces = torch.where((mmt >= 0)[:, None], x[mmt.clamp(min=0).long()], torch.zeros((), device=DEV)).view(-1, 4 * C)
+    ref = F.layer_norm(pieces, (4 * C,), g4, b4, 1e-5)
+    assert float((got - ref).abs().max()) <= 5e-6 * (1.0 + float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,N,xmag", [(1000, 96, 288, 1.0), (257, 96, 96, 1e-4), (128, 384, 96, 300.0),
+                                        (300, 768, 3072, 1.0), (64, 3072, 768, 1.0), (5, 192, 576, 1.0)])
+def test_token_gemm_is_fp32_class(M, K, N, xmag):
+    """The f16x3 token GEMM against float64: <= 1.5e-6 of sum|a w| (the bound of test_conv2d_f16x3_is_fp32_class), and
+    no further from the float64 value than 3x torch's own fp32 GEMM; f32 rows and pair rows in, the same bits."""
+    from al3d import detector_ops as D
+    from al3d import token_ops as T
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g)) * xmag).clamp(-6.0e4, 6.0e4).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    pk = T.PackedLinear(w, b)
+    ref = a.double() @ w.double().t() + b.double()
+    scale = a.abs().double() @ w.abs().double().t() + b.abs().double()
+    got = T.linear(a, pk)
+    e3 = float(((got.double() - ref).abs() / scale).max())
+    e32 = float((((a @ w.t() + b).double() - ref).abs() / scale).max())
+    assert e3 < 1.5e-6 and e3 < 3.0 * e32 + 1e-7, (e3, e32)
+    a_pair = D.rows_convert(a, True)
+    a_rt = D.rows_convert(a_pair, False)               # what the pair rows hold (22-23 significant bits)
+    got_p = T.linear(a_pair, pk, a_pair=True)
+    # pair rows in == their f32 values in (the same products, up to a re-split that may round xh the other way at a tie)
+    ref_rt = a_rt.double() @ w.double().t() + b.double()
+    assert float(((got_p.double() - ref_rt).abs() / scale).max()) < 1.5e-6
+    assert float(((got_p - T.linear(a_rt, pk)).double().abs() / scale).max()) < 2e-7
+    got_pp = D.rows_convert(T.linear(a_pair, pk, a_pair=True, out_pair=True), False) if N % 8 == 0 else None
+    if got_pp is not None:
+        assert bool(((got_pp - got_p).abs() <= 2.0 ** -21 * got_p.abs() + 2.0 ** -35).all())
+
+
+def test_token_gemm_epilogues():
+    """Exact GELU, residual, row scatter with dropped rows, in-place residual stream."""
+    from al3d import token_ops as T
+    g = torch.Generator().manual_seed(11)
+    M, K, N, R = 300, 96, 96, 260
+    a = torch.randn(M, K, generator=g).to(DEV)
+    w, b = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
+    pk = T.PackedLinear(w, b)
+    lin = a.double() @ w.double().t() + b.double()
+    got = T.linear(a, pk, act="gelu")
+    assert float((got.double() - F.gelu(lin)).abs().max()) <= 3e-6
+    perm = torch.randperm(M, generator=g)
+    rowmap = torch.full((M,), -1, dtype=torch.int32)
+    rowmap[perm[:R]] = torch.arange(R, dtype=torch.int32)          # R of the M rows land somewhere, the rest are dropped
+    rowmap = rowmap.to(DEV)
+    res = torch.randn(R, N, generator=g).to(DEV)
+    stream = res.clone()
+    out = T.linear(a, pk, residual=stream, rowmap=rowmap)          # scatter-add into the residual stream, in place
+    assert out.data_ptr() == stream.data_ptr()
+    ref = res.double().clone()
+    ref[rowmap[rowmap >= 0].long()] += lin[(rowmap >= 0)]
+    assert float((out.double() - ref).abs().max()) <= 3e-6 * (1.0 + float(ref.abs().max()))
+    with pytest.raises(Exception):
+        T.linear(a[:, :40].contiguous(), pk)                        # K mismatch
+
+
+@pytest.mark.parametrize("B,H,W,heads,shift", [(2, 14, 21, 3, 0), (2, 16, 23, 3, 3), (1, 8, 22, 24, 3), (3, 7, 7, 6, 3)])
+def test_window_attention_kernel_matches_float64(B, H, W, heads, shift):
+    """qkv in window order -> attention, against the restatement's WindowMSA core in float64 (bias gather through
+    mmdet's index, the additive 0 / -100 mask tensor) and bounded by torch's own fp32 evaluation."""
+    import swin_torch as R
+    from al3d import detector_ops as D
+    from al3d import token_ops as T
+    from al3d.models.swin import ShiftWindowMSA
+    C = 32 * heads
+    g = torch.Generator().manual_seed(H * W + heads)
+    attn = ShiftWindowMSA(C, heads, 7, shift)
+    attn.w_msa.relative_position_bias_table.data = torch.randn(169, heads, generator=g) * 0.7
+    attn = attn.to(DEV).eval()
+    m = attn.w_msa
+    rowmap, (nwy, nwx) = T.window_rowmap(B, H, W, 7, shift)
+    nwin = B * nwy * nwx
+    qkv = (torch.randn(nwin * 49, 3 * C, generator=g) * 1.5).to(DEV)
+
+    def core(dtype):
+        x = qkv.to(dtype).view(nwin, 49, 3, heads, 32).permute(2, 0, 3, 1, 4)
+        q, k, v = x[0], x[1], x[2]
+        a = (q * m.scale) @ k.transpose(-2, -1)
+        bias = m.relative_position_bias_table.to(dtype)[m.relative_position_index.view(-1)].view(49, 49, -1)
+        a = a + bias.permute(2, 0, 1).unsqueeze(0)
+        if shift:
+            Hp, Wp = nwy * 7, nwx * 7
+            img = torch.zeros((1, Hp, Wp, 1), device=DEV, dtype=dtype)
+            cnt = 0
+            for hs in (slice(0, -7), slice(-7, -shift), slice(-shift, None)):
+                for ws_ in (slice(0, -7), slice(-7, -shift), slice(-shift, None)):
+                    img[:, hs, ws_, :] = cnt
+                    cnt += 1
+            mw = R._window_partition(img, 7).view(-1, 49)
+            am = mw.unsqueeze(1) - mw.unsqueeze(2)
+            am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+            a = (a.view(B, nwy * nwx, heads, 49, 49) + am.unsqueeze(1).unsqueeze(0)).view(-1, heads, 49, 49)
+        return (a.softmax(-1) @ v).transpose(1, 2).reshape(nwin * 49, C)
+
+    with torch.no_grad():
+        ref, ref32 = core(torch.float64), core(torch.float32)
+    got = T.window_attention(qkv, m.relative_position_bias_table.detach(), heads, nwy, nwx, shift, m.scale, pair=False)
+    got = got.detach()
+    e = float((got.double() - ref).abs().max())
+    e32 = float((ref32.double() - ref).abs().max())
+    assert e <= 3.0 * e32 + 2e-6 and e <= 1e-5, (e, e32)
+    pair = D.rows_convert(T.window_attention(qkv, m.relative_position_bias_table.detach(), heads, nwy, nwx, shift, m.scale), False)
+    assert bool(((pair - got).abs() <= 2.0 ** -21 * got.abs() + 2.0 ** -35).all())
+
+
+# ------------------------------------------------------------------ modules
+@pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 23, 96, 3, True), (2, 14, 14, 192, 6, False), (1, 8, 22, 768, 24, True)])
+def test_swin_block_matches_restatement(B, H, W, C, heads, shift):
+    import swin_torch as R
+    from al3d.models.swin import SwinBlock, _Geometry
+    from al3d.synthetic import seed_modules_
+    blk = seed_modules_(SwinBlock(C, heads, 4 * C, 7, shift), 17).to(DEV)
+    x = torch.randn(B, H * W, C, generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        ref = R.block(blk.double(), x.double(), (H, W))
+        ref32 = R.block(blk.float(), x, (H, W))
+        got = blk(x.clone().view(B * H * W, C), _Geometry.of(B, H, W, 7, x.device)).view(B, H * W, C)
+    e, e32 = float((got.double() - ref).abs().max()), float((ref32.double() - ref).abs().max())
+    assert e <= 3.0 * e32 + 1e-6 * float(ref.abs().max()), (e, e32)
+
+
+def test_patch_merging_matches_restatement():
+    import swin_torch as R
+    from al3d.models.swin import PatchMerging, _Geometry
+    from al3d.synthetic import seed_modules_
+    B, H, W, C = 2, 9, 11, 96
+    pm = seed_modules_(PatchMerging(C, 2 * C), 4).to(DEV)
+    x = torch.randn(B, H * W, C, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        ref, hw = R.patch_merging(pm.double(), x.double(), (H, W))
+        ref32, _ = R.patch_merging(pm.float(), x, (H, W))
+        got, hw2 = pm(x.view(B * H * W, C), _Geometry.of(B, H, W, 7, x.device))
+    assert hw == hw2 == (5, 6)
+    e, e32 = float((got.view_as(ref).double() - ref).abs().max()), float((ref32.double() - ref).abs().max())
+    assert e <= 3.0 * e32 + 1e-6 * float(ref.abs().max()), (e, e32)
+
+
+def _swin_t():
+    from al3d.models.swin import SwinTransformer
+    from al3d.synthetic import seed_modules_
+    return seed_modules_(SwinTransformer(embed_dims=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7,
+                                         mlp_ratio=4, qkv_bias=True, patch_norm=True, out_indices=[1, 2, 3]), 23)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 96, 160), (6, 256, 704)])
+def test_swin_t_matches_restatement(B, H, W):
+    """Whole backbone against the torch restatement in float64 (small) / float32 (full configs[4] size: 6 cameras of
+    256 x 704), per output level, relative to the level's scale."""
+    import swin_torch as R
+    swin = _swin_t().to(DEV)
+    img = torch.randn(B, H, W, 3, generator=torch.Generator().manual_seed(9)).to(DEV)
+    with torch.no_grad():
+        got = swin(img)
+        again = swin(img)
+        ref32 = R.swin(swin, img)
+        ref = R.swin(swin.double(), img, torch.float64) if H < 200 else None
+        swin.float()
+    assert all(torch.equal(a, b) for a, b in zip(got, again))                      # deterministic
+    for lvl, (o, r32) in enumerate(zip(got, ref32)):
+        assert o.shape == r32.shape and bool(torch.isfinite(o).all())
+        s = float(r32.abs().max())
+        if ref is not None:
+            e, e32 = float((o.double() - ref[lvl]).abs().max()), float((r32.double() - ref[lvl]).abs().max())
+            assert e <= 3.0 * e32 + 2e-6 * s, (lvl, e, e32, s)
+        else:
+            assert float((o - r32).abs().max()) <= 2e-4 * s, (lvl, float((o - r32).abs().max()), s)
+
+
 def test_swin_t_levels_and_camera_branch_end_to_end():
     from al3d.models import DepthLSSTransform, GeneralizedLSSFPN
-    from al3d.models.swin import SwinTransformer
-    from test_camera_branch_gpu import _camera_setup, _seed_
+    from al3d.synthetic import camera_setup, seed_modules_
     torch.manual_seed(5)
     image_size, feature_size = (256, 704), (32, 88)
-    swin = SwinTransformer(embed_dims=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4,
-                           qkv_bias=True, patch_norm=True, out_indices=[1, 2, 3]).to(DEV).eval()
+    swin = _swin_t().to(DEV)
     names = set(swin.state_dict())
     for key in ("patch_embed.projection.weight", "patch_embed.norm.weight", "stages.0.blocks.1.attn.w_msa.qkv.bias",
                 "stages.2.blocks.5.attn.w_msa.relative_position_bias_table", "stages.1.blocks.0.ffn.layers.0.0.weight",
@@ -79,10 +306,10 @@ def test_swin_t_levels_and_camera_branch_end_to_end():
     assert "norm0.weight" not in names and "stages.3.downsample.norm.weight" not in names
     B, N = 1, 6
     img = torch.randn(B * N, *image_size, 3, device=DEV)
-    neck = _seed_(GeneralizedLSSFPN([192, 384, 768], 256, 3), 7).to(DEV)
-    vt = _seed_(DepthLSSTransform(256, 80, image_size, feature_size, [-54.0, 54.0, 0.3], [-54.0, 54.0, 0.3],
-                                  [-10.0, 10.0, 20.0], [1.0, 60.0, 0.5], downsample=2), 8).to(DEV)
-    K, cam2lidar, lidar2image, img_aug, lidar_aug, points = _camera_setup(B, N, 9, image_size)
+    neck = seed_modules_(GeneralizedLSSFPN([192, 384, 768], 256, 3), 7).to(DEV)
+    vt = seed_modules_(DepthLSSTransform(256, 80, image_size, feature_size, [-54.0, 54.0, 0.3], [-54.0, 54.0, 0.3],
+                                         [-10.0, 10.0, 20.0], [1.0, 60.0, 0.5], downsample=2), 8).to(DEV)
+    K, cam2lidar, lidar2image, img_aug, lidar_aug, points = camera_setup(B, N, 9, image_size)
     with torch.no_grad():
         feats = swin(img)
         assert [tuple(f.shape) for f in feats] == [(6, 32, 88, 192), (6, 16, 44, 384), (6, 8, 22, 768)]
@@ -92,6 +319,23 @@ def test_swin_t_levels_and_camera_branch_end_to_end():
         bev = vt(fpn[0].view(B, N, 32, 88, 256), [p.to(DEV) for p in points], lidar2image.to(DEV), K.to(DEV),
                  cam2lidar.to(DEV), img_aug.to(DEV), lidar_aug.to(DEV))
     assert tuple(bev.shape) == (1, 180, 180, 80) and bool(torch.isfinite(bev).all()) and float(bev.abs().max()) > 0
+
+
+def test_swin_reloads_weights_after_load_state_dict():
+    """The packed-weight caches follow the parameters: a load_state_dict after the first forward changes
+    the output accordingly."""
+    import swin_torch as R
+    from al3d.synthetic import seed_modules_
+    swin = _swin_t().to(DEV)
+    img = torch.randn(1, 64, 96, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        first = swin(img)
+        other = {k: v.clone() for k, v in seed_modules_(_swin_t(), 99).state_dict().items()}
+        swin.load_state_dict(other)
+        second = swin(img)
+        ref = R.swin(swin, img)
+    assert not torch.equal(first[0], second[0])
+    assert float((second[0] - ref[0]).abs().max()) <= 2e-4 * float(ref[0].abs().max())
 
 
 def test_assembled_camera_lidar_model_runs_and_is_deterministic():
@@ -104,19 +348,19 @@ def test_assembled_camera_lidar_model_runs_and_is_deterministic():
     from al3d.datasets import DeviceSweepLoader, PoolFrames
     from al3d.models import build_detector
     from al3d.models.bevfusion_model import BEVFusionCameraLidar, transfusion_head_for
+    from al3d.synthetic import camera_setup, seed_modules_
     from al3d.utils import Config
-    from test_camera_branch_gpu import _camera_setup, _seed_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = Config.fromfile(os.path.join(root, "examples", "active", "bevfusion_lidar_spatial_temporal_feature.py"))
     lidar = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     synthetic.seeded_init_(lidar, seed=0)
     model = BEVFusionCameraLidar(lidar, head=transfusion_head_for())
     for i, m in enumerate((model.camera_backbone, model.camera_neck, model.vtransform, model.fuser, model.head)):
-        _seed_(m, 40 + i)
+        seed_modules_(m, 40 + i)
     model = model.to(DEV).eval()
     pool = PoolFrames.from_synthetic(2, DEV, num_base=2, seed=1)
     ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, None, 1, device=DEV)))
-    K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = _camera_setup(1, 6, 9, (256, 704))
+    K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = camera_setup(1, 6, 9, (256, 704))
     img = torch.randn(1, 6, 256, 704, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
     mats = (lidar2image.to(DEV), K.to(DEV), cam2lidar.to(DEV), img_aug.to(DEV), lidar_aug.to(DEV))
     with torch.no_grad():

@@ -9,7 +9,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 
 from al3d import synthetic
@@ -17,7 +16,7 @@ from al3d.datasets import DeviceSweepLoader, PoolFrames
 from al3d.models import build_detector
 from al3d.models.bevfusion_model import BEVFusionCameraLidar, transfusion_head_for
 from al3d.utils import Config
-from test_camera_branch_gpu import _camera_setup, _seed_
+from al3d.synthetic import camera_setup as _camera_setup, seed_modules_ as _seed_
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
