@@ -452,21 +452,38 @@ __device__ __forceinline__ int tk_region1(int v, int n, int shift)
     return (v >= n - TK_WS ? 1 : 0) + (v >= n - shift ? 1 : 0);
 }
 
-// One wave per (window, head).  C-layout of v_mfma_f32_32x32x16: column = lane & 31, rows in the 16 registers
+// One wave (= one 64-thread workgroup) per (window, head).  The head's q, k, v rows (49 x 128 B each, 1152+ B apart in
+// the qkv matrix) come in by LDS-DMA, eight whole rows per instruction (every 128-byte line fetched once, by one
+// instruction); a row's eight 16-byte chunks are stored permuted (chunk q at position q ^ ((row >> 1) & 7), applied
+// on the SOURCE side: the LDS side of a DMA is lane-linear) so that the fragment reads are conflict-free.
+// C-layout of v_mfma_f32_32x32x16: column = lane & 31, rows in the 16 registers
 // (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); S^T puts the KEYS on the rows, so a query's softmax runs down a
 // lane's registers (+ one exchange with lane ^ 32), and P^T is already the B operand of O^T = V^T P^T: registers
 // 8 s .. 8 s + 7 of a tile are k-step s, in the order key = 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the V^T fragment
-// is loaded in that same order.  Both operands of both products are activations: each is split (xh, xl' = residual
+// is read in that same order.  Both operands of both products are activations: each is split (xh, xl' = residual
 // x 2^11) and the product is  xh yh  +  2^-11 (xh yl' + xl' yh)  with the two brackets in separate accumulators.
-__global__ __launch_bounds__(256) void tok_window_attention_kernel(TokAttnParams p)
+#define TK_AROWS 56                   // rows staged per array: 7 DMA instructions of 8 rows; rows 49 .. 55 are zero
+#define TK_ABYTES (TK_AROWS * 128)
+
+__device__ __forceinline__ unsigned tk_arow_off(int row, int chunk)      // byte offset of 16-byte chunk `chunk` of a staged row
 {
-    __shared__ float tbl[4][176];
-    __shared__ int treg[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= p.nwin * p.heads) return;              // wave-uniform; the kernel has no workgroup barrier
+    const int r = row < TK_AROWS ? row : TK_AROWS - 1;                   // rows 56 .. 63 of a tile read a zero row
+    return (unsigned)(r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
+}
+
+__global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char stg[3 * TK_ABYTES];    // k | q | v
+    __shared__ float tbl[1][176];
+    __shared__ int treg[1][64];
+    const int lane = threadIdx.x;
+    constexpr int wave = 0;
+    const int item = blockIdx.x;
     const int win = item / p.heads, head = item - win * p.heads;
     const int c = lane & 31, h = lane >> 5;
+    const int ld = 3 * p.C;
+    const float* base = p.qkv + (int64_t)win * TK_NT * ld + head * 32;
+    const unsigned stg_base = (unsigned)(size_t)(tk_lds_void*)stg;
     for (int t = lane; t < 169; t += 64) tbl[wave][t] = p.table[t * p.heads + head];
     {
         const int wi = win % (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
@@ -475,55 +492,72 @@ __global__ __launch_bounds__(256) void tok_window_attention_kernel(TokAttnParams
             ? tk_region1(wy * TK_WS + ty, p.nwy * TK_WS, p.shift) * 3 + tk_region1(wx * TK_WS + tx, p.nwx * TK_WS, p.shift)
             : 0;
     }
+    {
+        const int rl = lane >> 3, pos = lane & 7;
+#pragma unroll
+        for (int arr = 0; arr < 3; ++arr) {
+            const int aoff = arr == 0 ? p.C : arr == 1 ? 0 : 2 * p.C;
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int row = it * 8 + rl;
+                const int chunk = pos ^ ((row >> 1) & 7);
+                const float* src = row < TK_NT ? base + (int64_t)row * ld + aoff + chunk * 4 : g_tok_zero + chunk * 4;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(stg_base + arr * TK_ABYTES + it * 1024);
+                __builtin_amdgcn_global_load_lds((tk_gbl_void*)src, (tk_lds_void*)(size_t)dst, 16, 0, 0);
+            }
+        }
+    }
+    tk_wait_vm<7>();                                   // k and q have landed (v: 7 instructions still in flight)
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
-    const int ld = 3 * p.C;
-    const float* base = p.qkv + (int64_t)win * TK_NT * ld + head * 32;
-    f16x8 kh[2][2], kl[2][2], qh[2][2], ql[2][2];
+    // K fragments (A operand: rows = keys) stay in registers for both query tiles
+    f16x8 kh[2][2], kl[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 32 * i + c;
-        const bool ok = row < TK_NT;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const float* kp = base + (int64_t)row * ld + p.C + 16 * s + 8 * h;
-            const float* qp = base + (int64_t)row * ld + 16 * s + 8 * h;
-            float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, q0 = k0, q1 = k0;
-            if (ok) {
-                k0 = *reinterpret_cast<const float4*>(kp); k1 = *reinterpret_cast<const float4*>(kp + 4);
-                q0 = *reinterpret_cast<const float4*>(qp); q1 = *reinterpret_cast<const float4*>(qp + 4);
-            }
-            const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-            const float qv[8] = {q0.x * p.scale, q0.y * p.scale, q0.z * p.scale, q0.w * p.scale,
-                                 q1.x * p.scale, q1.y * p.scale, q1.z * p.scale, q1.w * p.scale};
-            tk_split8(kv, kh[i][s], kl[i][s]);
-            tk_split8(qv, qh[i][s], ql[i][s]);
+            tk_f32x4 lo, hi;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(lo), "=&v"(hi)
+                         : "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h)), "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h + 1))
+                         : "memory");
+            tk_split8v(lo, hi, kh[i][s], kl[i][s]);
         }
-    }
-    f32x16 sm[2][2], sc[2][2];
+    const bool masked = p.shift > 0;
+    // one 32-query tile at a time (a real loop: the state of a tile -- 64 logit + 32 output accumulators -- is live only
+    // inside its iteration, which is what lets several waves share a SIMD)
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+        const int query = 32 * j + c;
+        f16x8 qh[2], ql[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int s = 0; s < 2; ++s) {
+            tk_f32x4 lo, hi;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(lo), "=&v"(hi)
+                         : "v"(stg_base + TK_ABYTES + tk_arow_off(query, 4 * s + 2 * h)),
+                           "v"(stg_base + TK_ABYTES + tk_arow_off(query, 4 * s + 2 * h + 1))
+                         : "memory");
+            const float qv[8] = {lo[0] * p.scale, lo[1] * p.scale, lo[2] * p.scale, lo[3] * p.scale,
+                                 hi[0] * p.scale, hi[1] * p.scale, hi[2] * p.scale, hi[3] * p.scale};
+            tk_split8(qv, qh[s], ql[s]);
+        }
+        f32x16 sm[2], sc[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sm[i][j][r] = 0.f; sc[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { sm[i][r] = 0.f; sc[i][r] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                sc[i][j] = TK_MFMA(kl[i][s], qh[j][s], sc[i][j]);
-                sc[i][j] = TK_MFMA(kh[i][s], ql[j][s], sc[i][j]);
-                sm[i][j] = TK_MFMA(kh[i][s], qh[j][s], sm[i][j]);
+                sc[i] = TK_MFMA(kl[i][s], qh[s], sc[i]);
+                sc[i] = TK_MFMA(kh[i][s], ql[s], sc[i]);
+                sm[i] = TK_MFMA(kh[i][s], qh[s], sm[i]);
             }
-
-    // logits -> probabilities, in place in sm[i][j] (rows = keys, column = this lane's query of tile j)
-    const bool masked = p.shift > 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int query = 32 * j + c, qq = query < TK_NT ? query : TK_NT - 1;
+        // logits -> probabilities, in place in sm[i] (rows = keys, column = this lane's query)
+        const int qq = query < TK_NT ? query : TK_NT - 1;
         const int qcode = qq + 6 * ((qq * 37) >> 8) + 84;           // 13 y + x + 84
         const int qreg = treg[wave][qq];
         float mx = -INFINITY;
@@ -532,14 +566,14 @@ __global__ __launch_bounds__(256) void tok_window_attention_kernel(TokAttnParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = sm[i][j][r] + sc[i][j][r] * 0.00048828125f;
+                float v = sm[i][r] + sc[i][r] * 0.00048828125f;
                 if (key < TK_NT) {
                     v += tbl[wave][qcode - (key + 6 * ((key * 37) >> 8))];
                     if (masked && treg[wave][key] != qreg) v += -100.0f;
                 } else {
                     v = -INFINITY;
                 }
-                sm[i][j][r] = v;
+                sm[i][r] = v;
                 mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -548,60 +582,57 @@ __global__ __launch_bounds__(256) void tok_window_attention_kernel(TokAttnParams
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(sm[i][j][r] - mx);
-                sm[i][j][r] = e;
+                // e^(v - mx) = 2^((v - mx) log2 e): the product in two pieces so that the argument of v_exp_f32 carries no
+                // rounding of its own beyond 2^-24 relative (|v - mx| <= ~100 here)
+                const float d = sm[i][r] - mx;
+                const float t = __builtin_fmaf(d, 1.44269502162933349609f, d * 1.92596299112661746e-8f);
+                const float e = __builtin_amdgcn_exp2f(t);
+                sm[i][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
+        // O^T[d][query] = sum_key V[key][d] P[query][key]; P is normalised AFTER the product (one multiply per output)
+        tk_wait_vm<0>();                               // v has landed (no-op for the second tile)
+        f32x16 om, oc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { om[r] = 0.f; oc[r] = 0.f; }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sm[i][j][r] *= inv;
-    }
-
-    // O^T[d][query] = sum_key V[key][d] P[query][key]
-    f32x16 om[2], oc[2];
+            for (int s = 0; s < 2; ++s) {
+                float vv[8];
+                unsigned va[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { om[j][r] = 0.f; oc[j][r] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float vv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int key = 32 * i + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
-                vv[e] = key < TK_NT ? base[(int64_t)key * ld + 2 * p.C + c] : 0.f;
-            }
-            f16x8 vh, vl;
-            tk_split8(vv, vh, vl);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
+                for (int e = 0; e < 8; ++e) {
+                    const int key = 32 * i + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+                    va[e] = stg_base + 2 * TK_ABYTES + tk_arow_off(key, c >> 2) + ((c & 3) << 2);
+                }
+                // one block: the wait belongs to the reads (separate asm statements could be scheduled apart from their uses)
+                asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+                             "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(vv[0]), "=&v"(vv[1]), "=&v"(vv[2]), "=&v"(vv[3]), "=&v"(vv[4]), "=&v"(vv[5]), "=&v"(vv[6]), "=&v"(vv[7])
+                             : "v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]), "v"(va[6]), "v"(va[7])
+                             : "memory");
+                f16x8 vh, vl, ph, pl;
+                tk_split8(vv, vh, vl);
                 float pv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = sm[i][j][8 * s + e];
-                f16x8 ph, pl;
+                for (int e = 0; e < 8; ++e) pv[e] = sm[i][8 * s + e];
                 tk_split8(pv, ph, pl);
-                oc[j] = TK_MFMA(vl, ph, oc[j]);
-                oc[j] = TK_MFMA(vh, pl, oc[j]);
-                om[j] = TK_MFMA(vh, ph, om[j]);
+                oc = TK_MFMA(vl, ph, oc);
+                oc = TK_MFMA(vh, pl, oc);
+                om = TK_MFMA(vh, ph, om);
             }
-        }
-
-    // rows of O^T are d = (r & 3) + 8 (r >> 2) + 4 h: four consecutive channels per register quad
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int query = 32 * j + c;
         if (query >= TK_NT) continue;
+        // rows of O^T are d = (r & 3) + 8 (r >> 2) + 4 h: four consecutive channels per register quad
         float* orow = p.out + ((int64_t)win * TK_NT + query) * p.C + head * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float y[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = om[j][4 * g + e] + oc[j][4 * g + e] * 0.00048828125f;
+            for (int e = 0; e < 4; ++e) y[e] = (om[4 * g + e] + oc[4 * g + e] * 0.00048828125f) * inv;
             if (p.pair) {                                // group g of the head: xh[8] | xl'[8]; this lane owns elements 4 h .. 4 h + 3
                 _Float16 hh[4], ll[4];
 #pragma unroll
@@ -631,7 +662,7 @@ extern "C" int al3d_tok_window_attention_f32(const float* qkv, const float* tabl
     if (nwin == 0) return AL3D_OK;
     TokAttnParams p{qkv, table, out, nwin, C, heads, win_rows, win_cols, shift, scale, out_pair};
     const int64_t items = (int64_t)nwin * heads;
-    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)al3d_cdiv(items, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("tok_window_attention_kernel");
     return AL3D_OK;
 }
