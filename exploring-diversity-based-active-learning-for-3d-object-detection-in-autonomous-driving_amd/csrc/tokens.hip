@@ -167,6 +167,50 @@ extern "C" int al3d_tok_layernorm_f32(const float* x, const int* rowmap, int64_t
     return AL3D_OK;
 }
 
+// ------------------------------------------------------------------ patch rows of the 4 x 4 / stride 4 embedding
+// img [B][H][W][3] f32 channels-last -> rows [B * TH * TW][48] (pair rows or f32), row = one 4 x 4 patch in the order
+// k = (ky * 4 + kx) * 3 + c; pixels beyond H / W are zero (the reference pads the image to a multiple of the patch).
+// One lane per (row, group of 8 k).
+__global__ __launch_bounds__(256) void tok_patch_rows_kernel(const float* __restrict__ img, int B, int H, int W, int TH, int TW,
+                                                             int pair, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = (int64_t)B * TH * TW;
+    if (t >= rows * 6) return;
+    const int g = (int)(t % 6);
+    int64_t row = t / 6;
+    const int tx = (int)(row % TW), ty = (int)((row / TW) % TH), b = (int)(row / ((int64_t)TW * TH));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * g + e, ky = k / 12, r = k - 12 * ky, kx = r / 3, ch = r - 3 * kx;
+        const int y = 4 * ty + ky, x = 4 * tx + kx;
+        v[e] = (y < H && x < W) ? img[(((int64_t)b * H + y) * W + x) * 3 + ch] : 0.f;
+    }
+    float* o = out + row * 48 + 8 * g;
+    if (pair) {
+        uint4 hi, lo;
+        sp_split8(v, hi, lo);
+        *reinterpret_cast<uint4*>(o) = hi;
+        *reinterpret_cast<uint4*>(o + 4) = lo;
+    } else {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+extern "C" int al3d_tok_patch_rows_f32(const float* img, int B, int H, int W, int out_pair, float* out, void* stream)
+{
+    AL3D_REQUIRE(img && out && B >= 1 && H >= 1 && W >= 1, "al3d_tok_patch_rows_f32: bad arguments");
+    AL3D_REQUIRE(((uintptr_t)out & 15) == 0, "al3d_tok_patch_rows_f32: out must be 16-byte aligned");
+    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+    const int64_t n = (int64_t)B * TH * TW * 6;
+    hipLaunchKernelGGL(tok_patch_rows_kernel, dim3((unsigned)al3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, B, H, W, TH,
+                       TW, out_pair, out);
+    AL3D_CHECK_LAUNCH("tok_patch_rows_kernel");
+    return AL3D_OK;
+}
+
 // ------------------------------------------------------------------ token GEMM, f16x3, both operands by LDS-DMA
 struct TokGemmParams {
     const float* a;         // [M][K] f32 rows or pair rows

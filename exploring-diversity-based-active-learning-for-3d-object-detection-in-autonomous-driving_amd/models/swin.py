@@ -20,15 +20,15 @@ How a block runs (seven launches, no torch op touches an activation):
   fc1 + exact GELU, pair rows                                              al3d_tok_linear_f16x3
   fc2 + residual                                                           al3d_tok_linear_f16x3
 Patch merging = LN over the gathered 2 x 2 neighbourhood + one GEMM (weights re-ordered once from mmdet's
-channel-major unfold order to piece-major); the patch embedding is a 4 x 4 / stride 4 convolution on the dense conv
-kernel.  The modules only hold parameters (state-dict compatible); ``tests/swin_torch.py`` is the torch restatement the
+channel-major unfold order to piece-major); the patch embedding is a gather of 4 x 4 patches into rows of 48
+(al3d_tok_patch_rows_f32) + one GEMM.  The modules only hold parameters (state-dict compatible); ``tests/swin_torch.py`` is the torch restatement the
 kernels are checked against.  Eval only (no dropout / drop-path).
 """
 import torch
 from torch import nn
 
 from .. import token_ops as T
-from .bevfusion_camera import _ConvAffine, _versions
+from .bevfusion_camera import _versions
 from .registry import BACKBONES
 
 
@@ -196,22 +196,25 @@ class SwinBlockSequence(nn.Module):
 
 
 class _PatchEmbed(nn.Module):
+    """mmdet ``PatchEmbed``: Conv2d(in, embed, 4, stride 4) (+ LayerNorm) -- here a gather of 4 x 4 patches into rows of
+    48 and one token GEMM."""
+
     def __init__(self, in_channels, embed_dims, patch_size, patch_norm):
         super().__init__()
+        if in_channels != 3 or patch_size != 4:
+            raise NotImplementedError("the patch-row kernel is built for 3-channel images and 4 x 4 patches")
         self.patch_size = patch_size
         self.projection = nn.Conv2d(in_channels, embed_dims, kernel_size=patch_size, stride=patch_size)
         self.norm = nn.LayerNorm(embed_dims) if patch_norm else None
-        object.__setattr__(self, "_run", _ConvAffine(self.projection, None, False))
+        object.__setattr__(self, "_pk", _Packed())
 
     def forward(self, x):
         """x channels-last [B,H,W,3] -> token rows [B * H/4 * W/4, C], (H/4, W/4)."""
-        ps = self.patch_size
-        B, H, W, _ = x.shape
-        if W % ps or H % ps:
-            x = torch.nn.functional.pad(x, (0, 0, 0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
-        y = self._run(x)
-        hw = (y.shape[1], y.shape[2])
-        y = y.reshape(B * hw[0] * hw[1], -1)
+        pr = self.projection
+        w = self._pk.get(x.device, (pr,), lambda: T.PackedLinear(
+            pr.weight.detach().permute(0, 2, 3, 1).reshape(pr.out_channels, -1), pr.bias))      # [C, (ky, kx, c)]
+        rows, hw = T.patch_rows(x, pair=True)
+        y = T.linear(rows, w, a_pair=True)
         if self.norm is not None:
             y = T.layernorm(y, self.norm.weight, self.norm.bias, self.norm.eps)
         return y, hw

@@ -29,6 +29,18 @@ class PackedLinear:
         self.bias = None if bias is None else bias.detach().float().contiguous()
 
 
+def patch_rows(img, pair=True):
+    """img ``[B, H, W, 3]`` channels-last -> 4 x 4 patch rows ``[B * ceil(H/4) * ceil(W/4), 48]`` (k = (ky*4 + kx)*3 + c)."""
+    img = _dev(img, torch.float32, "img")
+    B, H, W, ch = img.shape
+    if ch != 3:
+        raise lib.Al3dError("patch_rows: expected 3 image channels")
+    th, tw = (H + 3) // 4, (W + 3) // 4
+    out = torch.empty((B * th * tw, 48), dtype=torch.float32, device=img.device)
+    lib.call("al3d_tok_patch_rows_f32", _ptr(img), B, H, W, int(pair), _ptr(out), _stream())
+    return out, (th, tw)
+
+
 def layernorm(x, gamma, beta, eps, rowmap=None, G=1, zero_out=False, rows_out=None, pair=False):
     """LN over ``G * C`` channels of (gathered) rows of ``x [rows, C]`` -> ``[rows_out, G * C]``; see
     ``al3d_tok_layernorm_f32``."""

@@ -553,6 +553,9 @@ int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int n
  * al3d_tok_window_attention_f32: qkv [nwin*49][3C] (q | k | v, each [heads][32]) -> softmax(q scale k^T + B + mask) v,
  *   [nwin*49][C]; B = table[(yq-yk+6)*13 + (xq-xk+6)][head]; mask = -100 between tokens of different shifted-window
  *   regions, derived from the window's position in its win_rows x win_cols grid and `shift` (0 = none). */
+/* img [B][H][W][3] f32 -> patch rows [B*ceil(H/4)*ceil(W/4)][48], k = (ky*4 + kx)*3 + c, zeros beyond the image: the A
+ * matrix of the 4x4 / stride-4 patch embedding (mmdet PatchEmbed: Conv2d(3, 96, 4, 4)) as a token GEMM with K = 48. */
+int al3d_tok_patch_rows_f32(const float* img, int B, int H, int W, int out_pair, float* out, void* stream);
 int al3d_tok_layernorm_f32(const float* x, const int* rowmap, int64_t rows_out, int C, int G, int zero_out,
                            const float* gamma, const float* beta, float eps, int out_pair, float* out, void* stream);
 int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt_image, const float* scale, const float* bias,
