@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256, 2) void tok_linear_f16x3_kernel(TokGemmParams 
             for (int r = 0; r < 16; ++r) {
                 const int ml = (r & 3) + 8 * (r >> 2) + 4 * fh;
                 float v = acc[r] * sc + sh;
-                if (p.act) v = tk_gelu(v);
+                if (p.act == 1) v = tk_gelu(v);
+                else if (p.act == 2) v = v <= 0.f ? 0.f : v;         // NaN propagates, like torch.relu
                 scr[ml * SP + j * 32 + fr] = v;
             }
         }
@@ -456,7 +457,7 @@ extern "C" int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt
     const int q = out_pair ? 8 : 4;
     AL3D_REQUIRE(N % q == 0 && ldc % q == 0 && ldc >= N, "al3d_tok_linear_f16x3: N=%d, ldc=%d must be multiples of %d, ldc >= N", N, ldc, q);
     AL3D_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= N), "al3d_tok_linear_f16x3: ldr=%d must be a multiple of 4 and >= N", ldr);
-    AL3D_REQUIRE(act == 0 || act == 1, "al3d_tok_linear_f16x3: act = 0 (none) or 1 (GELU)");
+    AL3D_REQUIRE(act >= 0 && act <= 2, "al3d_tok_linear_f16x3: act = 0 (none), 1 (GELU) or 2 (ReLU)");
     AL3D_REQUIRE((((uintptr_t)a | (uintptr_t)wgt_image | (uintptr_t)out | (uintptr_t)residual) & 15) == 0,
                  "al3d_tok_linear_f16x3: a / wgt / out / residual must be 16-byte aligned");
     if (M == 0) return AL3D_OK;
@@ -708,5 +709,181 @@ extern "C" int al3d_tok_window_attention_f32(const float* qkv, const float* tabl
     const int64_t items = (int64_t)nwin * heads;
     hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("tok_window_attention_kernel");
+    return AL3D_OK;
+}
+
+// ------------------------------------------------------------------ multi-head attention, head dim 16, any key count
+// The TransFusion query decoder (bevfusion/mmdet3d/models/utils/transformer.py:71-112: nn.MultiheadAttention with 8
+// heads of 16 channels; 200 queries against themselves, then against the 180 x 180 = 32,400 BEV cells).
+// One wave per (sample, head, 32-query tile, key chunk): S^T = K (Q scale)^T per 32-key tile -- head dim 16 is exactly
+// one k-step of v_mfma_f32_32x32x16 -- an online softmax down the accumulator registers (running max / sum per query
+// = per lane), and O^T += V^T P^T with P taken from the accumulators as the B operand (rows of O^T = the 16 channels;
+// the upper half of the 32-row tile is idle).  Both operands split as in the window kernel (main + 2^-11 correction
+// accumulators).  Each wave writes (max, sum, O[16]) of its chunk; tok_mha16_combine_kernel merges the chunks.
+struct TokMhaParams {
+    const float* q;         // [B][Pq][ldq], this head's 16 channels at column head * 16
+    const float* k;         // [B][Pk][ldk]
+    const float* v;         // [B][Pk][ldv]
+    float* part;            // [B][heads][chunks][qtiles * 32][18]: running max, sum, O[16]
+    int B, heads, Pq, Pk, ldq, ldk, ldv;
+    int qtiles, chunks, keys_per_chunk;          // keys_per_chunk: a multiple of 32
+    float scale;
+};
+
+__global__ __launch_bounds__(64) void tok_mha16_kernel(TokMhaParams p)
+{
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    int id = blockIdx.x;
+    const int chunk = id % p.chunks; id /= p.chunks;
+    const int qt = id % p.qtiles; id /= p.qtiles;
+    const int head = id % p.heads;
+    const int b = id / p.heads;
+    const int query = qt * 32 + c;
+    f16x8 qh, ql;
+    {
+        float qv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (query < p.Pq) {
+            const float* qp = p.q + ((int64_t)b * p.Pq + query) * p.ldq + head * 16 + 8 * h;
+            const float4 a = *reinterpret_cast<const float4*>(qp), b4 = *reinterpret_cast<const float4*>(qp + 4);
+            qv[0] = a.x * p.scale; qv[1] = a.y * p.scale; qv[2] = a.z * p.scale; qv[3] = a.w * p.scale;
+            qv[4] = b4.x * p.scale; qv[5] = b4.y * p.scale; qv[6] = b4.z * p.scale; qv[7] = b4.w * p.scale;
+        }
+        tk_split8(qv, qh, ql);
+    }
+    const int key0 = chunk * p.keys_per_chunk;
+    const int key1 = key0 + p.keys_per_chunk < p.Pk ? key0 + p.keys_per_chunk : p.Pk;
+    const float* kb = p.k + (int64_t)b * p.Pk * p.ldk + head * 16;
+    const float* vb = p.v + (int64_t)b * p.Pk * p.ldv + head * 16;
+    float run_max = -INFINITY, run_sum = 0.f;
+    f32x16 om, oc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { om[r] = 0.f; oc[r] = 0.f; }
+    for (int kt = key0; kt < key1; kt += 32) {
+        // K tile: A operand, lane (key c, half h) holds K[key][8 h .. 8 h + 7]
+        f16x8 kh, kl;
+        {
+            float kv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (kt + c < key1) {
+                const float* kp = kb + (int64_t)(kt + c) * p.ldk + 8 * h;
+                const float4 a = *reinterpret_cast<const float4*>(kp), b4 = *reinterpret_cast<const float4*>(kp + 4);
+                kv[0] = a.x; kv[1] = a.y; kv[2] = a.z; kv[3] = a.w; kv[4] = b4.x; kv[5] = b4.y; kv[6] = b4.z; kv[7] = b4.w;
+            }
+            tk_split8(kv, kh, kl);
+        }
+        // V^T fragments of the tile's two k-steps (issued early: their latency hides behind the logits)
+        float vv[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = kt + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+                vv[s][e] = (c < 16 && key < key1) ? vb[(int64_t)key * p.ldv + c] : 0.f;
+            }
+        f32x16 sm, sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
+        sc = TK_MFMA(kl, qh, sc);
+        sc = TK_MFMA(kh, ql, sc);
+        sm = TK_MFMA(kh, qh, sm);
+        float mx = run_max;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = key < key1 ? sm[r] + sc[r] * 0.00048828125f : -INFINITY;
+            sm[r] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));              // every tile holds at least one real key: mx is finite
+        const float resc = __builtin_amdgcn_exp2f((run_max - mx) * 1.44269504088896340736f);     // 0 on the first tile
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = sm[r] - mx;
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(d, 1.44269502162933349609f, d * 1.92596299112661746e-8f));
+            sm[r] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 32);
+        run_sum = run_sum * resc + sum;
+        run_max = mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { om[r] *= resc; oc[r] *= resc; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 vh, vl, ph, pl;
+            tk_split8(vv[s], vh, vl);
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = sm[8 * s + e];
+            tk_split8(pv, ph, pl);
+            oc = TK_MFMA(vl, ph, oc);
+            oc = TK_MFMA(vh, pl, oc);
+            om = TK_MFMA(vh, ph, om);
+        }
+    }
+    // rows of O^T: d = (r & 3) + 8 (r >> 2) + 4 h; d < 16 <=> r < 8
+    float* o = p.part + ((((int64_t)b * p.heads + head) * p.chunks + chunk) * (p.qtiles * 32) + query) * 18;
+    if (h == 0) { o[0] = run_max; o[1] = run_sum; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[2 + (r & 3) + 8 * (r >> 2) + 4 * h] = om[r] + oc[r] * 0.00048828125f;
+}
+
+// out[b][query][head * 16 + d] = sum_c e^(m_c - M) O_c[d] / sum_c e^(m_c - M) l_c
+__global__ __launch_bounds__(256) void tok_mha16_combine_kernel(const float* __restrict__ part, int B, int heads, int chunks,
+                                                                int qrows, int Pq, float* __restrict__ out, int ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * heads * Pq * 16) return;
+    const int d = (int)(t & 15);
+    int64_t r = t >> 4;
+    const int query = (int)(r % Pq); r /= Pq;
+    const int head = (int)(r % heads);
+    const int b = (int)(r / heads);
+    const float* base = part + (((int64_t)b * heads + head) * chunks * qrows + query) * 18;
+    float M = -INFINITY;
+    for (int c = 0; c < chunks; ++c) M = fmaxf(M, base[(int64_t)c * qrows * 18]);
+    float num = 0.f, den = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        const float* q = base + (int64_t)c * qrows * 18;
+        const float w = expf(q[0] - M);
+        num += w * q[2 + d];
+        den += w * q[1];
+    }
+    out[((int64_t)b * Pq + query) * ldo + head * 16 + d] = num / den;
+}
+
+extern "C" int64_t al3d_tok_mha16_workspace_bytes(int B, int heads, int Pq, int Pk)
+{
+    if (B < 1 || heads < 1 || Pq < 1 || Pk < 1) return 0;
+    const int qtiles = (Pq + 31) / 32;
+    int chunks = (Pk + 1023) / 1024;
+    return al3d_align((int64_t)B * heads * chunks * qtiles * 32 * 18 * 4, 256);
+}
+
+extern "C" int al3d_tok_mha16_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int B, int heads,
+                                  int Pq, int Pk, float scale, float* out, int ldo, void* workspace, void* stream)
+{
+    AL3D_REQUIRE(q && k && v && out && workspace, "al3d_tok_mha16_f32: null pointer");
+    AL3D_REQUIRE(B >= 1 && heads >= 1 && Pq >= 1 && Pk >= 1, "al3d_tok_mha16_f32: bad shape");
+    AL3D_REQUIRE(ldq >= heads * 16 && ldk >= heads * 16 && ldv >= heads * 16 && ldo >= heads * 16 && ldq % 4 == 0 && ldk % 4 == 0,
+                 "al3d_tok_mha16_f32: row pitches must cover heads x 16 channels (q, k pitches multiples of 4)");
+    AL3D_REQUIRE((((uintptr_t)q | (uintptr_t)k) & 15) == 0, "al3d_tok_mha16_f32: q / k must be 16-byte aligned");
+    TokMhaParams p;
+    p.q = q; p.k = k; p.v = v; p.part = (float*)workspace;
+    p.B = B; p.heads = heads; p.Pq = Pq; p.Pk = Pk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+    p.qtiles = (Pq + 31) / 32;
+    p.chunks = (Pk + 1023) / 1024;
+    p.keys_per_chunk = (int)al3d_align(al3d_cdiv(Pk, p.chunks), 32);
+    p.chunks = (int)al3d_cdiv(Pk, p.keys_per_chunk);       // no empty chunk: every partial holds at least one key
+    p.scale = scale;
+    const int64_t waves = (int64_t)B * heads * p.qtiles * p.chunks;
+    AL3D_REQUIRE(waves < ((int64_t)1 << 31), "al3d_tok_mha16_f32: too many work items");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tok_mha16_kernel, dim3((unsigned)waves), dim3(64), 0, s, p);
+    AL3D_CHECK_LAUNCH("tok_mha16_kernel");
+    const int64_t n = (int64_t)B * heads * Pq * 16;
+    hipLaunchKernelGGL(tok_mha16_combine_kernel, dim3((unsigned)al3d_cdiv(n, 256)), dim3(256), 0, s, (const float*)workspace, B,
+                       heads, p.chunks, p.qtiles * 32, Pq, out, ldo);
+    AL3D_CHECK_LAUNCH("tok_mha16_combine_kernel");
     return AL3D_OK;
 }

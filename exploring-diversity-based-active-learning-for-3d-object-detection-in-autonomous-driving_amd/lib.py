@@ -150,6 +150,9 @@ SIGNATURES = {
     "al3d_tok_layernorm_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p, c_p, c_flt, c_int, c_p, c_p]),
     "al3d_tok_linear_f16x3": (c_int, [c_p, c_int, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p, c_int, c_p, c_p,
                                       c_int, c_int, c_p]),
+    "al3d_tok_mha16_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "al3d_tok_mha16_f32": (c_int, [c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_int, c_int, c_int, c_flt, c_p, c_int, c_p,
+                                   c_p]),
     "al3d_tok_window_attention_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_flt, c_int, c_p,
                                               c_p]),
 }

@@ -20,49 +20,125 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import token_ops as T
 from .bevfusion_camera import _ConvAffine
 from .registry import HEADS
+from .swin import _Packed
+
+
+def _bn_fold(bn):
+    """eval BatchNorm1d -> (scale, shift) with y = x * scale + shift."""
+    inv = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
+    scale = bn.weight.detach().double() * inv
+    shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    return scale.float(), shift.float()
 
 
 class PositionEmbeddingLearned(nn.Module):
-    """transformer.py:14-30."""
+    """transformer.py:14-30: Conv1d(2 -> F) + BN + ReLU + Conv1d(F -> F) over positions; here two token GEMMs over
+    position ROWS ``[M, 2]`` (the two coordinates zero-padded to the GEMM's 16-channel step)."""
 
     def __init__(self, input_channel, num_pos_feats=288):
         super().__init__()
         self.position_embedding_head = nn.Sequential(
             nn.Conv1d(input_channel, num_pos_feats, kernel_size=1), nn.BatchNorm1d(num_pos_feats), nn.ReLU(inplace=True),
             nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+        object.__setattr__(self, "_pk", _Packed())
 
-    def forward(self, xyz):
-        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+    def packed(self, device):
+        c1, bn, _, c2 = self.position_embedding_head
+
+        def build():
+            s, t = _bn_fold(bn)
+            return (T.PackedLinear(c1.weight, t + c1.bias.detach().float() * s, scale=s, pad_k=16),
+                    T.PackedLinear(c2.weight, c2.bias))
+        return self._pk.get(device, (c1, bn, c2), build)
+
+    def hidden(self, pos_rows):
+        """[M, 2] -> the ReLU'd hidden rows [M, F] (input of the second layer)."""
+        l1, _ = self.packed(pos_rows.device)
+        return T.linear(F.pad(pos_rows.float(), (0, 14)).contiguous(), l1, act="relu")
+
+    def forward(self, pos_rows, residual=None, hidden=None):
+        """-> [M, F] position embedding rows (+ ``residual`` rows, fused into the second GEMM's epilogue)."""
+        _, l2 = self.packed(pos_rows.device)
+        hid = self.hidden(pos_rows) if hidden is None else hidden
+        out = None if residual is None else torch.empty_like(residual)
+        return T.linear(hid, l2, residual=residual, out=out)
 
 
 class TransformerDecoderLayer(nn.Module):
-    """transformer.py:33-112 (``cross_only=False``); ``nn.MultiheadAttention`` is the module the reference copied
-    (same parameters: in_proj_weight / in_proj_bias / out_proj)."""
+    """transformer.py:33-112 (``cross_only=False``).  ``self_attn`` / ``multihead_attn`` are ``nn.MultiheadAttention``
+    modules only as PARAMETER containers (in_proj_weight / in_proj_bias / out_proj: the reference's names); the
+    computation runs on the token kernels: input projections and out_proj as token GEMMs (residual fused), the
+    attention core on ``al3d_tok_mha16_f32``, LayerNorm on ``al3d_tok_layernorm_f32``."""
 
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", self_posembed=None,
                  cross_posembed=None):
         super().__init__()
+        if d_model != 16 * nhead:
+            raise NotImplementedError("the attention kernel is built for 16-channel heads (TransFusion: 128 / 8)")
+        self.nhead = nhead
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
-        self.activation = {"relu": F.relu, "gelu": F.gelu}[activation]
+        self.activation = activation
         self.self_posembed, self.cross_posembed = self_posembed, cross_posembed
+        object.__setattr__(self, "_pk", _Packed())
+        object.__setattr__(self, "_kpe", _Packed())
 
-    def forward(self, query, key, query_pos, key_pos):
-        """query [B,C,Pq], key [B,C,Pk], query_pos [B,Pq,2], key_pos [B,Pk,2] -> [B,C,Pq] (eval: dropouts are identity)."""
-        qpe = self.self_posembed(query_pos).permute(2, 0, 1)
-        kpe = self.cross_posembed(key_pos).permute(2, 0, 1)
-        query, key = query.permute(2, 0, 1), key.permute(2, 0, 1)
-        q = k = v = query + qpe
-        query = self.norm1(query + self.self_attn(q, k, value=v)[0])
-        kk = key + kpe
-        query = self.norm2(query + self.multihead_attn(query=query + qpe, key=kk, value=kk)[0])
-        query = self.norm3(query + self.linear2(self.activation(self.linear1(query))))
-        return query.permute(1, 2, 0)
+    def packed(self, device):
+        sa, ca = self.self_attn, self.multihead_attn
+        C = self.linear1.in_features
+
+        def build():
+            return dict(
+                sa_in=T.PackedLinear(sa.in_proj_weight, sa.in_proj_bias), sa_out=T.PackedLinear(sa.out_proj.weight, sa.out_proj.bias),
+                ca_q=T.PackedLinear(ca.in_proj_weight[:C], ca.in_proj_bias[:C]),
+                ca_kv=T.PackedLinear(ca.in_proj_weight[C:], None),
+                ca_out=T.PackedLinear(ca.out_proj.weight, ca.out_proj.bias),
+                l1=T.PackedLinear(self.linear1.weight, self.linear1.bias), l2=T.PackedLinear(self.linear2.weight, self.linear2.bias))
+        return self._pk.get(device, (sa, sa.out_proj, ca, ca.out_proj, self.linear1, self.linear2), build)
+
+    def key_pos_projection(self, key_pos_rows):
+        """(cross_posembed(key_pos)) W_kv^T + b_kv, [HW, 2C]: depends on the parameters and the fixed BEV grid only, so it is
+        computed once and cached; per sample  kv = key W_kv^T + this  ==  (key + key_pos_embedding) W_kv^T + b_kv."""
+        ca = self.multihead_attn
+        C = self.linear1.in_features
+        mods = (ca,) + tuple(self.cross_posembed.position_embedding_head)
+
+        def build():
+            kpe = self.cross_posembed(key_pos_rows)
+            return T.linear(kpe, T.PackedLinear(ca.in_proj_weight[C:], ca.in_proj_bias[C:]))
+        return self._kpe.get((key_pos_rows.device, key_pos_rows.data_ptr(), key_pos_rows.shape[0]), mods, build)
+
+    def forward(self, query, key, query_pos, key_pos, B):
+        """query rows [B*Pq, C], key rows [B*Pk, C], query_pos rows [B*Pq, 2], key_pos rows [Pk, 2] (shared by the samples)
+        -> query rows [B*Pq, C] (eval: dropouts are identity)."""
+        w = self.packed(query.device)
+        C = query.shape[1]
+        Pq, Pk = query.shape[0] // B, key.shape[0] // B
+        scale = 16 ** -0.5
+        ln = lambda n, x: T.layernorm(x, n.weight, n.bias, n.eps)     # noqa: E731
+        qhid = self.self_posembed.hidden(query_pos)
+        # self attention: q = k = v = query + query_pos_embedding
+        qin = self.self_posembed(query_pos, residual=query, hidden=qhid)
+        qkv = T.linear(qin, w["sa_in"])
+        sa = T.mha16(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, Pq, Pq, self.nhead, scale)
+        query = ln(self.norm1, T.linear(sa, w["sa_out"], residual=query, out=torch.empty_like(query)))
+        # cross attention: query + its embedding against key + key embedding (keys and values)
+        qin = self.self_posembed(query_pos, residual=query, hidden=qhid)
+        qc = T.linear(qin, w["ca_q"])
+        kvb = self.key_pos_projection(key_pos)
+        kv = torch.empty((B * Pk, 2 * C), dtype=torch.float32, device=key.device)
+        for b in range(B):
+            T.linear(key[b * Pk:(b + 1) * Pk], w["ca_kv"], residual=kvb, out=kv[b * Pk:(b + 1) * Pk])
+        ca = T.mha16(qc, kv[:, :C], kv[:, C:], B, Pq, Pk, self.nhead, scale)
+        query = ln(self.norm2, T.linear(ca, w["ca_out"], residual=query, out=torch.empty_like(query)))
+        hid = T.linear(query, w["l1"], act=self.activation)
+        return ln(self.norm3, T.linear(hid, w["l2"], residual=query, out=torch.empty_like(query)))
 
 
 class _ConvModule1d(nn.Module):
@@ -71,17 +147,18 @@ class _ConvModule1d(nn.Module):
         self.conv = nn.Conv1d(cin, cout, 1, bias=False)
         self.bn = nn.BatchNorm1d(cout)
 
-    def forward(self, x):
-        return F.relu(self.bn(self.conv(x)))
-
 
 class FFN(nn.Module):
-    """transformer.py:496-575: one small Conv1d stack per regression target."""
+    """transformer.py:496-575: one small Conv1d stack per regression target (``num_conv`` = 2 in every TransFusion
+    config: ConvModule(in -> 64) + Conv1d(64 -> classes)).  Here: the first layers of all targets as ONE token GEMM
+    (N = 64 x targets, BN + ReLU in the epilogue), the second layers as one block-diagonal GEMM."""
 
     def __init__(self, in_channels, heads, head_conv=64, init_bias=-2.19):
         super().__init__()
-        self.heads = heads
+        self.heads, self.head_conv = heads, head_conv
         for head, (classes, num_conv) in heads.items():
+            if num_conv != 2:
+                raise NotImplementedError("prediction heads are built for num_conv = 2 (every TransFusion config)")
             layers, c_in = [], in_channels
             for _ in range(num_conv - 1):
                 layers.append(_ConvModule1d(c_in, head_conv))
@@ -89,9 +166,36 @@ class FFN(nn.Module):
             layers.append(nn.Conv1d(head_conv, classes, 1, bias=True))
             setattr(self, head, nn.Sequential(*layers))
         getattr(self, "heatmap")[-1].bias.data.fill_(init_bias)
+        object.__setattr__(self, "_pk", _Packed())
 
-    def forward(self, x):
-        return {head: getattr(self, head)(x) for head in self.heads}
+    def packed(self, device):
+        names = list(self.heads)
+        mods = tuple(m for h in names for m in (getattr(self, h)[0].conv, getattr(self, h)[0].bn, getattr(self, h)[1]))
+
+        def build():
+            hc = self.head_conv
+            w1 = torch.cat([getattr(self, h)[0].conv.weight.detach().float().reshape(hc, -1) for h in names])
+            folds = [_bn_fold(getattr(self, h)[0].bn) for h in names]
+            s1, t1 = torch.cat([f[0] for f in folds]), torch.cat([f[1] for f in folds])
+            total = sum(self.heads[h][0] for h in names)
+            w2 = torch.zeros(total, hc * len(names), device=w1.device)
+            b2, spans, o = [], {}, 0
+            for i, h in enumerate(names):
+                last = getattr(self, h)[1]
+                c = last.out_channels
+                w2[o:o + c, i * hc:(i + 1) * hc] = last.weight.detach().float().reshape(c, hc)
+                b2.append(last.bias.detach().float())
+                spans[h] = (o, o + c)
+                o += c
+            return (T.PackedLinear(w1, t1, scale=s1), T.PackedLinear(w2, torch.cat(b2), pad_n=(total + 3) // 4 * 4), spans)
+        return self._pk.get(device, mods, build)
+
+    def forward(self, x, B):
+        """x rows [B*P, C] -> dict of [B, classes, P] (the reference's layout)."""
+        l1, l2, spans = self.packed(x.device)
+        out = T.linear(T.linear(x, l1, act="relu"), l2)               # [B*P, sum(classes) padded]
+        out = out.view(B, x.shape[0] // B, -1)
+        return {h: out[:, :, a:b].permute(0, 2, 1).contiguous() for h, (a, b) in spans.items()}
 
 
 class _ConvModule2d(nn.Module):
@@ -164,6 +268,13 @@ class TransFusionHead(nn.Module):
                                             _ConvAffine(self.heatmap_head[1], None, False)])
         self.query_labels = None
 
+    def _bev_pos_on(self, device):
+        cached = getattr(self, "_bev_pos_dev", None)
+        if cached is None or cached.device != torch.device(device):
+            cached = self.bev_pos[0].to(device).contiguous()
+            object.__setattr__(self, "_bev_pos_dev", cached)
+        return cached
+
     @staticmethod
     def create_2D_grid(x_size, y_size):
         """transfusion.py:173-184."""
@@ -177,22 +288,24 @@ class TransFusionHead(nn.Module):
         B, H, W, _ = x.shape
         lidar_nhwc = self._convs[0](x)                                        # [B,H,W,hidden]
         dense_nhwc = self._convs[2](self._convs[1](lidar_nhwc))               # [B,H,W,num_classes]
-        lidar_feat_flatten = lidar_nhwc.reshape(B, H * W, -1).permute(0, 2, 1)   # [B,C,H*W] (a view: h-major like .view)
+        key_rows = lidar_nhwc.reshape(B * H * W, -1)                          # token rows, h-major like the reference's .view
         dense_heatmap = dense_nhwc.permute(0, 3, 1, 2)                        # [B,num_classes,H,W]
-        bev_pos = self.bev_pos.repeat(B, 1, 1).to(x.device)
+        bev_pos = self._bev_pos_on(x.device)                                  # [H*W, 2] rows, shared by the samples
         top_class, top_index, heatmap = self._proposals(dense_heatmap)
-        query_feat = lidar_feat_flatten.gather(index=top_index[:, None, :].expand(-1, lidar_feat_flatten.shape[1], -1), dim=-1)
+        P = self.num_proposals
+        flat_index = (top_index + torch.arange(B, device=x.device)[:, None] * (H * W)).reshape(-1)
         self.query_labels = top_class
-        one_hot = F.one_hot(top_class, num_classes=self.num_classes).permute(0, 2, 1)
-        query_feat = query_feat + self.class_encoding(one_hot.float())
-        query_pos = bev_pos.gather(index=top_index[:, None, :].permute(0, 2, 1).expand(-1, -1, bev_pos.shape[-1]), dim=1)
+        # class encoding of a one-hot vector = one column of the Conv1d weight (+ bias)
+        ce = self.class_encoding
+        query_feat = key_rows[flat_index] + ce.weight[:, :, 0].t()[top_class.reshape(-1)] + ce.bias
+        query_pos = bev_pos[top_index.reshape(-1)]                            # [B*P, 2]
         ret_dicts = []
         for i in range(self.num_decoder_layers):
-            query_feat = self.decoder[i](query_feat, lidar_feat_flatten, query_pos, bev_pos)
-            res = self.prediction_heads[i](query_feat)
-            res["center"] = res["center"] + query_pos.permute(0, 2, 1)
+            query_feat = self.decoder[i](query_feat.contiguous(), key_rows, query_pos.contiguous(), bev_pos, B)
+            res = self.prediction_heads[i](query_feat, B)
+            res["center"] = res["center"] + query_pos.view(B, P, 2).permute(0, 2, 1)
             ret_dicts.append(res)
-            query_pos = res["center"].detach().clone().permute(0, 2, 1)
+            query_pos = res["center"].detach().permute(0, 2, 1).reshape(B * P, 2)
         ret_dicts[0]["query_heatmap_score"] = heatmap.gather(index=top_index[:, None, :].expand(-1, self.num_classes, -1),
                                                              dim=-1)
         ret_dicts[0]["dense_heatmap"] = dense_heatmap

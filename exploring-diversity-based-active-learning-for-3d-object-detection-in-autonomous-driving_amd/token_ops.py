@@ -15,18 +15,28 @@ from .selector_ops import _dev, _ptr, _stream
 
 
 class PackedLinear:
-    """``nn.Linear`` weights in the token GEMM's format: LDS-DMA image of the (wh, wl) f16 planes, the 2^-s scale of
-    the split, the bias."""
+    """``nn.Linear`` / 1x1 ``Conv1d`` weights in the token GEMM's format: LDS-DMA image of the (wh, wl) f16 planes, the
+    2^-s scale of the split (times ``scale``, e.g. a folded BatchNorm), the bias / shift.  ``pad_k`` / ``pad_n``
+    zero-pad the input / output channels (K must be a multiple of 16, N of 4)."""
 
-    def __init__(self, weight, bias=None):
-        w = weight.detach().float().contiguous()
+    def __init__(self, weight, bias=None, scale=None, pad_k=None, pad_n=None):
+        w = weight.detach().float().reshape(weight.shape[0], -1)
+        n, k = w.shape
+        pad_k, pad_n = pad_k or k, pad_n or n
+        if pad_k != k or pad_n != n:
+            w = torch.nn.functional.pad(w, (0, pad_k - k, 0, pad_n - n))
+        w = w.contiguous()
         self.n, self.k = w.shape
         if self.k % 16:
-            raise lib.Al3dError(f"PackedLinear: in_features={self.k} must be a multiple of 16")
-        planes, scale = split_f16x3(w.view(self.n, 1, self.k))
+            raise lib.Al3dError(f"PackedLinear: in_features={self.k} must be a multiple of 16 (use pad_k)")
+        if scale is not None:
+            scale = torch.nn.functional.pad(scale.detach().float(), (0, pad_n - n)).to(w.device)
+        planes, sc = split_f16x3(w.view(self.n, 1, self.k), scale)
         self.image = pack_dma_f16x3(planes).data
-        self.scale = scale
-        self.bias = None if bias is None else bias.detach().float().contiguous()
+        self.scale = sc
+        self.bias = None
+        if bias is not None:
+            self.bias = torch.nn.functional.pad(bias.detach().float(), (0, pad_n - n)).to(w.device).contiguous()
 
 
 def patch_rows(img, pair=True):
@@ -76,7 +86,7 @@ def linear(a, packed, a_pair=False, act=None, residual=None, rowmap=None, out=No
     if residual is not None:
         residual = _dev(residual, torch.float32, "residual")
     lib.call("al3d_tok_linear_f16x3", _ptr(a), int(a_pair), _ptr(packed.image), _ptr(packed.scale), _ptr(packed.bias),
-             M, K, packed.n, {None: 0, "gelu": 1}[act], _ptr(residual), 0 if residual is None else residual.shape[-1],
+             M, K, packed.n, {None: 0, "gelu": 1, "relu": 2}[act], _ptr(residual), 0 if residual is None else residual.shape[-1],
              _ptr(rowmap), _ptr(out), out.shape[-1], int(out_pair), _stream())
     return out
 
@@ -90,6 +100,22 @@ def window_attention(qkv, table, heads, win_rows, win_cols, shift, scale, pair=T
     out = torch.empty((rows, C), dtype=torch.float32, device=qkv.device)
     lib.call("al3d_tok_window_attention_f32", _ptr(qkv), _ptr(_dev(table, torch.float32, "table")), nwin, C, heads,
              win_rows, win_cols, int(shift), float(scale), int(pair), _ptr(out), _stream())
+    return out
+
+
+def mha16(q, k, v, B, Pq, Pk, heads, scale):
+    """Attention core of ``nn.MultiheadAttention`` for 16-channel heads: q ``[B * Pq, >= heads * 16]``, k / v
+    ``[B * Pk, ...]`` (column slices of wider row matrices are fine: the row pitch is the tensor's stride) ->
+    ``[B * Pq, heads * 16]``."""
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise lib.Al3dError(f"mha16: {name} must be a device float32 row matrix (unit column stride)")
+    if q.shape[0] != B * Pq or k.shape[0] != B * Pk or v.shape[0] != B * Pk:
+        raise lib.Al3dError("mha16: row counts do not match B, Pq, Pk")
+    out = torch.empty((B * Pq, heads * 16), dtype=torch.float32, device=q.device)
+    ws = torch.empty(lib.load().al3d_tok_mha16_workspace_bytes(B, heads, Pq, Pk), dtype=torch.uint8, device=q.device)
+    lib.call("al3d_tok_mha16_f32", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), B, heads,
+             Pq, Pk, float(scale), _ptr(out), out.shape[1], _ptr(ws), _stream())
     return out
 
 

@@ -547,8 +547,8 @@ int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int n
  *   map padding), or with zero_out (G == 1) a zero OUTPUT row (the window padding follows norm1).  C % 8 == 0,
  *   G in {1, 4}, G*C <= 1536.
  * al3d_tok_linear_f16x3: out[rowmap[m]] = act((a[m] . W^T) * scale + bias) + residual[rowmap[m]] for m < M; W as
- *   al3d_split_f16x3 planes [2][N][1][K] packed by al3d_pack_f16x3_dma; scale = 2^-s of the split; act 0 none / 1 exact
- *   (erf) GELU; rowmap null = identity, -1 = row dropped; residual (f32 rows, pitch ldr) may alias out.  K % 16 == 0,
+ *   al3d_split_f16x3 planes [2][N][1][K] packed by al3d_pack_f16x3_dma; scale = 2^-s of the split (times a folded BatchNorm scale, if any); act 0 none / 1 exact
+ *   (erf) GELU / 2 ReLU; rowmap null = identity, -1 = row dropped; residual (f32 rows, pitch ldr) may alias out.  K % 16 == 0,
  *   N % 4 == 0 (8 for pair output).
  * al3d_tok_window_attention_f32: qkv [nwin*49][3C] (q | k | v, each [heads][32]) -> softmax(q scale k^T + B + mask) v,
  *   [nwin*49][C]; B = table[(yq-yk+6)*13 + (xq-xk+6)][head]; mask = -100 between tokens of different shifted-window
@@ -563,6 +563,14 @@ int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt_image, con
                           float* out, int ldc, int out_pair, void* stream);
 int al3d_tok_window_attention_f32(const float* qkv, const float* table, int nwin, int C, int heads, int win_rows,
                                   int win_cols, int shift, float scale, int out_pair, float* out, void* stream);
+/* Multi-head attention with 16-channel heads, any number of keys (the TransFusion query decoder,
+ * bevfusion/mmdet3d/models/utils/transformer.py:71-112 -> nn.MultiheadAttention's core: softmax(q scale k^T) v after
+ * the input projections, before the output projection).  q [B][Pq][ldq], k [B][Pk][ldk], v [B][Pk][ldv] f32 with head
+ * h in columns h*16 .. h*16+15; out [B][Pq][ldo].  Keys are split into chunks of <= 1,024 handled by independent
+ * waves with an online softmax; workspace >= al3d_tok_mha16_workspace_bytes(). */
+int64_t al3d_tok_mha16_workspace_bytes(int B, int heads, int Pq, int Pk);
+int al3d_tok_mha16_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int B, int heads, int Pq,
+                       int Pk, float scale, float* out, int ldo, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------- runtime
  * A HIP stream restricted to n_cus compute units starting at first_cu (hipExtStreamCreateWithCUMask); the

@@ -3,8 +3,8 @@ computation (the reference's ``forward_single`` / ``get_bboxes``: bevfusion/mmde
 :714-851; transformer.py:71-112; transfusion_bbox_coder.py:37-123) on the same seeded parameters, written with other
 primitives: torch convolutions, unfolded peak windows, attention as explicit matrix products.  mmcv / mmdet are not importable and no checkpoint exists offline: parity unpinned, like the other
 BEVFusion rows.  What differs between the two sides is the three 3x3 convolutions (this build's channels-last f16x3
-kernels against torch fp32) and the layout handling around them; everything downstream is the same torch ops, so the
-comparison is: dense heatmap to 1e-4 of its scale, the same 200 proposals (a swap is excused only between scores
+kernels against torch fp32), the layout handling around them, and the whole query decoder (token GEMMs, the 16-channel
+multi-head attention kernel, LayerNorm kernel -- against explicit torch matrix products); the comparison is: dense heatmap to 1e-4 of its scale, the same 200 proposals (a swap is excused only between scores
 closer than 1e-6), decoded boxes to 1e-3."""
 import pytest
 import torch
@@ -58,6 +58,25 @@ def _mha(q_in, k_in, v_in, attn, heads):
     return out @ attn.out_proj.weight.T + attn.out_proj.bias
 
 
+def _posembed(pe, xyz):
+    """transformer.py:14-30 on positions [B, P, 2] -> [B, F, P], in plain torch."""
+    c1, bn, _, c2 = pe.position_embedding_head
+    x = F.conv1d(xyz.transpose(1, 2).contiguous(), c1.weight, c1.bias)
+    x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+    return F.conv1d(x, c2.weight, c2.bias)
+
+
+def _prediction_heads(ffn, x):
+    """transformer.py:496-575 on x [B, C, P], in plain torch."""
+    out = {}
+    for name in ffn.heads:
+        cm, last = getattr(ffn, name)
+        y = F.relu(F.batch_norm(F.conv1d(x, cm.conv.weight), cm.bn.running_mean, cm.bn.running_var, cm.bn.weight, cm.bn.bias,
+                                False, 0.0, cm.bn.eps))
+        out[name] = F.conv1d(y, last.weight, last.bias)
+    return out
+
+
 def _reference_forward(h, inputs):
     """An independent NCHW evaluation of the head's forward pass (the computation of transfusion.py:215-333 and
     transformer.py:71-112), written with other primitives than the module under test: torch convolutions, peaks through
@@ -85,8 +104,8 @@ def _reference_forward(h, inputs):
     assert torch.equal(cells[:, 0], (torch.arange(H * W, device=inputs.device) // W).float() + 0.5)
     qpos = torch.stack([cells[top_cell[b]] for b in range(bs)])            # [B, P, 2]
     dec = h.decoder[0]
-    qpe = dec.self_posembed(qpos).permute(2, 0, 1)
-    kpe = dec.cross_posembed(cells[None].expand(bs, -1, -1)).permute(2, 0, 1)
+    qpe = _posembed(dec.self_posembed, qpos).permute(2, 0, 1)
+    kpe = _posembed(dec.cross_posembed, cells[None].expand(bs, -1, -1)).permute(2, 0, 1)
     q, k = query.permute(2, 0, 1), flat.permute(2, 0, 1)
     q = F.layer_norm(q + _mha(q + qpe, q + qpe, q + qpe, dec.self_attn, h.num_heads), (q.shape[-1],), dec.norm1.weight,
                      dec.norm1.bias, dec.norm1.eps)
@@ -94,7 +113,7 @@ def _reference_forward(h, inputs):
                      dec.norm2.bias, dec.norm2.eps)
     ff = F.linear(F.relu(F.linear(q, dec.linear1.weight, dec.linear1.bias)), dec.linear2.weight, dec.linear2.bias)
     q = F.layer_norm(q + ff, (q.shape[-1],), dec.norm3.weight, dec.norm3.bias, dec.norm3.eps)
-    res = h.prediction_heads[0](q.permute(1, 2, 0))
+    res = _prediction_heads(h.prediction_heads[0], q.permute(1, 2, 0))
     res["center"] = res["center"] + qpos.permute(0, 2, 1)
     res["query_heatmap_score"] = torch.stack([masked[b][:, top_cell[b]] for b in range(bs)])
     res["dense_heatmap"] = dense
@@ -160,3 +179,25 @@ def test_transfusion_circle_nms_variant_runs_and_filters():
     dets = np.array([[0.0, 0.0, 0.9], [0.1, 0.0, 0.8], [3.0, 0.0, 0.7]], np.float32)
     assert circle_nms(dets, 0.175) == [0, 2]
     assert circle_nms(dets, 0.005) == [0, 1, 2]
+
+
+@pytest.mark.parametrize("B,Pq,Pk", [(2, 200, 200), (1, 200, 32400), (2, 37, 1500)])
+def test_mha16_kernel_matches_float64(B, Pq, Pk):
+    """``al3d_tok_mha16_f32`` (online softmax over key chunks, matrix-core products with both operands split) against the
+    attention core in float64, bounded by torch's own fp32 evaluation; q / k / v as column slices of wider matrices."""
+    from al3d import token_ops as T
+    heads, C = 8, 128
+    g = torch.Generator().manual_seed(Pq + Pk)
+    qm = (torch.randn(B * Pq, 3 * C, generator=g) * 1.3).to(DEV)
+    km = (torch.randn(B * Pk, 2 * C, generator=g) * 1.3).to(DEV)
+    q, k, v = qm[:, C:2 * C], km[:, :C], km[:, C:]
+
+    def core(dt):
+        def hf(x, L):
+            return x.to(dt).reshape(B, L, heads, 16).permute(0, 2, 1, 3)
+        w = torch.softmax((hf(q, Pq) * 0.25) @ hf(k, Pk).transpose(-1, -2), dim=-1)
+        return (w @ hf(v, Pk)).permute(0, 2, 1, 3).reshape(B * Pq, C)
+    ref, ref32 = core(torch.float64), core(torch.float32)
+    got = T.mha16(q, k, v, B, Pq, Pk, heads, 0.25)
+    e, e32 = float((got.double() - ref).abs().max()), float((ref32.double() - ref).abs().max())
+    assert e <= 3.0 * e32 + 1e-6 and e <= 1e-5, (e, e32)
