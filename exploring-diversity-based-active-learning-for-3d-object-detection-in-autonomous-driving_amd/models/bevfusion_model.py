@@ -80,6 +80,7 @@ def transfusion_head_for(grid=1440, in_channels=512):
     return TransFusionHead(
         num_proposals=200, auxiliary=True, in_channels=in_channels, hidden_channel=128, num_classes=10, num_decoder_layers=1,
         num_heads=8, nms_kernel_size=3, ffn_channel=256, dropout=0.1, bn_momentum=0.1, activation="relu",
+        transpose_input=True,          # the decoder map here is [H = y, W = x]; the head works on the reference's [x, y]
         common_heads=dict(center=[2, 2], height=[1, 2], dim=[3, 2], rot=[2, 2], vel=[2, 2]),
         test_cfg=dict(dataset="nuScenes", grid_size=[grid, grid, 1], out_size_factor=8, voxel_size=[0.075, 0.075],
                       pc_range=[-54.0, -54.0], nms_type=None),

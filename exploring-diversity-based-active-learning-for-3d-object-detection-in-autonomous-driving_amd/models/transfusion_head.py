@@ -235,8 +235,13 @@ class TransFusionHead(nn.Module):
 
     def __init__(self, num_proposals=128, auxiliary=True, in_channels=128 * 3, hidden_channel=128, num_classes=4,
                  num_decoder_layers=3, num_heads=8, nms_kernel_size=1, ffn_channel=256, dropout=0.1, bn_momentum=0.1,
-                 activation="relu", common_heads=None, num_heatmap_convs=2, test_cfg=None, bbox_coder=None, **_unused):
+                 activation="relu", common_heads=None, num_heatmap_convs=2, test_cfg=None, bbox_coder=None,
+                 transpose_input=False, **_unused):
         super().__init__()
+        # The reference's BEV maps are [x, y] (rows = x); this build's detector maps are [H = y, W = x].  With
+        # ``transpose_input`` the head transposes the map it is handed, so that its 3x3 kernels, the BEV position grid
+        # and the decoded (x, y) keep the reference's meaning when it sits behind this build's necks.
+        self.transpose_input = bool(transpose_input)
         self.num_classes, self.num_proposals, self.auxiliary = num_classes, num_proposals, auxiliary
         self.in_channels, self.num_heads, self.num_decoder_layers = in_channels, num_heads, num_decoder_layers
         self.nms_kernel_size, self.test_cfg, self.bbox_coder = nms_kernel_size, dict(test_cfg or {}), dict(bbox_coder or {})
@@ -282,9 +287,11 @@ class TransFusionHead(nn.Module):
         coord_base = torch.cat([(bx + 0.5)[None], (by + 0.5)[None]], dim=0)[None]
         return coord_base.view(1, 2, -1).permute(0, 2, 1)
 
-    def forward(self, x):
+    def forward(self, x, finetune=False, **_unused):
         if self.training:
             raise RuntimeError("al3d TransFusionHead implements the eval() path only")
+        if self.transpose_input:
+            x = x.permute(0, 2, 1, 3).contiguous()
         B, H, W, _ = x.shape
         lidar_nhwc = self._convs[0](x)                                        # [B,H,W,hidden]
         dense_nhwc = self._convs[2](self._convs[1](lidar_nhwc))               # [B,H,W,num_classes]
@@ -341,6 +348,16 @@ class TransFusionHead(nn.Module):
         masked = (score * peak).reshape(B, C, H * W)
         order = masked.reshape(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]
         return order // (H * W), order % (H * W), masked
+
+    def predict(self, example, preds_dicts, test_cfg=None, **_unused):
+        """The det3d head contract (``bbox_head.predict(example, preds, test_cfg)``, voxelnet.py:73-81) over
+        ``get_bboxes`` (fusion_models/bevfusion.py:287-301 -> transfusion.py:714-851): one dict per sample with
+        ``box3d_lidar`` [K, 9], ``scores``, ``label_preds``, ``metadata`` -- what the uncertainty selectors read
+        (det3d/selectors/entropy_selector.py:50-86: ``output['scores']``)."""
+        rets = self.get_bboxes(preds_dicts)
+        metas = example.get("metadata", None) or [None] * len(rets)
+        return [dict(box3d_lidar=r["bboxes"], scores=r["scores"], label_preds=r["labels"], metadata=m)
+                for r, m in zip(rets, metas)]
 
     # ---------------------------------------------------------------- decode
     def _decode(self, heatmap, rot, dim, center, height, vel):

@@ -122,3 +122,62 @@ def test_full_size_sweep_and_selection(tmp_path):
     ex = next(iter(loader))
     assert int(ex["num_voxels"][0]) > 60000
     assert list(ex["shape"][0]) == [1440, 1440, 40]
+
+
+@pytest.mark.gpu
+def test_entropy_selector_end_to_end_on_the_lidar_detector(tmp_path):
+    """BASELINE configs[3] with its detection half: voxelnet_0p075 encoder -> SECOND/SECONDFPN -> TransFusionHead behind
+    the det3d contract (``detector(example, return_loss=False, estimate=True)`` -> per-frame dicts with ``scores``), swept
+    at full size under the EntropySelector (entropy_selector.py:50-86): the per-frame entropies equal the formula on the
+    detector's own scores, a frame without detections gives NaN (the reference's mean over an empty tensor), and the
+    selector ranks by them under the cost budget.  Seeded weights, synthetic frames (parity unpinned)."""
+    import json
+    import pickle
+    import random
+    from al3d import sweep as S, synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames
+    from al3d.models import build_detector
+    from al3d.selectors import build_selector
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(ROOT, "examples", "active", "bevfusion_lidar_entropy.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    n = 6
+    pool = PoolFrames.from_synthetic(n, DEV, num_base=3, seed=11)
+    loader = DeviceSweepLoader(pool, cfg.voxel_generator, None, 2, device=DEV)
+    # the detector contract, one batch
+    with torch.no_grad():
+        out, middle = model(next(iter(loader)), return_loss=False, estimate=True)
+    assert len(out) == 2 and set(out[0]) >= {"box3d_lidar", "scores", "label_preds", "metadata"}
+    assert out[0]["box3d_lidar"].shape[1] == 9 and 0 < len(out[0]["scores"]) <= 200
+    assert tuple(middle[-1].shape) == (2, 512, 180, 180)
+    emb, ent = S.sweep_embeddings(model, loader, DEV, n, with_entropy=True)
+    assert emb.shape == (n, 512) and ent.shape == (n,) and bool(torch.isfinite(ent).all())
+    with torch.no_grad():
+        ref = []
+        for ex in loader:
+            for o in model(ex, return_loss=False, estimate=True)[0]:
+                s = o["scores"].double()
+                ref.append(float((-s * s.log() - (1 - s) * (1 - s).log()).mean()))
+    np.testing.assert_allclose(ent.cpu().numpy(), np.asarray(ref), rtol=5e-6)
+    # no detection survives the score filter -> every frame's entropy is NaN (mean of an empty tensor)
+    model.bbox_head.bbox_coder["score_threshold"] = 2.0
+    _, ent_nan = S.sweep_embeddings(model, loader, DEV, n, with_entropy=True)
+    assert bool(torch.isnan(ent_nan).all())
+    model.bbox_head.bbox_coder["score_threshold"] = 0.0
+    # the selector on top (tools/active_select.py:152-163 call sequence)
+    infos, _ = synthetic.make_pool(1, seed=0)
+    infos = infos[:n]
+    ip, bp = str(tmp_path / "infos.pkl"), str(tmp_path / "buffer.json")
+    pickle.dump(infos, open(ip, "wb"))
+    json.dump({"0": []}, open(bp, "w"))
+    loader.sampler = list(range(n))
+    random.seed(3407)
+    sel = build_selector(dict(type="EntropySelector", budget=3, buffer_file=bp, infos_origin=ip, detector=model,
+                              dataloader=loader, pred=True, buffer_path=str(tmp_path / "entropy.pt")))
+    sel.select_samples(local_rank=0)
+    picked = sel.get_selected_samples()[sel.current_budget]
+    order = np.argsort(-ent.cpu().numpy(), kind="stable").tolist()
+    assert len(picked) >= 1 and picked == order[:len(picked)]
+    assert torch.equal(torch.load(str(tmp_path / "entropy.pt"), weights_only=True), ent.cpu())

@@ -116,9 +116,10 @@ def main():
         n = len(infos)
         per = (n + world - 1) // world
         mine = list(range(rank * per, min(n, (rank + 1) * per)))
-        # embedding-only models (bbox_head=None, e.g. the BEVFusion lidar branch) need no anchors
-        anchors = None if cfg.model.get("bbox_head") is None else \
-            generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+        # embedding-only models (bbox_head=None, e.g. the BEVFusion lidar branch) and anchor-free heads need no anchors
+        head_cfg = cfg.model.get("bbox_head")
+        anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128]) \
+            if head_cfg is not None and head_cfg.get("type") == "MultiGroupHead" else None      # TransFusionHead is anchor-free
         if args.synthetic_scenes:
             pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
             loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
