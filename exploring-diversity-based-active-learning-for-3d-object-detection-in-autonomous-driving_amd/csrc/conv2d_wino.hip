@@ -1,0 +1,337 @@
+// 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) in f16x3 arithmetic (conv2d_f16x3.hip): 16 multiplies per
+// 2 x 2 output tile and (input, output) channel pair instead of 36, i.e. 2.25 x fewer matrix-core products on the
+// eleven stride-1 3x3 layers of the SECOND neck (det3d/models/necks/rpn.py:66-113 -- 58 of its 67.6 GFLOP per frame).
+//
+//   V = B^T d B   (4 x 4 input patch d, stride 2; entries are +-sums of four pixels: fp32 adds)
+//   U = G g G^T   (computed once per layer in float64 on the host, rounded to fp32, then split like any f16x3 weight)
+//   M_p = sum_cin V_p U_p  for the 16 positions p of the 4 x 4 transformed patch  (the matrix-core part)
+//   Y = A^T M A   (2 x 2 outputs; fp32 adds), then BN scale / shift / ReLU
+//
+// Workgroup = 256 threads, output tile 16 x 16 pixels (64 Winograd tiles) x 64 output channels, input channels in
+// chunks of 16.  Per chunk the raw fp32 halo (18 x 18 pixels x 16 channels) arrives in LDS by DMA (ring of three stages,
+// one barrier per chunk).  Wave w owns the four positions of transformed ROW w, and every lane computes its own A
+// fragments in registers: lane (tile, k half) reads the two patch rows that row w combines (8 pixels x 8 channels), forms
+// t = d[r1] +- d[r2], the four column combinations, and splits them (xh, xl' = residual x 2^11) -- no transformed image
+// in LDS, no barrier between transform and products.  2 x 2 MFMA tiles of 32 x 32 per position, B fragments streamed
+// from L2 in fragment order (al3d_pack_f16x3_wino), three products per MAC into one fp32 accumulator (xl' wd, xh wl,
+// xh wh).  256 accumulator registers per lane: one workgroup per CU.
+// The output transform runs along the row inside a wave's registers and across the four waves through LDS.
+//
+// Numerics: measured error against float64 stays at the fp32-input kernel's level (tests/test_dense_gpu.py); the
+// kernel is NOT bit-identical to the direct kernels (another summation tree).  gfx950 only.
+#include "al3d_common.h"
+#include "sp_rows.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define WN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define WN_T 16                         // output tile edge
+#define WN_HW (WN_T + 2)                // halo edge
+#define WN_HP (WN_HW * WN_HW)           // 324 halo pixels
+#define WN_STAGE 24576                  // bytes per halo stage: 24 DMA instructions of 16 pixels x 64 B (324 pixels used)
+#define WN_NS 3
+#define WN_XP 36                        // floats per (row a, j, tile) line of the output exchange: 32 channels + pad
+
+typedef float wn_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void wn_lds_void;
+typedef const __attribute__((address_space(1))) void wn_gbl_void;
+
+struct WinoParams {
+    const float* in;        // [B, H, W, Cin] f32
+    const _Float16* wgt;    // [2 planes][Cout/32][Cin/16][16 positions][64 lanes][8] f16 (al3d_pack_f16x3_wino)
+    const float* scale;     // BN scale * 2^-s
+    const float* shift;
+    float* out;             // [B, H, W, ldc]
+    int B, H, W, Cin, Cout, ldc, coff, relu;
+    int tiles_x, tiles_y, ntiles, nblocks;
+};
+
+__device__ __attribute__((aligned(64))) float g_wn_zero[16];
+
+__device__ __forceinline__ void wn_split(float x, _Float16& h, _Float16& l)
+{
+    h = (_Float16)x;
+    l = (_Float16)__builtin_fmaf((float)h, -2048.0f, x * 2048.0f);
+}
+
+// same XCD-aware (pixel tile, channel block) order as conv2d_f16x3.hip
+__device__ __forceinline__ bool wn_tile_of_block(const WinoParams& p, int& tile, int& nblk)
+{
+    const int id = blockIdx.x, span = 8 * p.nblocks;
+    const int grp = id / span, rem = id - grp * span;
+    nblk = rem >> 3;
+    tile = grp * 8 + (rem & 7);
+    return tile < p.ntiles;
+}
+
+// The halo's 16-byte chunk q of pixel (row, col) sits at position q ^ ((col >> 2) & 3) of the pixel's 64 bytes (applied
+// on the source side of the DMA): the eight tiles of a tile row then read eight different bank groups.
+__device__ __forceinline__ int wn_swz(int col) { return (col >> 2) & 3; }
+
+template <int IO>
+__global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_NS * WN_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile, nblk;
+    if (!wn_tile_of_block(p, tile, nblk)) return;
+    const int tx_ = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty_ = tile % p.tiles_y; tile /= p.tiles_y;
+    const int b = tile;
+    const int n0 = nblk * 64;
+    const int y0 = ty_ * WN_T - 1, x0 = tx_ * WN_T - 1;
+    const int nchunks = p.Cin >> 4;
+    const unsigned smem_base = (unsigned)(size_t)(wn_lds_void*)smem;
+
+    // ---- halo by LDS-DMA: instruction k of wave w covers halo pixels 16 (6 w + k) .. + 15; lane (px = l >> 2, pos = l & 3)
+    // fetches chunk pos ^ swz(col).  Addresses depend on the chunk only through a constant stride.
+    const char* hsrc[6];
+    unsigned hinc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int hp = 16 * (6 * wave + k) + (lane >> 2);
+        const int row = hp / WN_HW, col = hp - row * WN_HW;
+        const int iy = y0 + row, ix = x0 + col;
+        const int q = (lane & 3) ^ wn_swz(col);
+        const bool ok = hp < WN_HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        hsrc[k] = reinterpret_cast<const char*>(ok ? p.in + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + 4 * q : g_wn_zero + 4 * q);
+        hinc[k] = ok ? 64u : 0u;
+    }
+    auto issue_halo = [&](int chunk) {
+        const int cc = chunk < nchunks ? chunk : nchunks - 1;          // past the end: re-fetch the last chunk (6 DMAs, always)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + (chunk % WN_NS) * WN_STAGE + wave * 6144);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            __builtin_amdgcn_global_load_lds((wn_gbl_void*)(hsrc[k] + (size_t)cc * hinc[k]), (wn_lds_void*)(size_t)(dst + k * 1024), 16, 0, 0);
+    };
+
+    // ---- this wave's weight stream: positions 4 w .. 4 w + 3 (transformed row a = w), both 32-channel tiles of the block
+    const int NT = p.Cout >> 5;
+    const _Float16* bsrc[2][2];                       // [plane][n tile]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bsrc[pl][j] = p.wgt + ((((int64_t)pl * NT + (n0 >> 5) + j) * nchunks) * 16 + wave * 4) * 512 + lane * 8;
+    f16x8 fb[4][2][2];                                // [position in the row][plane][n tile]
+    auto load_b = [&](int chunk, int c) {
+        const int cc = chunk < nchunks ? chunk : nchunks - 1;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fb[c][pl][j] = *reinterpret_cast<const f16x8*>(bsrc[pl][j] + ((int64_t)cc * 16 + c) * 512);
+    };
+
+    // ---- this lane's patch rows.  Transformed row a = wave:  t = d[r1] + sg d[r2]  with (r1, r2, sg) =
+    // (0,2,-), (1,2,+), (2,1,-), (1,3,-);  then V[a][c] = t0 - t2, t1 + t2, t2 - t1, t1 - t3.
+    const int r1 = wave == 0 ? 0 : wave == 2 ? 2 : 1, r2 = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
+    const float sg = wave == 1 ? 1.0f : -1.0f;
+    unsigned aoff[2][2][4][2];                        // [m tile][row r1 / r2][pixel c][16-byte half]: byte offsets in a stage
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int tl = 32 * m + fr, ty = tl >> 3, tx = tl & 7;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int row = 2 * ty + (rr == 0 ? r1 : r2), col = 2 * tx + c;
+                const int hp = row * WN_HW + col;
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    aoff[m][rr][c][e] = (unsigned)(hp * 64 + (((2 * fh + e) ^ wn_swz(col)) << 4));
+            }
+    }
+
+    f32x16 acc[4][2][2];                              // [position in the row][m tile][n tile]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+
+    issue_halo(0);
+    issue_halo(1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) load_b(0, c);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        // in issue order behind halo(chunk): at most this wave's 16 weight loads of chunk - 1 (long consumed), halo(chunk + 1)
+        // (6) and the 16 weight loads of this chunk -> "all but the youngest 22" covers halo(chunk)
+        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // everyone's share landed; every wave is past chunk - 1's LDS reads
+        issue_halo(chunk + 2);                         // -> the stage chunk - 1 used
+        const unsigned sb = smem_base + (chunk % WN_NS) * WN_STAGE;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            wn_f32x4 d[2][4][2];
+            asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
+                         "ds_read_b128 %4, %20\n\tds_read_b128 %5, %21\n\tds_read_b128 %6, %22\n\tds_read_b128 %7, %23\n\t"
+                         "ds_read_b128 %8, %24\n\tds_read_b128 %9, %25\n\tds_read_b128 %10, %26\n\tds_read_b128 %11, %27\n\t"
+                         "ds_read_b128 %12, %28\n\tds_read_b128 %13, %29\n\tds_read_b128 %14, %30\n\tds_read_b128 %15, %31\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(d[0][0][0]), "=&v"(d[0][0][1]), "=&v"(d[0][1][0]), "=&v"(d[0][1][1]), "=&v"(d[0][2][0]), "=&v"(d[0][2][1]),
+                           "=&v"(d[0][3][0]), "=&v"(d[0][3][1]), "=&v"(d[1][0][0]), "=&v"(d[1][0][1]), "=&v"(d[1][1][0]), "=&v"(d[1][1][1]),
+                           "=&v"(d[1][2][0]), "=&v"(d[1][2][1]), "=&v"(d[1][3][0]), "=&v"(d[1][3][1])
+                         : "v"(sb + aoff[m][0][0][0]), "v"(sb + aoff[m][0][0][1]), "v"(sb + aoff[m][0][1][0]), "v"(sb + aoff[m][0][1][1]),
+                           "v"(sb + aoff[m][0][2][0]), "v"(sb + aoff[m][0][2][1]), "v"(sb + aoff[m][0][3][0]), "v"(sb + aoff[m][0][3][1]),
+                           "v"(sb + aoff[m][1][0][0]), "v"(sb + aoff[m][1][0][1]), "v"(sb + aoff[m][1][1][0]), "v"(sb + aoff[m][1][1][1]),
+                           "v"(sb + aoff[m][1][2][0]), "v"(sb + aoff[m][1][2][1]), "v"(sb + aoff[m][1][3][0]), "v"(sb + aoff[m][1][3][1])
+                         : "memory");
+            float t[4][8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[c][e] = __builtin_fmaf(sg, d[1][c][e >> 2][e & 3], d[0][c][e >> 2][e & 3]);
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v0 = t[0][e] - t[2][e], v1 = t[1][e] + t[2][e], v2 = t[2][e] - t[1][e], v3 = t[1][e] - t[3][e];
+                _Float16 hh, ll;
+                wn_split(v0, hh, ll); ah[0][e] = hh; al[0][e] = ll;
+                wn_split(v1, hh, ll); ah[1][e] = hh; al[1][e] = ll;
+                wn_split(v2, hh, ll); ah[2][e] = hh; al[2][e] = ll;
+                wn_split(v3, hh, ll); ah[3][e] = hh; al[3][e] = ll;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f16x8 wd[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wd[j] = fb[c][0][j] * (_Float16)0.00048828125f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(al[c], wd[j], acc[c][m][j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][1][j], acc[c][m][j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][0][j], acc[c][m][j]);
+                if (m == 1) load_b(chunk + 1, c);      // position c's weights of this chunk are through: fetch the next chunk's
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's dummy requests must not outlive the workgroup's LDS
+
+    // ---- output transform.  Wave w holds row a = w of M (positions (w, 0..3)):  P_w[j] = sum_c M[w][c] A^T[j][c]
+    // in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), then Y[i][j] = sum_a A^T[i][a] P_a[j] across the waves through LDS,
+    // one 32-channel half at a time: X[a][j][tile][32 + pad] floats = 72 KB in the halo ring's storage.
+    float* X = reinterpret_cast<float*>(smem);
+    static_assert(4 * 2 * 64 * WN_XP * 4 <= WN_NS * WN_STAGE, "exchange must fit the halo ring");
+#pragma unroll
+    for (int j_n = 0; j_n < 2; ++j_n) {
+        __syncthreads();                               // the ring (or the previous half's exchange) is no longer read
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tl = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float m0 = acc[0][i][j_n][r], m1 = acc[1][i][j_n][r], m2 = acc[2][i][j_n][r], m3 = acc[3][i][j_n][r];
+                X[((wave * 2 + 0) * 64 + tl) * WN_XP + fr] = (m0 + m1) + m2;
+                X[((wave * 2 + 1) * 64 + tl) * WN_XP + fr] = (m1 - m2) - m3;
+            }
+        __syncthreads();
+        // 256 output pixels x 32 channels of this half: a lane takes 8 consecutive channels of a pixel
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int item = tid + 256 * pass;         // 1,024 items = 256 pixels x 4 channel groups
+            const int g = item & 3, px = item >> 2;
+            const int oy = px >> 4, ox = px & 15;
+            const int tl = (oy >> 1) * 8 + (ox >> 1), i = oy & 1, j = ox & 1;
+            const int y = ty_ * WN_T + oy, x = tx_ * WN_T + ox;
+            const int n = n0 + 32 * j_n + 8 * g;
+            if (y >= p.H || x >= p.W || n >= p.Cout) continue;
+            float v[8];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const float* xp = X + ((0 * 2 + j) * 64 + tl) * WN_XP + 8 * g + 4 * hlf;
+                const float4 p0 = *reinterpret_cast<const float4*>(xp);
+                const float4 p1 = *reinterpret_cast<const float4*>(xp + 2 * 64 * WN_XP);
+                const float4 p2 = *reinterpret_cast<const float4*>(xp + 4 * 64 * WN_XP);
+                const float4 p3 = *reinterpret_cast<const float4*>(xp + 6 * 64 * WN_XP);
+                float4 yv;
+                if (i == 0) yv = make_float4((p0.x + p1.x) + p2.x, (p0.y + p1.y) + p2.y, (p0.z + p1.z) + p2.z, (p0.w + p1.w) + p2.w);
+                else yv = make_float4((p1.x - p2.x) - p3.x, (p1.y - p2.y) - p3.y, (p1.z - p2.z) - p3.z, (p1.w - p2.w) - p3.w);
+                v[4 * hlf + 0] = yv.x; v[4 * hlf + 1] = yv.y; v[4 * hlf + 2] = yv.z; v[4 * hlf + 3] = yv.w;
+            }
+            const float4 s0 = *reinterpret_cast<const float4*>(p.scale + n), s1 = *reinterpret_cast<const float4*>(p.scale + n + 4);
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            float sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.shift) {
+                const float4 t0 = *reinterpret_cast<const float4*>(p.shift + n), t1 = *reinterpret_cast<const float4*>(p.shift + n + 4);
+                sh[0] = t0.x; sh[1] = t0.y; sh[2] = t0.z; sh[3] = t0.w; sh[4] = t1.x; sh[5] = t1.y; sh[6] = t1.z; sh[7] = t1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = v[e] * sc[e] + sh[e];
+                if (p.relu) v[e] = v[e] <= 0.f ? 0.f : v[e];           // NaN propagates, like torch.relu
+            }
+            float* o = p.out + (((int64_t)b * p.H + y) * p.W + x) * p.ldc + p.coff + n;
+            if constexpr ((IO & SP_IO_OUT_PAIR) != 0) {
+                uint4 hi, lo;
+                sp_split8(v, hi, lo);
+                *reinterpret_cast<uint4*>(o) = hi;
+                *reinterpret_cast<uint4*>(o + 4) = lo;
+            } else {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    }
+}
+
+// planes [2][Cout][16][Cin] f16 (al3d_split_f16x3 of U = G g G^T, position p = a * 4 + c) ->
+// [2][Cout/32][Cin/16][16][64 lanes][8]: lane (r, h) of fragment (n tile, chunk, position) holds U[32 nt + r][16 chunk + 8 h + j]
+__global__ void pack_wino_kernel(const _Float16* __restrict__ planes, int Cout, int Cin, _Float16* __restrict__ out, int64_t count)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= count) return;
+    const int nch = Cin >> 4;
+    int64_t r = o;
+    const int j = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int pos = r % 16; r /= 16;
+    const int chunk = r % nch; r /= nch;
+    const int nt = r % (Cout >> 5); r /= (Cout >> 5);
+    const int pl = (int)r;
+    const int n = nt * 32 + (lane & 31), cin = chunk * 16 + 8 * (lane >> 5) + j;
+    out[o] = planes[(((int64_t)pl * Cout + n) * 16 + pos) * Cin + cin];
+}
+
+extern "C" int al3d_pack_f16x3_wino(const void* planes_f16x2, int Cout, int Cin, void* out_frag, void* stream)
+{
+    AL3D_REQUIRE(planes_f16x2 && out_frag, "al3d_pack_f16x3_wino: null pointer");
+    AL3D_REQUIRE(Cout >= 64 && Cout % 64 == 0 && Cin >= 16 && Cin % 16 == 0, "al3d_pack_f16x3_wino: Cout %% 64, Cin %% 16 (got %d, %d)", Cout, Cin);
+    const int64_t count = (int64_t)2 * Cout * 16 * Cin;
+    hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)al3d_cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)planes_f16x2, Cout, Cin, (_Float16*)out_frag, count);
+    AL3D_CHECK_LAUNCH("pack_wino_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const float* scale, const float* shift,
+                                            float* out, int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu,
+                                            int io, void* stream)
+{
+    AL3D_REQUIRE(in && wgt_wino && scale && out, "al3d_conv3x3_nhwc_f16x3_wino: null pointer (scale carries the weight exponent and is required)");
+    AL3D_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 16 && Cin % 16 == 0 && Cout >= 64 && Cout % 64 == 0,
+                 "al3d_conv3x3_nhwc_f16x3_wino: Cin %% 16, Cout %% 64 (got %d, %d)", Cin, Cout);
+    AL3D_REQUIRE(io == 0 || io == SP_IO_OUT_PAIR, "al3d_conv3x3_nhwc_f16x3_wino: io = 0 or 2 (f32 pixels in)");
+    AL3D_REQUIRE(coff >= 0 && coff + Cout <= ldc && ldc % 8 == 0 && coff % 8 == 0, "al3d_conv3x3_nhwc_f16x3_wino: channel window");
+    AL3D_REQUIRE((((uintptr_t)in | (uintptr_t)wgt_wino | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
+                 "al3d_conv3x3_nhwc_f16x3_wino: pointers must be 16-byte aligned");
+    WinoParams p;
+    p.in = in; p.wgt = (const _Float16*)wgt_wino; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ldc = ldc; p.coff = coff; p.relu = relu;
+    p.tiles_x = (int)al3d_cdiv(W, WN_T); p.tiles_y = (int)al3d_cdiv(H, WN_T);
+    p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = Cout / 64;
+    const dim3 grid((unsigned)(al3d_cdiv(p.ntiles, 8) * 8 * p.nblocks));
+    if (io == 0) hipLaunchKernelGGL(conv3x3_f16x3_wino_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_f16x3_wino_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv3x3_f16x3_wino_kernel");
+    return AL3D_OK;
+}

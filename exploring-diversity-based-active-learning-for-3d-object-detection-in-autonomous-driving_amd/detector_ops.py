@@ -145,6 +145,24 @@ def pack_dma_f16x3(planes):
     return F16x3Packed("dma", out, cout, taps, cin)
 
 
+def pack_wino_f16x3(w_packed, scale=None):
+    """f32 packed 3x3 weights [Cout, 9, Cin] -> Winograd F(2x2, 3x3) weights U = G g G^T (float64 on the host side of the
+    split, then the usual f16x3 planes) in fragment order for ``al3d_conv3x3_nhwc_f16x3_wino``, + the scale to hand it."""
+    w = _dev(w_packed, torch.float32, "w")
+    cout, taps, cin = w.shape
+    assert taps == 9
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ak,okqc,bq->oabc", G, w.double().view(cout, 3, 3, cin), G).reshape(cout, 16, cin).float().contiguous()
+    planes, scale = split_f16x3(U, scale)
+    out = torch.empty((2, cout // 32, cin // 16, 16, 64, 8), dtype=torch.float16, device=w.device)
+    lib.call("al3d_pack_f16x3_wino", _ptr(planes), cout, cin, _ptr(out), _stream())
+    return F16x3Packed("wino", out, cout, 9, cin), scale
+
+
+def wino_ok(cout, cin, ksize, stride, pad):
+    return (ksize, stride, pad) == (3, 1, 1) and cout % 64 == 0 and cin % 16 == 0
+
+
 class GldsPacked:
     """f16x3 sparse-conv weights in the LDS image order of the DMA-gather kernel
     (al3d_sp_pack_glds_f16x3: [K][Cin/16][2][ceil32(Cout)][16] f16, halves swizzled)."""
@@ -175,6 +193,8 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
     the scale to hand them).  With the layer geometry given (``ksize="deconv"`` for the 2x2
     transposed conv), f16x3 weights are put in fragment order for the streamed-weight kernels."""
     if MATH == "f16x3":
+        if DENSE == "wino" and ksize not in (None, "deconv") and wino_ok(w_packed.shape[0], w_packed.shape[2], ksize, stride, pad):
+            return pack_wino_f16x3(w_packed, scale)
         planes, scale = split_f16x3(w_packed, scale)
         if ksize is not None and DENSE != "lds":
             if ksize != "deconv" and frag_ok(planes.shape[1], planes.shape[3], ksize, stride, pad):
@@ -183,7 +203,7 @@ def pack_dense(w_packed, scale=None, ksize=None, stride=None, pad=None):
                 return pack_frag_f16x3(planes), scale
             # streamed weights pay off once a launch has enough steps to amortise the deeper prologue:
             # stride-2 3x3 (72 steps) -12 %, fused head (32) -5 %, 1x1 deblock (8) +8 % -> LDS-staged
-            if DENSE in ("auto", "dma"):
+            if DENSE in ("auto", "dma", "wino"):
                 return pack_dma_f16x3(planes), scale
             steps = planes.shape[2] * planes.shape[3] // 16
             if DENSE == "bstream" or (DENSE == "stream" and ksize != "deconv" and steps >= 24):
@@ -271,7 +291,7 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
     if isinstance(w_packed, F16x3Packed):             # fragment-ordered f16x3
         pk = w_packed
         B, H, W, Cin = x.shape
-        if pk.cin != Cin or pk.taps != ksize * ksize or (pk.kind in ("frag3x3", "frag16") and (stride, pad) != (1, 1)):
+        if pk.cin != Cin or pk.taps != ksize * ksize or (pk.kind in ("frag3x3", "frag16", "wino") and (stride, pad) != (1, 1)):
             raise lib.Al3dError("conv2d_nhwc: fragment-ordered weights do not match this layer's geometry")
         OH = (H + 2 * pad - ksize) // stride + 1
         OW = (W + 2 * pad - ksize) // stride + 1
@@ -284,6 +304,14 @@ def conv2d_nhwc(x, w_packed, scale, shift, ksize, stride, pad, relu, out=None, c
             if gap is not None:
                 raise lib.Al3dError("conv2d_nhwc: this weight format has no fused GAP (see gap_fusable)")
             lib.call("al3d_conv3x3_nhwc_f16x3_frag_io", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
+                     B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, io, _stream())
+            return out
+        if pk.kind == "wino":
+            if io not in (0, IO_OUT_PAIR):
+                raise lib.Al3dError("conv2d_nhwc: the Winograd 3x3 kernel reads f32 pixels (it may write pair pixels)")
+            if gap is not None:
+                raise lib.Al3dError("conv2d_nhwc: this weight format has no fused GAP (see gap_fusable)")
+            lib.call("al3d_conv3x3_nhwc_f16x3_wino", _ptr(x), _ptr(pk.data), _ptr(scale), _ptr(shift), _ptr(out),
                      B, H, W, Cin, pk.cout, out.shape[3], coff, 1 if relu else 0, io, _stream())
             return out
         if pk.kind == "dma":

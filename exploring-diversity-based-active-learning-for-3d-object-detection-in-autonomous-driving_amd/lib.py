@@ -146,6 +146,8 @@ SIGNATURES = {
     "al3d_gap_reduce_parts_f32": (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p]),
     "al3d_gap_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "al3d_gap_nhwc_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p]),
+    "al3d_pack_f16x3_wino": (c_int, [c_p, c_int, c_int, c_p, c_p]),
+    "al3d_conv3x3_nhwc_f16x3_wino": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 9 + [c_p]),
     "al3d_tok_patch_rows_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_tok_layernorm_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p, c_p, c_flt, c_int, c_p, c_p]),
     "al3d_tok_linear_f16x3": (c_int, [c_p, c_int, c_p, c_p, c_p, c_i64, c_int, c_int, c_int, c_p, c_int, c_p, c_p,

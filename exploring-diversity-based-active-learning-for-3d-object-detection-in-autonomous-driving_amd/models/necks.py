@@ -131,7 +131,7 @@ class RPN(nn.Module):
                 consumers.append(self._deblocks_p[j]["w"])
             if i + 1 < len(self._blocks_p):
                 consumers.append(self._blocks_p[i + 1][0]["w"])
-            blk_pair = pairing and len(convs) > 1 and self._kind(convs[-1]["w"]) == "frag3x3" and \
+            blk_pair = pairing and len(convs) > 1 and self._kind(convs[-1]["w"]) in ("frag3x3", "wino") and \
                 convs[-1]["scale"].shape[0] % 8 == 0 and all(self._kind(w) == "dma" for w in consumers)
             for ci, c in enumerate(convs):
                 io = 0

@@ -77,6 +77,11 @@ PIPELINE = {"1": "split", "split": "split", "0": None, "off": None, "none": None
 _SIDE = {}
 
 
+# AL3D_SIDE_AFTER_SPARSE=1: in "ahead" mode the side stream starts batch i+1's voxelizer + rulebook when batch i's sparse
+# encoder has finished (beside the dense neck) instead of right away (beside the level-0 sparse convolutions)
+SIDE_AFTER_SPARSE = _os.environ.get("AL3D_SIDE_AFTER_SPARSE", "0") == "1"
+
+
 # AL3D_SIDE_CUS=n: the side stream may use only n compute units (hipExtStreamCreateWithCUMask); 0 = all
 SIDE_CUS = int(_os.environ.get("AL3D_SIDE_CUS", "0"))
 
@@ -177,7 +182,16 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                 if pending is not None:
                     example, ahead, ev = pending
                     main.wait_event(ev)
-                    if mode == "ahead":
+                    if mode == "ahead" and SIDE_AFTER_SPARSE and hasattr(detector, "dense_stage"):
+                        # the next batch's index work (random grid traffic) is released only once this batch's
+                        # sparse convolutions -- the gather-bound kernels it would slow down -- are through: it
+                        # then runs beside the matrix-core-bound neck, which does not notice it
+                        x, middle = detector.sparse_stage(example, book=ahead)
+                        sparse_done = torch.cuda.Event()
+                        sparse_done.record(main)
+                        side.wait_event(sparse_done)
+                        preds, middle = detector.dense_stage(example, x, middle, estimate=True)
+                    elif mode == "ahead":
                         preds, middle = detector(example, return_loss=False, estimate=True, book=ahead)
                     else:
                         x, middle = ahead

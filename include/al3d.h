@@ -534,6 +534,15 @@ int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int n
                                 float min_distance, float* out, int64_t* out_frame_off, void* workspace,
                                 void* stream);
 
+/* 3x3 / stride 1 / pad 1 as Winograd F(2x2, 3x3) in f16x3 arithmetic (det3d/models/necks/rpn.py:66-113: the eleven
+ * stride-1 3x3 layers of the SECOND neck): 2.25 x fewer matrix-core products than the direct kernels above, the input
+ * and output transforms in fp32.  wgt_wino = al3d_pack_f16x3_wino() of the al3d_split_f16x3 planes [2][Cout][16][Cin] of
+ * U = G g G^T (position a*4 + c; computed in float64 by the host); Cin % 16 == 0, Cout % 64 == 0; io = 0 or 2 (pair
+ * pixels out).  fp32-class like the direct kernels, not bit-identical to them. */
+int al3d_pack_f16x3_wino(const void* planes_f16x2, int Cout, int Cin, void* out_frag, void* stream);
+int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const float* scale, const float* shift, float* out,
+                                 int B, int H, int W, int Cin, int Cout, int ldc, int coff, int relu, int io, void* stream);
+
 /* ---------------------------------------------------------------- token matrices (Swin-T image backbone, BASELINE configs[4])
  * The reference configures mmdet 2.20.0's SwinTransformer (bevfusion/configs/nuscenes/det/transfusion/secfpn/
  * camera+lidar/swint_v0p075/default.yaml:  embed_dims 96, depths [2,2,6,2], num_heads [3,6,12,24], window_size 7),

@@ -393,3 +393,38 @@ def test_conv3x3_streamed_kernel_writes_pair_pixels():
     assert torch.equal(b[..., 32:].reshape(-1, 128).view(torch.int32), want.view(torch.int32))
     with pytest.raises(Exception, match="reads f32"):
         D.conv2d_nhwc(x, wf, sc3, shift, 3, 1, 1, True, out=b, coff=32, io=D.IO_IN_PAIR)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,xmag", [(2, 32, 32, 128, 128, 1.0), (1, 37, 21, 256, 128, 1e-4), (2, 16, 48, 256, 256, 300.0),
+                                                 (1, 64, 64, 128, 64, 1.0)])
+def test_conv3x3_winograd_f16x3_is_fp32_class(B, H, W, Cin, Cout, xmag):
+    """Winograd F(2x2, 3x3) in f16x3 arithmetic against the exact (fp64) convolution: the same gate as
+    test_conv2d_f16x3_is_fp32_class -- <= 1.5e-6 of sum|a*b| and at most 3x the fp32-input kernel's error -- at O(1),
+    tiny and large activations, on maps that are not multiples of the 16 x 16 tile; pair-pixel output holds the same values;
+    BN scale / shift / ReLU and the channel window."""
+    from al3d import detector_ops as D
+    g = torch.Generator().manual_seed(H * 7 + Cin)
+    x = (torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, H, W, generator=g)) * xmag).clamp(-6.0e4, 6.0e4)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    ref = _nhwc(F.conv2d(x.double(), w.double(), padding=1))
+    scale = _nhwc(F.conv2d(x.abs().double(), w.abs().double(), padding=1))
+    wp = D.pack_conv_weight(w).to(DEV)
+    xd = _nhwc(x).to(DEV)
+    got32 = D.conv2d_nhwc(xd, wp, None, None, 3, 1, 1, False).cpu().double()
+    ww, sc = D.pack_wino_f16x3(wp)
+    got = D.conv2d_nhwc(xd, ww, sc, None, 3, 1, 1, False)
+    assert torch.equal(got, D.conv2d_nhwc(xd, ww, sc, None, 3, 1, 1, False))          # deterministic
+    e32 = ((got32 - ref).abs() / scale).max().item()
+    ew = ((got.cpu().double() - ref).abs() / scale).max().item()
+    assert ew < 1.5e-6 and ew < 3.0 * e32 + 1e-8, (e32, ew)
+    pair = D.conv2d_nhwc(xd, ww, sc, None, 3, 1, 1, False, io=D.IO_OUT_PAIR)
+    back = D.rows_convert(pair.view(-1, Cout), False).view_as(got)
+    assert bool(((back - got).abs() <= 2.0 ** -21 * got.abs() + 2.0 ** -35).all())
+    # epilogue: BN scale / shift / ReLU into a channel window of a wider map
+    bs, bt = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    ww2, sc2 = D.pack_wino_f16x3(wp, bs)
+    wide = torch.full((B, H, W, Cout + 16), 7.0, device=DEV)
+    D.conv2d_nhwc(xd, ww2, sc2, bt, 3, 1, 1, True, out=wide, coff=8)
+    want = torch.relu(ref.to(DEV) * bs.double() + bt.double())
+    assert float((wide[..., 8:8 + Cout].double() - want).abs().max()) <= 2e-6 * float(scale.max()) * float(bs.max()) + 1e-6
+    assert bool((wide[..., :8] == 7.0).all()) and bool((wide[..., 8 + Cout:] == 7.0).all())

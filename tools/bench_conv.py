@@ -32,6 +32,12 @@ for (H, Cin, Cout, k, s, p) in shapes:
     if MODE in ('f16x3dma', 'f16x3dmapair', 'f16x3fragpair'):
         w, sc = D.split_f16x3(w, sc)
         w = D.pack_frag_f16x3(w) if D.frag_ok(Cout, Cin, k, s, p) else D.pack_dma_f16x3(w)
+    if MODE == 'f16x3wino':
+        if D.wino_ok(Cout, Cin, k, s, p):
+            w, sc = D.pack_wino_f16x3(w, sc)
+        else:
+            w, sc = D.split_f16x3(w, sc)
+            w = D.pack_dma_f16x3(w)
     if MODE == 'f16x3frag':
         w, sc = D.split_f16x3(w, sc)
         w = D.pack_frag_f16x3(w) if D.frag_ok(Cout, Cin, k, s, p) else D.pack_bstream_f16x3(w)
