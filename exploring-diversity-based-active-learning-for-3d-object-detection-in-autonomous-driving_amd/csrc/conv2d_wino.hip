@@ -28,6 +28,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define WN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define WN_IC(v) std::integral_constant<int, v>{}
 #define WN_T 16                         // output tile edge
 #define WN_HW (WN_T + 2)                // halo edge
 #define WN_HP (WN_HW * WN_HW)           // 324 halo pixels
@@ -110,7 +111,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
             __builtin_amdgcn_global_load_lds((wn_gbl_void*)(hsrc[k] + (size_t)cc * hinc[k]), (wn_lds_void*)(size_t)(dst + k * 1024), 16, 0, 0);
     };
 
-    // ---- this wave's weight stream: positions 4 w .. 4 w + 3 (transformed row a = w), both 32-channel tiles of the block
+    // ---- this wave's weight stream: positions 4 w .. 4 w + 3 (transformed row a = w), both 32-channel tiles of the block.
+    // Loaded by inline asm (the compiler would hoist plain loads to the top of the loop and then drain vmcnt(0), halo DMAs
+    // included, before the first product) into the registers the previous chunk's products have just released.
     const int NT = p.Cout >> 5;
     const _Float16* bsrc[2][2];                       // [plane][n tile]
 #pragma unroll
@@ -119,34 +122,43 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
         for (int j = 0; j < 2; ++j)
             bsrc[pl][j] = p.wgt + ((((int64_t)pl * NT + (n0 >> 5) + j) * nchunks) * 16 + wave * 4) * 512 + lane * 8;
     f16x8 fb[4][2][2];                                // [position in the row][plane][n tile]
-    auto load_b = [&](int chunk, int c) {
+    auto load_b = [&](int chunk, int c, f16x8 (&f)[2][2]) {
         const int cc = chunk < nchunks ? chunk : nchunks - 1;
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                fb[c][pl][j] = *reinterpret_cast<const f16x8*>(bsrc[pl][j] + ((int64_t)cc * 16 + c) * 512);
+        const int64_t o = ((int64_t)cc * 16 + c) * 1024;        // bytes
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                     "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
+                     : "=&v"(f[0][0]), "=&v"(f[0][1]), "=&v"(f[1][0]), "=&v"(f[1][1])
+                     : "v"(reinterpret_cast<const char*>(bsrc[0][0]) + o), "v"(reinterpret_cast<const char*>(bsrc[0][1]) + o),
+                       "v"(reinterpret_cast<const char*>(bsrc[1][0]) + o), "v"(reinterpret_cast<const char*>(bsrc[1][1]) + o)
+                     : "memory");
+    };
+    // the weights of a chunk are waited for together, with every register tied to the wait; the six halo DMAs issued
+    // after them may stay in flight
+    auto wait_b = [&]() {
+        asm volatile("s_waitcnt vmcnt(6)"
+                     : "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]),
+                       "+v"(fb[1][1][0]), "+v"(fb[1][1][1]), "+v"(fb[2][0][0]), "+v"(fb[2][0][1]), "+v"(fb[2][1][0]), "+v"(fb[2][1][1]),
+                       "+v"(fb[3][0][0]), "+v"(fb[3][0][1]), "+v"(fb[3][1][0]), "+v"(fb[3][1][1])
+                     :: "memory");
     };
 
     // ---- this lane's patch rows.  Transformed row a = wave:  t = d[r1] + sg d[r2]  with (r1, r2, sg) =
     // (0,2,-), (1,2,+), (2,1,-), (1,3,-);  then V[a][c] = t0 - t2, t1 + t2, t2 - t1, t1 - t3.
     const int r1 = wave == 0 ? 0 : wave == 2 ? 2 : 1, r2 = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
     const float sg = wave == 1 ? 1.0f : -1.0f;
-    unsigned aoff[2][2][4][2];                        // [m tile][row r1 / r2][pixel c][16-byte half]: byte offsets in a stage
+    // byte offsets of this lane's reads in a stage: (tile 0, row r1) per (pixel c, 16-byte half); tile 1 is eight halo
+    // rows further (+ 9216 B), row r2 a wave-uniform distance away
+    unsigned ao[4][2];
+    {
+        const int ty = fr >> 3, tx = fr & 7;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int tl = 32 * m + fr, ty = tl >> 3, tx = tl & 7;
+        for (int c = 0; c < 4; ++c) {
+            const int col = 2 * tx + c, hp = (2 * ty + r1) * WN_HW + col;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int row = 2 * ty + (rr == 0 ? r1 : r2), col = 2 * tx + c;
-                const int hp = row * WN_HW + col;
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    aoff[m][rr][c][e] = (unsigned)(hp * 64 + (((2 * fh + e) ^ wn_swz(col)) << 4));
-            }
+            for (int e = 0; e < 2; ++e) ao[c][e] = (unsigned)(hp * 64 + (((2 * fh + e) ^ wn_swz(col)) << 4));
+        }
     }
+    const int rdelta = __builtin_amdgcn_readfirstlane((r2 - r1) * WN_HW * 64);
 
     f32x16 acc[4][2][2];                              // [position in the row][m tile][n tile]
 #pragma unroll
@@ -158,62 +170,89 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
-    issue_halo(0);
-    issue_halo(1);
+    // the patch rows of tile m from stage `sb`: sixteen 16-byte reads, issued here, waited for by patch_wait()
+    wn_f32x4 d[2][4][2];
+    auto patch_read = [&](unsigned sb) {             // sb = stage base + tile offset (0 / 9216)
+        const unsigned s1 = sb + rdelta;
+        asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
+                     "ds_read_b128 %4, %20\n\tds_read_b128 %5, %21\n\tds_read_b128 %6, %22\n\tds_read_b128 %7, %23\n\t"
+                     "ds_read_b128 %8, %24\n\tds_read_b128 %9, %25\n\tds_read_b128 %10, %26\n\tds_read_b128 %11, %27\n\t"
+                     "ds_read_b128 %12, %28\n\tds_read_b128 %13, %29\n\tds_read_b128 %14, %30\n\tds_read_b128 %15, %31"
+                     : "=&v"(d[0][0][0]), "=&v"(d[0][0][1]), "=&v"(d[0][1][0]), "=&v"(d[0][1][1]), "=&v"(d[0][2][0]), "=&v"(d[0][2][1]),
+                       "=&v"(d[0][3][0]), "=&v"(d[0][3][1]), "=&v"(d[1][0][0]), "=&v"(d[1][0][1]), "=&v"(d[1][1][0]), "=&v"(d[1][1][1]),
+                       "=&v"(d[1][2][0]), "=&v"(d[1][2][1]), "=&v"(d[1][3][0]), "=&v"(d[1][3][1])
+                     : "v"(sb + ao[0][0]), "v"(sb + ao[0][1]), "v"(sb + ao[1][0]), "v"(sb + ao[1][1]),
+                       "v"(sb + ao[2][0]), "v"(sb + ao[2][1]), "v"(sb + ao[3][0]), "v"(sb + ao[3][1]),
+                       "v"(s1 + ao[0][0]), "v"(s1 + ao[0][1]), "v"(s1 + ao[1][0]), "v"(s1 + ao[1][1]),
+                       "v"(s1 + ao[2][0]), "v"(s1 + ao[2][1]), "v"(s1 + ao[3][0]), "v"(s1 + ao[3][1])
+                     : "memory");
+    };
+    auto patch_wait = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(d[0][0][0]), "+v"(d[0][0][1]), "+v"(d[0][1][0]), "+v"(d[0][1][1]), "+v"(d[0][2][0]), "+v"(d[0][2][1]),
+                       "+v"(d[0][3][0]), "+v"(d[0][3][1]), "+v"(d[1][0][0]), "+v"(d[1][0][1]), "+v"(d[1][1][0]), "+v"(d[1][1][1]),
+                       "+v"(d[1][2][0]), "+v"(d[1][2][1]), "+v"(d[1][3][0]), "+v"(d[1][3][1])
+                     :: "memory");
+    };
+    // d -> the four A fragment pairs of the row's positions
+    auto transform = [&](f16x8 (&ah)[4], f16x8 (&al)[4]) {
+        float t[4][8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) load_b(0, c);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        // in issue order behind halo(chunk): at most this wave's 16 weight loads of chunk - 1 (long consumed), halo(chunk + 1)
-        // (6) and the 16 weight loads of this chunk -> "all but the youngest 22" covers halo(chunk)
-        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                  // everyone's share landed; every wave is past chunk - 1's LDS reads
-        issue_halo(chunk + 2);                         // -> the stage chunk - 1 used
-        const unsigned sb = smem_base + (chunk % WN_NS) * WN_STAGE;
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            wn_f32x4 d[2][4][2];
-            asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
-                         "ds_read_b128 %4, %20\n\tds_read_b128 %5, %21\n\tds_read_b128 %6, %22\n\tds_read_b128 %7, %23\n\t"
-                         "ds_read_b128 %8, %24\n\tds_read_b128 %9, %25\n\tds_read_b128 %10, %26\n\tds_read_b128 %11, %27\n\t"
-                         "ds_read_b128 %12, %28\n\tds_read_b128 %13, %29\n\tds_read_b128 %14, %30\n\tds_read_b128 %15, %31\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(d[0][0][0]), "=&v"(d[0][0][1]), "=&v"(d[0][1][0]), "=&v"(d[0][1][1]), "=&v"(d[0][2][0]), "=&v"(d[0][2][1]),
-                           "=&v"(d[0][3][0]), "=&v"(d[0][3][1]), "=&v"(d[1][0][0]), "=&v"(d[1][0][1]), "=&v"(d[1][1][0]), "=&v"(d[1][1][1]),
-                           "=&v"(d[1][2][0]), "=&v"(d[1][2][1]), "=&v"(d[1][3][0]), "=&v"(d[1][3][1])
-                         : "v"(sb + aoff[m][0][0][0]), "v"(sb + aoff[m][0][0][1]), "v"(sb + aoff[m][0][1][0]), "v"(sb + aoff[m][0][1][1]),
-                           "v"(sb + aoff[m][0][2][0]), "v"(sb + aoff[m][0][2][1]), "v"(sb + aoff[m][0][3][0]), "v"(sb + aoff[m][0][3][1]),
-                           "v"(sb + aoff[m][1][0][0]), "v"(sb + aoff[m][1][0][1]), "v"(sb + aoff[m][1][1][0]), "v"(sb + aoff[m][1][1][1]),
-                           "v"(sb + aoff[m][1][2][0]), "v"(sb + aoff[m][1][2][1]), "v"(sb + aoff[m][1][3][0]), "v"(sb + aoff[m][1][3][1])
-                         : "memory");
-            float t[4][8];
+            for (int e = 0; e < 8; ++e) t[c][e] = __builtin_fmaf(sg, d[1][c][e >> 2][e & 3], d[0][c][e >> 2][e & 3]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[c][e] = __builtin_fmaf(sg, d[1][c][e >> 2][e & 3], d[0][c][e >> 2][e & 3]);
-            f16x8 ah[4], al[4];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v0 = t[0][e] - t[2][e], v1 = t[1][e] + t[2][e], v2 = t[2][e] - t[1][e], v3 = t[1][e] - t[3][e];
-                _Float16 hh, ll;
-                wn_split(v0, hh, ll); ah[0][e] = hh; al[0][e] = ll;
-                wn_split(v1, hh, ll); ah[1][e] = hh; al[1][e] = ll;
-                wn_split(v2, hh, ll); ah[2][e] = hh; al[2][e] = ll;
-                wn_split(v3, hh, ll); ah[3][e] = hh; al[3][e] = ll;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f16x8 wd[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) wd[j] = fb[c][0][j] * (_Float16)0.00048828125f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(al[c], wd[j], acc[c][m][j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][1][j], acc[c][m][j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][0][j], acc[c][m][j]);
-                if (m == 1) load_b(chunk + 1, c);      // position c's weights of this chunk are through: fetch the next chunk's
-            }
+        for (int e = 0; e < 8; ++e) {
+            const float v0 = t[0][e] - t[2][e], v1 = t[1][e] + t[2][e], v2 = t[2][e] - t[1][e], v3 = t[1][e] - t[3][e];
+            _Float16 hh, ll;
+            wn_split(v0, hh, ll); ah[0][e] = hh; al[0][e] = ll;
+            wn_split(v1, hh, ll); ah[1][e] = hh; al[1][e] = ll;
+            wn_split(v2, hh, ll); ah[2][e] = hh; al[2][e] = ll;
+            wn_split(v3, hh, ll); ah[3][e] = hh; al[3][e] = ll;
         }
+    };
+    // the 24 products of one (chunk, m tile); after_pos(c) runs when position c's six are issued
+    auto products = [&](auto m_, const f16x8 (&ah)[4], const f16x8 (&al)[4], auto&& after_pos) {
+        constexpr int m = decltype(m_)::value;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f16x8 wd[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wd[j] = fb[c][0][j] * (_Float16)0.00048828125f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(al[c], wd[j], acc[c][m][j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][1][j], acc[c][m][j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][0][j], acc[c][m][j]);
+            after_pos(c);
+        }
+    };
+    // ---- main loop: per chunk one barrier; per tile patch reads -> transform -> 24 products.  The next chunk's weights
+    // are requested position by position as the second tile's products release their registers; the halo of chunk + 2 is
+    // requested behind them, so waiting for the weights ("all but the youngest 6") leaves that DMA in flight.
+    f16x8 ah0[4], al0[4];
+    issue_halo(0);
+    load_b(0, 0, fb[0]); load_b(0, 1, fb[1]); load_b(0, 2, fb[2]); load_b(0, 3, fb[3]);
+    issue_halo(1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        wait_b();                                      // this chunk's weights and, older than them, halo(chunk)
+        __builtin_amdgcn_s_barrier();                  // everyone's share landed; every wave is past chunk - 1's LDS reads
+        const unsigned sb = smem_base + (chunk % WN_NS) * WN_STAGE;
+        patch_read(sb);
+        patch_wait();
+        transform(ah0, al0);
+        products(WN_IC(0), ah0, al0, [](int) {});
+        patch_read(sb + 8 * WN_HW * 64);
+        patch_wait();
+        transform(ah0, al0);
+        products(WN_IC(1), ah0, al0, [&](int c) {
+            if (c == 0) load_b(chunk + 1, 0, fb[0]);
+            else if (c == 1) load_b(chunk + 1, 1, fb[1]);
+            else if (c == 2) load_b(chunk + 1, 2, fb[2]);
+            else load_b(chunk + 1, 3, fb[3]);
+        });
+        issue_halo(chunk + 2);                         // -> the stage chunk - 1 used (free since this chunk's barrier)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's dummy requests must not outlive the workgroup's LDS
 
