@@ -137,7 +137,7 @@ class ConvTimer:
         else:
             out.update(kernel="conv2d_mfma_kernel", peak=MFMA_F32_PEAK_TFLOPS,
                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
-        for pmc in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for pmc in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", pmc)
             if not os.path.exists(pmc):      # PMC passes are separate runs (rocprofv3 --pmc); see DESIGN.md
                 continue
@@ -146,7 +146,9 @@ class ConvTimer:
                 if rec:
                     out["traffic"] = round(rec["hbm_mb_corrected"] * 1e6)
                     out["traffic_detail"] = {k: rec[k] for k in ("fetch_mb_raw", "fetch_mb_x2", "write_mb", "launches",
-                                                                 "correction") if k in rec}
+                                                                 "correction", "hbm_mb_fetch_as_counted", "hbm_mb_fetch_x2",
+                                                                 "algorithmic_mb", "x2_applies", "ratio_as_counted",
+                                                                 "ratio_x2") if k in rec}
                     out["traffic_note"] = rec.get("note", "") + " (" + os.path.basename(pmc) + ")"
                     break
             except Exception:
@@ -233,8 +235,9 @@ class SparseTimer:
                 L["K"] * L["cin"] * L["cout"] * 4.0
             tot_unique += uniq
             rows.append(dict(cin=L["cin"], cout=L["cout"], K=L["K"], n_out=L["n_out"], pairs=L["pairs"],
-                             valid=round(L["pairs"] / max(1, L["n_out"] * L["K"]), 3), avg_us=round(us, 1),
-                             tflops=round(flop / us / 1e6, 1), gbs=round(byts / us / 1e3, 1)))
+                             n_in=L["n_in"], valid=round(L["pairs"] / max(1, L["n_out"] * L["K"]), 3), avg_us=round(us, 1),
+                             tflops=round(flop / us / 1e6, 1), gather_gbs=round(byts / us / 1e3, 1),
+                             unique_mb=round(uniq / 1e6, 1), unique_gbs=round(uniq / us / 1e3, 1)))
             tot_flop += flop
             tot_bytes += byts
             tot_ms += us / 1e3
@@ -249,13 +252,15 @@ class SparseTimer:
                     algorithmic_gflop_per_frame=round(tot_flop / self.batch_frames / 1e9, 3),
                     algorithmic_mb_per_frame=round(tot_bytes / self.batch_frames / 1e6, 2),
                     achieved_tflops=round(tf, 1), mfma_peak_tflops=round(peak, 1), frac_mfma=round(tf / peak, 4),
-                    achieved_gbs=round(gbs, 1), hbm_peak_gbs=HBM_PEAK_GBS, frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
-                    bytes_note="achieved_gbs uses SURVEY 8d's per-layer formula, which prices every gathered (row, tap) "
-                               "pair as memory traffic (a gather/GEMM/scatter formulation); here outputs are written once "
-                               "and gathers are served by L2 / LDS-DMA, so it is a gather rate, not HBM traffic -- "
-                               "unique_* counts the bytes that must cross HBM once",
+                    hbm_peak_gbs=HBM_PEAK_GBS,
                     unique_mb_per_frame=round(tot_unique / self.batch_frames / 1e6, 2),
-                    unique_gbs=round(tot_unique / tot_ms / 1e6, 1), frac_hbm_unique=round(tot_unique / tot_ms / 1e6 / HBM_PEAK_GBS, 4),
+                    unique_gbs=round(tot_unique / tot_ms / 1e6, 1), frac_hbm=round(tot_unique / tot_ms / 1e6 / HBM_PEAK_GBS, 4),
+                    gather_gbs=round(gbs, 1),
+                    bytes_note="frac_hbm = unique bytes (input rows + output rows + residual rows + weights: what must cross "
+                               "HBM once) / time / 8 TB/s.  gather_gbs is SURVEY 8d's per-layer formula, which prices every "
+                               "gathered (row, tap) pair as memory traffic (a gather/GEMM/scatter formulation): gathers here "
+                               "are L2 / LDS-DMA hits, so it is a gather rate, not HBM traffic, and is not divided by the "
+                               "HBM peak",
                     measured="HIP events around each sparse-conv launch of the timed steps (rank 0); pairs from "
                              "the rulebook of one batch (every batch holds the same base frames)",
                     layers=rows)

@@ -1,7 +1,7 @@
 """Turn rocprofv3 rocpd (.db) outputs into the summaries committed under profiles/.
 
   python tools/rocpd_summary.py stats  <kernel-trace.db> <out.csv>
-  python tools/rocpd_summary.py hbm    <FETCH_SIZE.db> <WRITE_SIZE.db> <out.json> [note]
+  python tools/rocpd_summary.py hbm    <FETCH_SIZE.db> <WRITE_SIZE.db> <out.json> [note] [bench-line.json]
 
 ``stats`` reproduces rocprofv3 --stats' kernel table (calls, total/avg/min/max ns, share).
 ``hbm`` sums the two single-counter passes per kernel and applies the gfx950 correction from
@@ -44,32 +44,65 @@ def per_kernel(db, counter):
     return acc
 
 
-# Kernels whose global loads fetch 64-byte segments (16 f32 channels of a pixel / of a 16-channel row): FETCH_SIZE
-# tallies those correctly.  Everything else issues fully coalesced 16 B/lane loads or LDS-DMA, whose 128-byte
-# requests gfx950 tallies at 64 B (MI355X_MICROARCH.md): FETCH_SIZE x 2.
-NO_X2 = ("conv3x3_f16x3", "conv2d_f16x3_kernel", "conv2d_f16x3_bstream", "sp_conv_wave2_kernel<16,")
+def algorithmic_from_bench_line(path):
+    """Algorithmic HBM bytes per launch for the kernels whose work the bench line describes: the sparse-conv template
+    instances (mean over the layers an instance serves of: input rows + output rows + residual rows + weights + the index
+    table it streams, from ``roofline_sparse.layers``) and the streamed 3x3 dense kernel (its launch mix at the bench's
+    batch size).  -> {kernel-name prefix: MB}."""
+    try:
+        line = json.loads(open(path).read().strip().split("\n")[-1])
+    except Exception:
+        return {}
+    out = {}
+    sp = line.get("roofline_sparse") or {}
+    groups = {}
+    for L in sp.get("layers", []):
+        table = L["K"] * L["n_out"] * 4.0 / 1e6                         # tap-major index table, one entry per (tap, row)
+        groups.setdefault((L["cin"] if L["cin"] >= 16 else 16, L["cout"]), []).append(L["unique_mb"] + table)
+    for (cin, cout), v in groups.items():
+        mb = sum(v) / len(v)
+        for fam in ("sp_conv_wave2_kernel", "sp_conv_glds_kernel", "sp_conv_rng_kernel"):
+            out[f"{fam}<{cin}, {cout},"] = mb
+    frames = sp.get("frames_per_launch")
+    if frames:
+        # SECOND neck at 128 x 128 / 64 x 64 (rpn.py:66-113), f32 pixels: in + out bytes of the nine f32-writing 3x3 launches
+        px1, px2 = 128 * 128 * 4.0 * frames / 1e6, 64 * 64 * 4.0 * frames / 1e6
+        mix = [px1 * (256 + 128)] + [px1 * (128 + 128)] * 4 + [px2 * (256 + 256)] * 4
+        out["conv3x3_f16x3_frag_kernel<0>"] = sum(mix) / len(mix)
+    return out
 
 
-def hbm(fdb, wdb, out, note):
+def hbm(fdb, wdb, out, note, bench_line=None):
+    """Per kernel: raw FETCH_SIZE / WRITE_SIZE per launch, the two candidate totals (fetch as counted, fetch x 2 -- gfx950
+    tallies the 128-byte requests of fully coalesced 16 B/lane loads and LDS-DMA at 64 B, MI355X_MICROARCH.md), and --
+    where the bench line gives the launch's algorithmic bytes -- WHICH of the two the comparison supports (``x2_applies`` is
+    derived from that comparison, never asserted; null when no algorithmic count is available)."""
     fetch, write = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
+    algo = algorithmic_from_bench_line(bench_line) if bench_line else {}
     res = {}
     for k, (n, kb) in fetch.items():
         wn, wkb = write.get(k, (0, 0.0))
-        f_avg = kb / n
-        w_avg = wkb / wn if wn else 0.0
-        x2 = not k.startswith(NO_X2)
-        res[k] = {"launches": n, "fetch_kb_raw": f_avg, "write_kb": w_avg,
-                  "fetch_mb_raw": f_avg * 1024 / 1e6, "fetch_mb_x2": 2.0 * f_avg * 1024 / 1e6,
-                  "write_mb": w_avg * 1024 / 1e6,
-                  "hbm_mb_corrected": ((2.0 if x2 else 1.0) * f_avg + w_avg) * 1024 / 1e6,
-                  "x2_applies": x2,
-                  "correction": ("FETCH_SIZE x 2 (MI355X_MICROARCH.md: gfx950 tallies the 128-byte requests of fully "
-                                 "coalesced 16 B/lane loads and LDS-DMA at 64 B); WRITE_SIZE as counted") if x2 else
-                                ("none: this kernel's loads fetch 64-byte segments (16 f32 channels per pixel / row unit), "
-                                 "which FETCH_SIZE tallies correctly -- raw FETCH_SIZE + WRITE_SIZE equals the algorithmic "
-                                 "bytes of the launch mix"),
-                  "note": note}
-    res = dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_mb_corrected"] * kv[1]["launches"]))
+        f_mb = kb / n * 1024 / 1e6
+        w_mb = (wkb / wn if wn else 0.0) * 1024 / 1e6
+        a = next((v for pref, v in algo.items() if k.startswith(pref)), None)
+        raw, x2 = f_mb + w_mb, 2.0 * f_mb + w_mb
+        entry = {"launches": n, "fetch_mb_raw": round(f_mb, 2), "write_mb": round(w_mb, 2),
+                 "hbm_mb_fetch_as_counted": round(raw, 2), "hbm_mb_fetch_x2": round(x2, 2), "algorithmic_mb": None,
+                 "x2_applies": None, "note": note}
+        if a:
+            import math
+            entry["algorithmic_mb"] = round(a, 2)
+            entry["ratio_as_counted"] = round(raw / a, 3)
+            entry["ratio_x2"] = round(x2 / a, 3)
+            entry["x2_applies"] = bool(abs(math.log(x2 / a)) < abs(math.log(raw / a)))
+            entry["hbm_mb_corrected"] = round(x2 if entry["x2_applies"] else raw, 2)
+            entry["basis"] = ("x2_applies = whichever of (FETCH_SIZE + WRITE_SIZE) and (2 x FETCH_SIZE + WRITE_SIZE) is closer "
+                              "to the algorithmic bytes of the launch (bench line: rows in + rows out + residual + weights + "
+                              "index table per sparse layer; in + out pixels for the dense launch mix).  A corrected total "
+                              "BELOW the algorithmic count means part of the input was still in the 256 MiB Infinity Cache "
+                              "from its producer (the counters see memory-side requests only)")
+        res[k] = entry
+    res = dict(sorted(res.items(), key=lambda kv: -(kv[1]["hbm_mb_fetch_x2"]) * kv[1]["launches"]))
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
 
@@ -79,4 +112,4 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     else:
         note = sys.argv[5] if len(sys.argv) > 5 else ""
-        hbm(sys.argv[2], sys.argv[3], sys.argv[4], note)
+        hbm(sys.argv[2], sys.argv[3], sys.argv[4], note, sys.argv[6] if len(sys.argv) > 6 else None)
