@@ -18,7 +18,11 @@
 // The output transform runs along the row inside a wave's registers and across the four waves through LDS.
 //
 // Numerics: measured error against float64 stays at the fp32-input kernel's level (tests/test_dense_gpu.py); the
-// kernel is NOT bit-identical to the direct kernels (another summation tree).  gfx950 only.
+// kernel is NOT bit-identical to the direct kernels (another summation tree).
+// Status (round 3): at parity with the direct streamed kernel, not ahead -- with 256 accumulator registers
+// only one wave fits a SIMD, and the input transform + split (~8 vector instructions per MFMA) is not hidden behind the
+// products by the compiler's schedule (a software-pipelined variant with sched_group_barrier measured the same); it
+// stays opt-in (AL3D_DENSE=wino).  gfx950 only.
 #include "al3d_common.h"
 #include "sp_rows.h"
 #include <type_traits>
@@ -170,46 +174,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
-    // the patch rows of tile m from stage `sb`: sixteen 16-byte reads, issued here, waited for by patch_wait()
-    wn_f32x4 d[2][4][2];
-    auto patch_read = [&](unsigned sb) {             // sb = stage base + tile offset (0 / 9216)
+    // The patch rows of a tile are read and transformed in two halves (the fragment's two 16-byte pieces = channels
+    // 8 h .. 8 h + 3 and 8 h + 4 .. 8 h + 7): eight 16-byte reads and 32 live registers at a time instead of sixteen / 64.
+    wn_f32x4 d[2][4];                                 // [row r1 / r2][pixel c]
+    auto patch_read = [&](unsigned sb, int e) {       // sb = stage base + tile offset (0 / 9216)
         const unsigned s1 = sb + rdelta;
-        asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
-                     "ds_read_b128 %4, %20\n\tds_read_b128 %5, %21\n\tds_read_b128 %6, %22\n\tds_read_b128 %7, %23\n\t"
-                     "ds_read_b128 %8, %24\n\tds_read_b128 %9, %25\n\tds_read_b128 %10, %26\n\tds_read_b128 %11, %27\n\t"
-                     "ds_read_b128 %12, %28\n\tds_read_b128 %13, %29\n\tds_read_b128 %14, %30\n\tds_read_b128 %15, %31"
-                     : "=&v"(d[0][0][0]), "=&v"(d[0][0][1]), "=&v"(d[0][1][0]), "=&v"(d[0][1][1]), "=&v"(d[0][2][0]), "=&v"(d[0][2][1]),
-                       "=&v"(d[0][3][0]), "=&v"(d[0][3][1]), "=&v"(d[1][0][0]), "=&v"(d[1][0][1]), "=&v"(d[1][1][0]), "=&v"(d[1][1][1]),
-                       "=&v"(d[1][2][0]), "=&v"(d[1][2][1]), "=&v"(d[1][3][0]), "=&v"(d[1][3][1])
-                     : "v"(sb + ao[0][0]), "v"(sb + ao[0][1]), "v"(sb + ao[1][0]), "v"(sb + ao[1][1]),
-                       "v"(sb + ao[2][0]), "v"(sb + ao[2][1]), "v"(sb + ao[3][0]), "v"(sb + ao[3][1]),
-                       "v"(s1 + ao[0][0]), "v"(s1 + ao[0][1]), "v"(s1 + ao[1][0]), "v"(s1 + ao[1][1]),
-                       "v"(s1 + ao[2][0]), "v"(s1 + ao[2][1]), "v"(s1 + ao[3][0]), "v"(s1 + ao[3][1])
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                     "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+                     : "=&v"(d[0][0]), "=&v"(d[0][1]), "=&v"(d[0][2]), "=&v"(d[0][3]), "=&v"(d[1][0]), "=&v"(d[1][1]), "=&v"(d[1][2]),
+                       "=&v"(d[1][3])
+                     : "v"(sb + ao[0][e]), "v"(sb + ao[1][e]), "v"(sb + ao[2][e]), "v"(sb + ao[3][e]),
+                       "v"(s1 + ao[0][e]), "v"(s1 + ao[1][e]), "v"(s1 + ao[2][e]), "v"(s1 + ao[3][e])
                      : "memory");
     };
     auto patch_wait = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(d[0][0][0]), "+v"(d[0][0][1]), "+v"(d[0][1][0]), "+v"(d[0][1][1]), "+v"(d[0][2][0]), "+v"(d[0][2][1]),
-                       "+v"(d[0][3][0]), "+v"(d[0][3][1]), "+v"(d[1][0][0]), "+v"(d[1][0][1]), "+v"(d[1][1][0]), "+v"(d[1][1][1]),
-                       "+v"(d[1][2][0]), "+v"(d[1][2][1]), "+v"(d[1][3][0]), "+v"(d[1][3][1])
+                     : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[1][2]), "+v"(d[1][3])
                      :: "memory");
     };
-    // d -> the four A fragment pairs of the row's positions
-    auto transform = [&](f16x8 (&ah)[4], f16x8 (&al)[4]) {
-        float t[4][8];
+    // d (half e) -> elements 4 e .. 4 e + 3 of the four A fragment pairs of the row's positions
+    auto transform = [&](f16x8 (&ah)[4], f16x8 (&al)[4], int e) {
+        float t[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[c][e] = __builtin_fmaf(sg, d[1][c][e >> 2][e & 3], d[0][c][e >> 2][e & 3]);
+            for (int i = 0; i < 4; ++i) t[c][i] = __builtin_fmaf(sg, d[1][c][i], d[0][c][i]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v0 = t[0][e] - t[2][e], v1 = t[1][e] + t[2][e], v2 = t[2][e] - t[1][e], v3 = t[1][e] - t[3][e];
+        for (int i = 0; i < 4; ++i) {
+            const float v0 = t[0][i] - t[2][i], v1 = t[1][i] + t[2][i], v2 = t[2][i] - t[1][i], v3 = t[1][i] - t[3][i];
             _Float16 hh, ll;
-            wn_split(v0, hh, ll); ah[0][e] = hh; al[0][e] = ll;
-            wn_split(v1, hh, ll); ah[1][e] = hh; al[1][e] = ll;
-            wn_split(v2, hh, ll); ah[2][e] = hh; al[2][e] = ll;
-            wn_split(v3, hh, ll); ah[3][e] = hh; al[3][e] = ll;
+            wn_split(v0, hh, ll); ah[0][4 * e + i] = hh; al[0][4 * e + i] = ll;
+            wn_split(v1, hh, ll); ah[1][4 * e + i] = hh; al[1][4 * e + i] = ll;
+            wn_split(v2, hh, ll); ah[2][4 * e + i] = hh; al[2][4 * e + i] = ll;
+            wn_split(v3, hh, ll); ah[3][4 * e + i] = hh; al[3][4 * e + i] = ll;
         }
+    };
+    auto make_a = [&](unsigned sb, f16x8 (&ah)[4], f16x8 (&al)[4]) {     // a whole tile's fragments (two halves)
+        patch_read(sb, 0); patch_wait(); transform(ah, al, 0);
+        patch_read(sb, 1); patch_wait(); transform(ah, al, 1);
     };
     // the 24 products of one (chunk, m tile); after_pos(c) runs when position c's six are issued
     auto products = [&](auto m_, const f16x8 (&ah)[4], const f16x8 (&al)[4], auto&& after_pos) {
@@ -228,31 +230,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
             after_pos(c);
         }
     };
-    // ---- main loop: per chunk one barrier; per tile patch reads -> transform -> 24 products.  The next chunk's weights
-    // are requested position by position as the second tile's products release their registers; the halo of chunk + 2 is
-    // requested behind them, so waiting for the weights ("all but the youngest 6") leaves that DMA in flight.
     f16x8 ah0[4], al0[4];
-    issue_halo(0);
-    load_b(0, 0, fb[0]); load_b(0, 1, fb[1]); load_b(0, 2, fb[2]); load_b(0, 3, fb[3]);
-    issue_halo(1);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        wait_b();                                      // this chunk's weights and, older than them, halo(chunk)
-        __builtin_amdgcn_s_barrier();                  // everyone's share landed; every wave is past chunk - 1's LDS reads
-        const unsigned sb = smem_base + (chunk % WN_NS) * WN_STAGE;
-        patch_read(sb);
-        patch_wait();
-        transform(ah0, al0);
-        products(WN_IC(0), ah0, al0, [](int) {});
-        patch_read(sb + 8 * WN_HW * 64);
-        patch_wait();
-        transform(ah0, al0);
-        products(WN_IC(1), ah0, al0, [&](int c) {
-            if (c == 0) load_b(chunk + 1, 0, fb[0]);
-            else if (c == 1) load_b(chunk + 1, 1, fb[1]);
-            else if (c == 2) load_b(chunk + 1, 2, fb[2]);
-            else load_b(chunk + 1, 3, fb[3]);
-        });
-        issue_halo(chunk + 2);                         // -> the stage chunk - 1 used (free since this chunk's barrier)
+    {
+        // ---- plain loop: per chunk one barrier; per tile patch reads -> transform -> 24 products.  The next chunk's weights
+        // are requested position by position as the second tile's products release their registers; the halo of chunk + 2 is
+        // requested behind them, so waiting for the weights ("all but the youngest 6") leaves that DMA in flight.
+        issue_halo(0);
+        load_b(0, 0, fb[0]); load_b(0, 1, fb[1]); load_b(0, 2, fb[2]); load_b(0, 3, fb[3]);
+        issue_halo(1);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            wait_b();                                  // this chunk's weights and, older than them, halo(chunk)
+            __builtin_amdgcn_s_barrier();              // everyone's share landed; every wave is past chunk - 1's LDS reads
+            const unsigned sb = smem_base + (chunk % WN_NS) * WN_STAGE;
+            make_a(sb, ah0, al0);
+            products(WN_IC(0), ah0, al0, [](int) {});
+            make_a(sb + 8 * WN_HW * 64, ah0, al0);
+            products(WN_IC(1), ah0, al0, [&](int c) {
+                if (c == 0) load_b(chunk + 1, 0, fb[0]);
+                else if (c == 1) load_b(chunk + 1, 1, fb[1]);
+                else if (c == 2) load_b(chunk + 1, 2, fb[2]);
+                else load_b(chunk + 1, 3, fb[3]);
+            });
+            issue_halo(chunk + 2);                     // -> the stage chunk - 1 used (free since this chunk's barrier)
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's dummy requests must not outlive the workgroup's LDS
 
