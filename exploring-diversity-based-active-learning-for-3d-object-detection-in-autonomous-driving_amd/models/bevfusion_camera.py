@@ -81,7 +81,9 @@ class _ConvBNReLU(nn.Module):
         key = (x.device, D.MATH, D.DENSE, _versions(self.conv, self.bn))
         if self._packed is None or self._packed[0] != key:
             scale, shift = D.fold_bn(self.bn)
-            w, scale = D.pack_dense(D.pack_conv_weight(self.conv.weight).to(x.device), scale.to(x.device))
+            c = self.conv
+            geom = (c.kernel_size[0], c.stride[0], c.padding[0]) if c.in_channels % 16 == 0 else (None, None, None)
+            w, scale = D.pack_dense(D.pack_conv_weight(c.weight).to(x.device), scale.to(x.device), *geom)
             self._packed = (key, w, scale, shift.to(x.device))
         _, w, scale, shift = self._packed
         return D.conv2d_nhwc(x, w, scale, shift, self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0], True)
