@@ -76,7 +76,7 @@ __device__ __forceinline__ bool wn_tile_of_block(const WinoParams& p, int& tile,
 // on the source side of the DMA): the eight tiles of a tile row then read eight different bank groups.
 __device__ __forceinline__ int wn_swz(int col) { return (col >> 2) & 3; }
 
-template <int IO>
+template <int IO, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_NS * WN_STAGE];
@@ -136,14 +136,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
                        "v"(reinterpret_cast<const char*>(bsrc[1][0]) + o), "v"(reinterpret_cast<const char*>(bsrc[1][1]) + o)
                      : "memory");
     };
-    // the weights of a chunk are waited for together, with every register tied to the wait; the six halo DMAs issued
-    // after them may stay in flight
-    auto wait_b = [&]() {
-        asm volatile("s_waitcnt vmcnt(6)"
-                     : "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]),
-                       "+v"(fb[1][1][0]), "+v"(fb[1][1][1]), "+v"(fb[2][0][0]), "+v"(fb[2][0][1]), "+v"(fb[2][1][0]), "+v"(fb[2][1][1]),
-                       "+v"(fb[3][0][0]), "+v"(fb[3][0][1]), "+v"(fb[3][1][0]), "+v"(fb[3][1][1])
-                     :: "memory");
+    // Position c's weights are waited for where its first product is issued (not all four at the top of the chunk): in
+    // issue order behind them sit the later positions' loads (4 each) and the halo DMAs of chunk + 2 (6), so "all but the
+    // youngest 18 / 14 / 10 / 6" covers positions 0 / 1 / 2 / 3 -- the last position's request, issued at the very end of
+    // the previous chunk, gets three quarters of this chunk's first tile as cover.
+    auto wait_b_pos = [&](int c, f16x8 (&f)[2][2]) {
+        if (c == 0) asm volatile("s_waitcnt vmcnt(18)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]) :: "memory");
+        else if (c == 1) asm volatile("s_waitcnt vmcnt(14)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]) :: "memory");
+        else if (c == 2) asm volatile("s_waitcnt vmcnt(10)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]) :: "memory");
     };
 
     // ---- this lane's patch rows.  Transformed row a = wave:  t = d[r1] + sg d[r2]  with (r1, r2, sg) =
@@ -210,23 +211,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
         }
     };
     auto make_a = [&](unsigned sb, f16x8 (&ah)[4], f16x8 (&al)[4]) {     // a whole tile's fragments (two halves)
-        patch_read(sb, 0); patch_wait(); transform(ah, al, 0);
-        patch_read(sb, 1); patch_wait(); transform(ah, al, 1);
+        if constexpr (ABL == 2 || ABL == 5) {              // dev ablation: no patch reads, no transform
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ah[c] = fb[c][0][0]; al[c] = fb[c][1][0]; }
+            return;
+        }
+        if constexpr (ABL != 3) { patch_read(sb, 0); patch_wait(); }
+        transform(ah, al, 0);
+        if constexpr (ABL != 3) { patch_read(sb, 1); patch_wait(); }
+        transform(ah, al, 1);
     };
     // the 24 products of one (chunk, m tile); after_pos(c) runs when position c's six are issued
     auto products = [&](auto m_, const f16x8 (&ah)[4], const f16x8 (&al)[4], auto&& after_pos) {
         constexpr int m = decltype(m_)::value;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            if (m == 0) wait_b_pos(c, fb[c]);
             f16x8 wd[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) wd[j] = fb[c][0][j] * (_Float16)0.00048828125f;
+            if constexpr (ABL == 1) {                    // dev ablation: no products (operands kept alive)
+                asm volatile("" :: "v"(al[c]), "v"(ah[c]), "v"(wd[0]), "v"(wd[1]), "v"(fb[c][1][0]), "v"(fb[c][1][1]), "v"(fb[c][0][0]), "v"(fb[c][0][1]));
+            } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(al[c], wd[j], acc[c][m][j]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][1][j], acc[c][m][j]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[c][m][j] = WN_MFMA(ah[c], fb[c][0][j], acc[c][m][j]);
+            }
             after_pos(c);
         }
     };
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
         load_b(0, 0, fb[0]); load_b(0, 1, fb[1]); load_b(0, 2, fb[2]); load_b(0, 3, fb[3]);
         issue_halo(1);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            wait_b();                                  // this chunk's weights and, older than them, halo(chunk)
+            asm volatile("s_waitcnt vmcnt(22)" ::: "memory");           // halo(chunk): behind it this chunk's 16 weight loads and halo(chunk + 1)
             __builtin_amdgcn_s_barrier();              // everyone's share landed; every wave is past chunk - 1's LDS reads
             const unsigned sb = smem_base + (chunk % WN_NS) * WN_STAGE;
             make_a(sb, ah0, al0);
@@ -259,6 +272,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16x3_wino_kernel(WinoParams p
     // ---- output transform.  Wave w holds row a = w of M (positions (w, 0..3)):  P_w[j] = sum_c M[w][c] A^T[j][c]
     // in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), then Y[i][j] = sum_a A^T[i][a] P_a[j] across the waves through LDS,
     // one 32-channel half at a time: X[a][j][tile][32 + pad] floats = 72 KB in the halo ring's storage.
+    if constexpr (ABL == 4 || ABL == 5) {                // dev ablation: no output transform / stores (one word keeps the products alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[q][i][j][r];
+        if (keep == 123.456f) p.out[0] = keep;
+        return;
+    }
     float* X = reinterpret_cast<float*>(smem);
     static_assert(4 * 2 * 64 * WN_XP * 4 <= WN_NS * WN_STAGE, "exchange must fit the halo ring");
 #pragma unroll
@@ -369,6 +395,11 @@ extern "C" int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_win
     p.tiles_x = (int)al3d_cdiv(W, WN_T); p.tiles_y = (int)al3d_cdiv(H, WN_T);
     p.ntiles = p.tiles_x * p.tiles_y * B; p.nblocks = Cout / 64;
     const dim3 grid((unsigned)(al3d_cdiv(p.ntiles, 8) * 8 * p.nblocks));
+#ifdef AL3D_WINO_ABLATE
+    hipLaunchKernelGGL((conv3x3_f16x3_wino_kernel<0, AL3D_WINO_ABLATE>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("conv3x3_f16x3_wino_kernel");
+    return AL3D_OK;
+#endif
     if (io == 0) hipLaunchKernelGGL(conv3x3_f16x3_wino_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv3x3_f16x3_wino_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("conv3x3_f16x3_wino_kernel");
