@@ -195,3 +195,33 @@ def test_pipeline_registry_builds_the_reference_val_pipeline():
     assert len(ds) == 1 and isinstance(ds.pipeline, Compose) and len(ds.pipeline.transforms) == 6
     with pytest.raises(NotImplementedError):
         Compose([dict(type="Preprocess", cfg=dict(mode="train"))])
+
+
+def test_swin_row_maps_equal_roll_pad_partition_and_unfold():
+    """Host logic of the Swin-T token path (al3d/token_ops.py): the (shifted) window row map equals torch's pad -> roll ->
+    window partition of an index image, every token appears exactly once, padding is -1; the patch-merging map equals
+    ``F.unfold`` of the corner-padded index image in piece-major order.  (The kernels that consume them: tests/test_swin_gpu.py.)"""
+    import importlib.util
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = [d for d in os.listdir(root) if d.endswith("_amd") and os.path.isdir(os.path.join(root, d, "csrc"))][0]
+    src = open(os.path.join(root, pkg, "token_ops.py")).read()
+    # the two map builders are pure numpy: evaluate them without importing the package (which loads the HIP library)
+    ns = {"np": np}
+    start = src.index("def window_rowmap(")
+    exec(src[start:], ns)
+    for (B, H, W, shift) in ((2, 9, 11, 3), (1, 14, 21, 0), (3, 7, 7, 3), (2, 64, 176, 3)):
+        m, (nwy, nwx) = ns["window_rowmap"](B, H, W, 7, shift)
+        Hp, Wp = nwy * 7, nwx * 7
+        assert Hp >= H and Wp >= W and Hp - H < 7 and Wp - W < 7
+        assert sorted(m[m >= 0].tolist()) == list(range(B * H * W)) and int((m < 0).sum()) == B * (Hp * Wp - H * W)
+        idx = torch.arange(B * H * W, dtype=torch.float32).view(B, H, W, 1) + 1.0
+        pad = F.pad(idx, (0, 0, 0, Wp - W, 0, Hp - H))
+        sh = torch.roll(pad, (-shift, -shift), (1, 2)).view(B, nwy, 7, nwx, 7).permute(0, 1, 3, 2, 4).reshape(-1)
+        assert np.array_equal(sh.long().numpy() - 1, m.astype(np.int64))
+        mm, (OH, OW) = ns["merge_rowmap"](B, H, W)
+        un = F.unfold(F.pad(idx.permute(0, 3, 1, 2), (0, W % 2, 0, H % 2)), 2, stride=2)
+        assert (OH, OW) == ((H + 1) // 2, (W + 1) // 2)
+        assert np.array_equal(un.transpose(1, 2).reshape(-1).long().numpy() - 1, mm.astype(np.int64))
