@@ -306,6 +306,52 @@ extern "C" int al3d_lss_geometry_f32(const float* frustum, int64_t points_per_ca
     return AL3D_OK;
 }
 
+// ------------------------------------------------------------------ depth distribution of the depth net
+// depth_lss.py:93-96: depth = x[:, :D].softmax(dim=1) on the depth net's output.  Here the net's map is channels-last
+// y [BN][fH][fW][ldy] (D depth logits first, then the context channels) and the pooling wants probabilities as
+// [BN][D][fH][fW]: one wave per pixel -- max, exp, sum over the D logits (D <= 256), normalise, transposed store.
+__global__ __launch_bounds__(256) void lss_depth_softmax_kernel(const float* __restrict__ y, int64_t pixels, int hw, int D, int ldy,
+                                                                float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t px = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (px >= pixels) return;                           // wave-uniform
+    const float* row = y + px * ldy;
+    float v[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int d = lane + 64 * t;
+        v[t] = d < D ? row[d] : -INFINITY;
+        mx = fmaxf(mx, v[t]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { v[t] = expf(v[t] - mx); sum += v[t]; }      // exp(-inf) = 0 for the lanes beyond D
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const int64_t img = px / hw, pos = px - img * hw;
+    float* o = out + img * (int64_t)D * hw + pos;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int d = lane + 64 * t;
+        if (d < D) o[(int64_t)d * hw] = v[t] / sum;
+    }
+}
+
+extern "C" int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW, int D, int ldy, float* out, void* stream)
+{
+    AL3D_REQUIRE(y && out && BN >= 1 && fH >= 1 && fW >= 1 && D >= 1 && D <= 256 && ldy >= D,
+                 "al3d_lss_depth_softmax_f32: bad arguments (1 <= D <= 256 <= ... ldy >= D)");
+    const int64_t pixels = (int64_t)BN * fH * fW;
+    hipLaunchKernelGGL(lss_depth_softmax_kernel, dim3((unsigned)al3d_cdiv(pixels, 4)), dim3(256), 0, (hipStream_t)stream, y, pixels,
+                       fH * fW, D, ldy, out);
+    AL3D_CHECK_LAUNCH("lss_depth_softmax_kernel");
+    return AL3D_OK;
+}
+
 // ------------------------------------------------------------------ lidar depth image of the depth-aware LSS transform
 // BaseDepthTransform.forward (bevfusion/mmdet3d/models/vtransforms/base.py:225-262): every lidar point of a sample is
 // taken back through the lidar augmentation, projected into each camera (lidar2image), through the image

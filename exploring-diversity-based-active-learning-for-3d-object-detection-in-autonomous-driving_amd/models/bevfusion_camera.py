@@ -57,6 +57,11 @@ def bev_pool(x, geom, B, dx, bx, nx, depth=None, ctx_shape=None):
     return out
 
 
+def _mat3(a, b):
+    """[..., 3, 3] x [..., 3, 3] written out (a handful of per-camera matrices: no library GEMM launch for them)."""
+    return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)
+
+
 def _versions(*mods):
     """Version counters of every parameter / buffer of ``mods``: ``load_state_dict`` and in-place edits bump them, so a
     packed-weight cache keyed on this is rebuilt after weights change."""
@@ -150,7 +155,7 @@ class LSSViewTransform(nn.Module):
         rows = torch.zeros((B * N, 44), dtype=torch.float32, device=dev)
         rows[:, 0:9] = torch.inverse(post_rots).reshape(B * N, 9)
         rows[:, 9:12] = post_trans.reshape(B * N, 3)
-        rows[:, 12:21] = camera2lidar_rots.matmul(torch.inverse(intrins)).reshape(B * N, 9)
+        rows[:, 12:21] = _mat3(camera2lidar_rots, torch.inverse(intrins)).reshape(B * N, 9)
         rows[:, 21:24] = camera2lidar_trans.reshape(B * N, 3)
         if "extra_rots" in kwargs:
             rows[:, 24:33] = kwargs["extra_rots"].reshape(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)
@@ -329,7 +334,9 @@ class DepthLSSTransform(LSSViewTransform):
         y = torch.cat([d, x.reshape(B * N, fH, fW, Cin)], dim=-1).contiguous()
         for layer in self._dn:
             y = layer(y)
-        depth = torch.softmax(y[..., :self.D], dim=-1).permute(0, 3, 1, 2).contiguous()
+        y = y.contiguous()
+        depth = torch.empty((B * N, self.D, fH, fW), dtype=torch.float32, device=y.device)
+        lib.call("al3d_lss_depth_softmax_f32", _ptr(y), B * N, fH, fW, self.D, y.shape[-1], _ptr(depth), _stream())
         return depth, y[..., self.D:self.D + self.C].contiguous()
 
     def forward(self, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix):

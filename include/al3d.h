@@ -499,6 +499,9 @@ int al3d_lss_geometry_f32(const float* frustum, int64_t points_per_camera, const
  * LAST in point order stays (the reference's indexed assignment on the CPU).  cam_rows [ncam][24] = lidar2image[:3,:3]
  * | lidar2image[:3,3] | img_aug[:3,:3] | img_aug[:3,3]; aug_rows [12] = inverse(lidar_aug[:3,:3]) | lidar_aug[:3,3]
  * (device memory).  workspace: al3d_lss_depth_image_workspace_bytes. */
+/* depth_lss.py:93-96: softmax over the D depth logits of the depth net's channels-last output y [BN][fH][fW][ldy] (logits
+ * in channels 0 .. D-1), written as [BN][D][fH][fW] probabilities for the pooling; D <= 256. */
+int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW, int D, int ldy, float* out, void* stream);
 int64_t al3d_lss_depth_image_workspace_bytes(int ncam, int iH, int iW);
 int al3d_lss_depth_image_f32(const float* points, int64_t npts, int stride, const float* cam_rows, int ncam,
                              const float* aug_rows, int iH, int iW, float* depth, void* workspace, void* stream);
