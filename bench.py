@@ -344,39 +344,35 @@ def bevfusion_lidar_leg(dev, frames=48, batch=16):
                     "synthetic frames resident in HBM, AL3D_PIPELINE as the headline"}
 
 
-def bevfusion_camera_lidar_leg(dev, batch=4, reps=3):
-    """BASELINE configs[4] on one GPU: the assembled camera+lidar model (Swin-T -> LSS-FPN -> depth LSS view transform;
-    sparse lidar encoder; ConvFuser; SECOND/SECONDFPN decoder; 512-d embedding) on synthetic inputs of the configured
-    shapes (6 cameras of 256 x 704, 0.075 m voxels) with seeded weights: frames/s of embeddings, per-stage ms per
-    sample (HIP events), and the Swin-T stage against the f16x3 matrix-core roof."""
-    from al3d import synthetic
-    from al3d.datasets import DeviceSweepLoader, PoolFrames
+def bevfusion_camera_lidar_leg(dev, frames=16, batch=4):
+    """BASELINE configs[4] on one GPU: the registered ``BEVFusion`` detector (Swin-T -> LSS-FPN -> depth LSS view transform;
+    sparse lidar encoder; ConvFuser; SECOND/SECONDFPN decoder; 512-d fused-BEV embedding; examples/active/
+    bevfusion_camera_lidar_spatial_temporal_feature.py) swept by ``sweep_embeddings`` over ``CameraLidarSweepLoader`` batches
+    of synthetic inputs of the configured shapes (6 cameras of 256 x 704, 0.075 m voxels) with seeded weights: frames/s of
+    the embedding sweep, per-stage ms per sample (HIP events, one extra forward), the Swin-T stage against the f16x3 roof."""
+    from al3d import sweep as S, synthetic
+    from al3d.datasets import CameraLidarSweepLoader, PoolFrames
     from al3d.models import build_detector
-    from al3d.models.bevfusion_model import BEVFusionCameraLidar
     from al3d.utils import Config
-    cfg = Config.fromfile(os.path.join(ROOT, "examples", "active", "bevfusion_lidar_spatial_temporal_feature.py"))
-    lidar = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-    synthetic.seeded_init_(lidar, seed=0)
-    model = BEVFusionCameraLidar(lidar, head=None)
+    cfg = Config.fromfile(os.path.join(ROOT, "examples", "active", "bevfusion_camera_lidar_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model.lidar, seed=0)
     for i, m in enumerate((model.camera_backbone, model.camera_neck, model.vtransform, model.fuser)):
         synthetic.seed_modules_(m, 30 + i)
     model = model.to(dev).eval()
-    pool = PoolFrames.from_synthetic(batch, dev, num_base=min(batch, 4), seed=1)
-    ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, None, batch, device=dev)))
-    K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = synthetic.camera_setup(batch, 6, 9, (256, 704))
-    img = torch.randn(batch, 6, 256, 704, 3, device=dev)
-    points = [pool.frames[i] for i in range(batch)]
-    a = (ex, img, points, lidar2image.to(dev), K.to(dev), cam2lidar.to(dev), img_aug.to(dev), lidar_aug.to(dev))
+    pool = PoolFrames.from_synthetic(frames, dev, num_base=min(frames, 4), seed=1)
+    loader = CameraLidarSweepLoader(pool, cfg.voxel_generator, None, batch, device=dev)
+    S.sweep_embeddings(model, loader, dev, frames)                     # warm-up: weight packing, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = S.sweep_embeddings(model, loader, dev, frames)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ex = next(iter(loader))
     with torch.no_grad():
-        model(*a)                                                      # warm-up (packs weights)
-        emb, _, _ = model(*a, timed=True)
-        stage = {k: round(v / batch, 3) for k, v in model.stage_ms.items()}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            model(*a)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        model._run(ex, ex["img"], ex["points"], ex["lidar2image"], ex["camera_intrinsics"], ex["camera2lidar"],
+                   ex["img_aug_matrix"], ex["lidar_aug_matrix"], timed=True)
+    stage = {k: round(v / batch, 3) for k, v in model.stage_ms.items()}
     swin_ms = stage.get("camera backbone (Swin-T)", 0.0)
     roof = None
     if swin_ms > 0:
@@ -386,11 +382,12 @@ def bevfusion_camera_lidar_leg(dev, batch=4, reps=3):
                 "unit": "TFLOP/s", "frac": round(ach / peak, 3),
                 "note": "algorithmic flops (194 GFLOP per sample) / stage time from HIP events; peak = dense f16 MFMA "
                         "2.5 PFLOP/s / 3 products per MAC (f16x3); the stage-0/1 GEMMs (C = 96, 192) are HBM-bound"}
-    return {"value": round(batch / dt, 2), "unit": "frames/s", "batch": batch, "ms_per_sample": stage,
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "frames": frames, "batch": batch, "ms_per_sample": stage,
             "voxels_per_frame": round(float(ex["num_voxels"].float().mean())), "finite": bool(torch.isfinite(emb).all()),
             "roofline": roof,
-            "what": "BEVFusion camera+lidar swint_v0p075 convfuser: fused-BEV embeddings, synthetic inputs, seeded weights, "
-                    "no detection head; every stage on this build's HIP kernels"}
+            "what": "BEVFusion camera+lidar swint_v0p075 convfuser: fused-BEV embedding sweep (sweep_embeddings over "
+                    "CameraLidarSweepLoader), synthetic inputs, seeded weights, no detection head; every stage on this "
+                    "build's HIP kernels"}
 
 
 def cpu_baseline(cfg, model_cpu_state, infos, feats, sample_frames=2):

@@ -113,3 +113,40 @@ class DeviceSweepLoader:
                 "anchors": self.anchors,
                 "metadata": [{"token": self.pool.tokens[i], "index": i} for i in ids],
             }
+
+
+class CameraLidarSweepLoader(DeviceSweepLoader):
+    """``DeviceSweepLoader`` + the camera side of a BEVFusion sample (``al3d.models.bevfusion_model.CAMERA_KEYS``): channels-
+    last images ``img [B, N, H, W, 3]``, the per-sample point clouds (the view transform rasterises them into the depth
+    image), and the 4 x 4 matrices ``lidar2image``, ``camera_intrinsics``, ``camera2lidar``, ``img_aug_matrix`` ``[B, N, 4, 4]``
+    and ``lidar_aug_matrix [B, 4, 4]`` (bevfusion/mmdet3d/models/fusion_models/bevfusion.py:165-205's arguments).
+
+    ``images``: ``[M, N, H, W, 3]`` float32 device tensor, frame i uses ``images[i % M]`` (a real pool would hold M = frames);
+    ``calib``: dict of the five matrices with a leading dimension of 1 (one rig) or M.  Both default to seeded synthetic
+    content (``synthetic.camera_setup``; there is no nuScenes camera data offline)."""
+
+    def __init__(self, pool, voxel_cfg, anchors, batch_size=4, indices=None, device="cuda", image_size=(256, 704),
+                 num_cameras=6, images=None, calib=None, num_image_base=4, seed=0):
+        super().__init__(pool, voxel_cfg, anchors, batch_size, indices, device)
+        self.image_size, self.num_cameras = tuple(image_size), int(num_cameras)
+        if images is None:
+            g = torch.Generator().manual_seed(seed)
+            images = torch.randn(num_image_base, self.num_cameras, *self.image_size, 3, generator=g)
+        self.images = images.to(self.device, dtype=torch.float32).contiguous()
+        if calib is None:
+            K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = synthetic.camera_setup(1, self.num_cameras, seed + 9, self.image_size)
+            calib = dict(camera_intrinsics=K, camera2lidar=cam2lidar, lidar2image=lidar2image, img_aug_matrix=img_aug,
+                         lidar_aug_matrix=lidar_aug)
+        self.calib = {k: v.to(self.device, dtype=torch.float32) for k, v in calib.items()}
+
+    def __iter__(self):
+        M = self.images.shape[0]
+        for ex in super().__iter__():
+            ids = [m["index"] for m in ex["metadata"]]
+            sel = torch.as_tensor([i % M for i in ids], device=self.device)
+            ex["img"] = self.images[sel]
+            ex["points"] = [self.pool.frames[i] for i in ids]
+            for k, v in self.calib.items():
+                rows = torch.as_tensor([i % v.shape[0] for i in ids], device=self.device)
+                ex[k] = v[rows]
+            yield ex

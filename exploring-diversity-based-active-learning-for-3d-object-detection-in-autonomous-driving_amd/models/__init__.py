@@ -10,6 +10,7 @@ from .box_coder import GroundBox3dCoderTorch, build_box_coder
 from .bevfusion_camera import ConvFuser, DepthLSSTransform, GeneralizedLSSFPN, LSSViewTransform
 from .transfusion_head import TransFusionHead
 from .swin import SwinTransformer
+from .bevfusion_model import BEVFusion, BEVFusionCameraLidar
 
 __all__ = ["READERS", "BACKBONES", "NECKS", "HEADS", "DETECTORS", "build_detector",
            "build_reader", "build_backbone", "build_neck", "build_head", "build_box_coder"]

@@ -14,7 +14,9 @@ import torch
 from torch import nn
 
 from .. import detector_ops as D
+from . import builder
 from .bevfusion_camera import ConvFuser, DepthLSSTransform, GeneralizedLSSFPN
+from .registry import DETECTORS
 from .swin import SwinTransformer
 from .transfusion_head import TransFusionHead
 
@@ -46,7 +48,14 @@ class BEVFusionCameraLidar(nn.Module):
     def forward(self, example, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix,
                 timed=False):
         """example: the lidar batch (``DeviceSweepLoader`` dict); img [B,N,H,W,3] channels-last.
-        -> (embedding [B,512], decoder map [B,180,180,512], head predictions or None)."""
+        -> (embedding [B,512], decoder map [B,180,180,512], decoded boxes per sample or None)."""
+        emb, dec, preds = self._run(example, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix,
+                                    lidar_aug_matrix, timed=timed)
+        return emb, dec, (None if preds is None else self.head.get_bboxes(preds))
+
+    def _run(self, example, img, points, lidar2image, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix,
+             book=None, timed=False):
+        """-> (embedding, decoder map, raw head predictions or None)."""
         B, N = img.shape[:2]
         marks = []
 
@@ -64,7 +73,7 @@ class BEVFusionCameraLidar(nn.Module):
             side = self._side_stream(img.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                lidar_bev, _ = self.lidar.sparse_stage(example)
+                lidar_bev, _ = self.lidar.sparse_stage(example, book=book)
                 lidar_bev.record_stream(main)
         feats = self.camera_backbone(img.reshape(B * N, *img.shape[2:]))
         mark("camera backbone (Swin-T)")
@@ -75,7 +84,7 @@ class BEVFusionCameraLidar(nn.Module):
         cam = cam.permute(0, 2, 1, 3).contiguous()                   # [x, y] -> this build's [H=y, W=x]
         mark("view transform (depth LSS)")
         if lidar_bev is None:
-            lidar_bev, _ = self.lidar.sparse_stage(example)
+            lidar_bev, _ = self.lidar.sparse_stage(example, book=book)
         else:
             torch.cuda.current_stream(img.device).wait_stream(self._side_stream(img.device))
         mark("lidar encoder")
@@ -88,8 +97,9 @@ class BEVFusionCameraLidar(nn.Module):
         mark("decoder + embedding")
         preds = None
         if self.head is not None:
-            out = self.head(dec)
-            preds = self.head.get_bboxes(out)
+            preds = self.head(dec)
+            if timed:
+                self.head.get_bboxes(preds)            # the decode is part of the stage's time
             mark("TransFusionHead")
         if timed:
             torch.cuda.synchronize()
@@ -108,3 +118,55 @@ def transfusion_head_for(grid=1440, in_channels=512):
                       pc_range=[-54.0, -54.0], nms_type=None),
         bbox_coder=dict(pc_range=[-54.0, -54.0], post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
                         score_threshold=0.0, out_size_factor=8, voxel_size=[0.075, 0.075], code_size=10))
+
+
+CAMERA_KEYS = ("img", "points", "lidar2image", "camera_intrinsics", "camera2lidar", "img_aug_matrix", "lidar_aug_matrix")
+
+
+@DETECTORS.register_module
+class BEVFusion(BEVFusionCameraLidar):
+    """The camera+lidar model behind the det3d detector contract, so that the selectors and ``tools/active_select.py`` sweep
+    it like any other detector (BASELINE configs[4]; reference flow ``fusion_models/bevfusion.py:207-305`` ->
+    ``heads/bbox/transfusion.py:714-851``; the reference itself has no selector hook under ``bevfusion/``).
+
+    ``BEVFusion(lidar=<FPNVoxelNet cfg without head>, bbox_head=<TransFusionHead cfg or None>, image_size=..., ...)``;
+    ``detector(example, return_loss=False, estimate=True)`` -> ``(list[dict(box3d_lidar, scores, label_preds, metadata)],
+    middle)`` with ``middle[-1]`` the decoder map (its ``mean(-1).mean(-1)`` is the fused-BEV embedding).  ``example`` is
+    the lidar batch of ``DeviceSweepLoader`` plus the camera side (``CAMERA_KEYS``: channels-last images ``[B,N,H,W,3]``,
+    per-sample point clouds, the 4 x 4 calibration / augmentation matrices; ``al3d.datasets.CameraLidarSweepLoader``)."""
+
+    def __init__(self, lidar, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None, **kwargs):
+        lidar_det = builder.build_detector(lidar, train_cfg=train_cfg, test_cfg=test_cfg) if isinstance(lidar, dict) else lidar
+        head = builder.build_head(bbox_head) if isinstance(bbox_head, dict) else bbox_head
+        super().__init__(lidar_det, head=head, **kwargs)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    @property
+    def bbox_head(self):
+        return self.head
+
+    def prepare(self, example):
+        """Index work of the lidar half (sparse-conv rulebook), run one batch ahead by the sweep."""
+        return self.lidar.prepare(example)
+
+    def forward(self, example, return_loss=True, finetune=False, book=None, **kwargs):
+        if return_loss:
+            raise NotImplementedError("al3d implements the inference sweep, not training")
+        missing = [k for k in CAMERA_KEYS if k not in example]
+        if missing:
+            raise KeyError(f"BEVFusion: the example lacks the camera side {missing} (use CameraLidarSweepLoader)")
+        from .detectors import NHWCFeature
+        emb, dec, preds = self._run(example, example["img"], example["points"], example["lidar2image"],
+                                    example["camera_intrinsics"], example["camera2lidar"], example["img_aug_matrix"],
+                                    example["lidar_aug_matrix"], book=book)
+        metas = example.get("metadata", None) or [None] * dec.shape[0]
+        if self.head is None:
+            if not kwargs.get("estimate", False):
+                raise RuntimeError("this detector was built without a bbox_head: only the estimate=True embedding sweep "
+                                   "is available")
+            out = [dict(metadata=m) for m in metas]
+        else:
+            out = self.head.predict(example, preds, self.test_cfg)
+        if kwargs.get("estimate", False):
+            return out, [NHWCFeature(dec, emb)]
+        return out

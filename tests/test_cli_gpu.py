@@ -45,3 +45,22 @@ def test_cli_with_the_bevfusion_lidar_config(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
     out = json.load(open(tmp_path / "data" / "buffers" / "bevfusion_lidar_stf.json"))
     assert list(out) == ["0", "20"] and len(out["20"]) >= 5 and all(0 <= i < 40 for i in out["20"])
+
+
+@pytest.mark.parametrize("config,buffer", [("bevfusion_camera_lidar_spatial_temporal_feature.py", "bevfusion_camera_lidar_stf.json"),
+                                           ("bevfusion_camera_lidar_entropy.py", "bevfusion_camera_lidar_entropy.json"),
+                                           ("bevfusion_lidar_entropy.py", "bevfusion_lidar_entropy.json")])
+def test_cli_with_the_bevfusion_detector_configs(tmp_path, config, buffer):
+    """The same two-invocation flow on BASELINE configs[4] (the registered ``BEVFusion`` camera+lidar detector over
+    ``CameraLidarSweepLoader`` batches: fused-BEV embeddings, and with the TransFusionHead under the EntropySelector) and on the
+    lidar-only detector with its head (configs[3])."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "active_select.py"), "--config",
+           os.path.join(ROOT, "examples", "active", config), "--budget", "20", "--pred", "--synthetic-scenes", "1",
+           "--batch", "4"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for _ in range(2):
+        r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+    out = json.load(open(tmp_path / "data" / "buffers" / buffer))
+    assert list(out) == ["0", "20"] and len(out["20"]) >= 5 and all(0 <= i < 40 for i in out["20"])
+    assert len(set(out["20"])) == len(out["20"])

@@ -78,14 +78,16 @@ def main():
             fileio.dump(logs, os.path.join(os.path.dirname(sel_cfg.infos_origin), "log.json"))
         if distributed:
             torch.distributed.barrier()
-        sel_cfg["logs_file"] = os.path.join(os.path.dirname(sel_cfg.infos_origin), "log.json")
-        sel_cfg.setdefault("distance_store_file", None)
-        # the selectors' own defaults for their caches are the reference authors' absolute paths
-        # (spatial_temporal_feature_selector.py:24, feature_selector.py:20, ...): a synthetic run keeps them next
-        # to the buffer file instead
         import inspect
         from al3d.selectors import SELECTORS
         accepted = inspect.signature(SELECTORS.get(sel_cfg.type).__init__).parameters
+        if "logs_file" in accepted:                     # the map selectors; the uncertainty selectors take no scene logs
+            sel_cfg["logs_file"] = os.path.join(os.path.dirname(sel_cfg.infos_origin), "log.json")
+        if "distance_store_file" in accepted:
+            sel_cfg.setdefault("distance_store_file", None)
+        # the selectors' own defaults for their caches are the reference authors' absolute paths
+        # (spatial_temporal_feature_selector.py:24, feature_selector.py:20, ...): a synthetic run keeps them next
+        # to the buffer file instead
         for key, name in (("buffer_path", "feature_pred.pt"), ("weighted_feat_path", "weighted_feature_pred.pt")):
             if key in accepted:
                 sel_cfg.setdefault(key, os.path.join(os.path.dirname(sel_cfg.buffer_file) or ".", name))
@@ -120,7 +122,18 @@ def main():
         head_cfg = cfg.model.get("bbox_head")
         anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128]) \
             if head_cfg is not None and head_cfg.get("type") == "MultiGroupHead" else None      # TransFusionHead is anchor-free
-        if args.synthetic_scenes:
+        if args.synthetic_scenes and cfg.model.get("type") == "BEVFusion":
+            # camera+lidar: the lidar batch plus synthetic six-camera images and one calibration rig (configs[4])
+            from al3d.datasets import CameraLidarSweepLoader
+            pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
+            cam = cfg.get("camera", {})
+            loader = CameraLidarSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev,
+                                            image_size=tuple(cam.get("image_size", (256, 704))),
+                                            num_cameras=int(cam.get("num_cameras", 6)))
+        elif cfg.model.get("type") == "BEVFusion":
+            raise SystemExit("BEVFusion camera+lidar pools need decoded camera images: only --synthetic-scenes is wired "
+                             "(hand CameraLidarSweepLoader your own `images` / `calib` tensors from Python)")
+        elif args.synthetic_scenes:
             pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
             loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
         else:
