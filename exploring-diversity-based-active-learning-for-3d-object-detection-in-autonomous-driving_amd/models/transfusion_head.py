@@ -236,8 +236,14 @@ class TransFusionHead(nn.Module):
     def __init__(self, num_proposals=128, auxiliary=True, in_channels=128 * 3, hidden_channel=128, num_classes=4,
                  num_decoder_layers=3, num_heads=8, nms_kernel_size=1, ffn_channel=256, dropout=0.1, bn_momentum=0.1,
                  activation="relu", common_heads=None, num_heatmap_convs=2, test_cfg=None, bbox_coder=None,
-                 transpose_input=False, **_unused):
+                 transpose_input=False, class_names=None, **_unused):
         super().__init__()
+        # det3d heads carry their class names grouped by task (mg_head.py:364); the BEVFusion configs list
+        # ``object_classes`` once for the whole model -- default: the ten nuScenes classes in the reference's order
+        # (bevfusion/configs/nuscenes/default.yaml)
+        names = class_names or ["car", "truck", "construction_vehicle", "bus", "trailer", "barrier", "motorcycle", "bicycle",
+                                "pedestrian", "traffic_cone"][:num_classes]
+        self.class_names = [list(names)] if names and isinstance(names[0], str) else [list(g) for g in names]
         # The reference's BEV maps are [x, y] (rows = x); this build's detector maps are [H = y, W = x].  With
         # ``transpose_input`` the head transposes the map it is handed, so that its 3x3 kernels, the BEV position grid
         # and the decoded (x, y) keep the reference's meaning when it sits behind this build's necks.

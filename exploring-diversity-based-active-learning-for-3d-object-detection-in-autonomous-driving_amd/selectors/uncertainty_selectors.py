@@ -250,7 +250,11 @@ class PPALSelector(_WeightedFeatureSelector):
                 example = example_to_device(batch, device)
                 preds, middle = self.detector(example, return_loss=False, estimate=True)
                 emb = gap_embedding(middle[-1])
-                ents.append(preds.frame_weighted_entropy(cw))
+                if hasattr(preds, "frame_weighted_entropy"):
+                    ents.append(preds.frame_weighted_entropy(cw))
+                else:                                   # plain per-frame dicts (e.g. TransFusionHead.predict)
+                    from ..sweep import _weighted_entropy_of
+                    ents.append(torch.stack([_weighted_entropy_of(p["scores"], p["label_preds"], cw) for p in preds]))
                 feats.append(emb)
                 b = emb.shape[0]
                 index.extend(sampler[seen:seen + b] if sampler else range(seen, seen + b))

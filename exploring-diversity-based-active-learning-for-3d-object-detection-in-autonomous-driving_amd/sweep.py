@@ -250,3 +250,15 @@ def _entropy_of(scores):
     if s.shape[2] == 0:
         return torch.full((), float("nan"), device=s.device)
     return ops.frame_entropy(s, cnt)[0]
+
+
+def _weighted_entropy_of(scores, labels, class_weight):
+    """Per-frame sum of binary entropy x class weight of the frame's boxes (ppal_selector.py:99-109) for detectors that
+    return plain dict lists; a frame without detections gives the empty sum 0."""
+    from . import selector_ops as ops
+    s = scores.float().contiguous().view(1, 1, -1)
+    if s.shape[2] == 0:
+        return torch.zeros((), device=s.device)
+    lab = labels.to(torch.int32).contiguous().view(1, 1, -1)
+    cnt = torch.tensor([[s.shape[2]]], dtype=torch.int32, device=s.device)
+    return ops.frame_weighted_entropy(s, lab, cnt, class_weight)[0]

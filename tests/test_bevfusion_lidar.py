@@ -181,3 +181,46 @@ def test_entropy_selector_end_to_end_on_the_lidar_detector(tmp_path):
     order = np.argsort(-ent.cpu().numpy(), kind="stable").tolist()
     assert len(picked) >= 1 and picked == order[:len(picked)]
     assert torch.equal(torch.load(str(tmp_path / "entropy.pt"), weights_only=True), ent.cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", ["BadgeSelector", "UWESelector", "PPALSelector"])
+def test_weighted_feature_selectors_run_on_the_lidar_detector(cls, tmp_path):
+    """The embedding x uncertainty selectors (badge / uwe / ppal) on the BEVFusion lidar-only detector with its TransFusionHead:
+    they read per-frame ``scores`` / ``label_preds`` from plain dict predictions (the sweep's fallbacks) and the head's
+    ``class_names``; property checks on the picks (distinct, within the pool, cost within the budget)."""
+    import json
+    import pickle
+    import random
+    from al3d import synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames
+    from al3d.models import build_detector
+    from al3d.selectors import build_selector
+    from al3d.utils import Config
+    cfg = Config.fromfile(os.path.join(ROOT, "examples", "active", "bevfusion_lidar_entropy.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    n = 8
+    pool = PoolFrames.from_synthetic(n, DEV, num_base=4, seed=11)
+    loader = DeviceSweepLoader(pool, cfg.voxel_generator, None, 2, device=DEV)
+    loader.sampler = list(range(n))
+    infos, _ = synthetic.make_pool(1, seed=0)
+    infos = infos[:n]
+    ip, bp = str(tmp_path / "infos.pkl"), str(tmp_path / "buffer.json")
+    pickle.dump(infos, open(ip, "wb"))
+    json.dump({"0": [], "1": [1]}, open(bp, "w"))     # a previous round: these selectors need a non-empty buffer (reference quirk)
+    # PPAL's candidate loop has no pool bound (reference quirk): keep its expanded budget below the 8-frame pool's cost
+    kw = dict(type=cls, budget=1 if cls == "PPALSelector" else 5, buffer_file=bp, infos_origin=ip, detector=model, dataloader=loader, pred=True,
+              distance_store_file=None)
+    if cls in ("BadgeSelector", "UWESelector"):
+        kw.update(weighted_feat_path=str(tmp_path / "wf.pt"))
+    else:
+        cw = str(tmp_path / "cw.json")
+        json.dump({c: 1.0 + 0.1 * i for i, c in enumerate(model.bbox_head.class_names[0])}, open(cw, "w"))
+        kw.update(feat_path=str(tmp_path / "pf.pt"), ent_path=str(tmp_path / "pe.pt"), class_weight_file=cw)
+    random.seed(3407)
+    sel = build_selector(kw)
+    sel.select_samples(local_rank=0)
+    picked = sel.get_selected_samples()[sel.current_budget]
+    assert 2 <= len(picked) <= n and len(set(picked)) == len(picked) and all(0 <= i < n for i in picked) and 1 in picked
