@@ -152,6 +152,9 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
     __shared__ unsigned s_prefix, s_need, s_sel_cnt, s_eq_seen;
     __shared__ unsigned long long key_s[HN_MAXK];       // (score bits << 32) | ~anchor
     __shared__ float cx_s[HN_MAXK][4], cy_s[HN_MAXK][4];
+    // per-wave histograms of the select passes: 16 x 256 words in cx_s's storage (free until the decode phase)
+    unsigned (*hist_w)[256] = reinterpret_cast<unsigned (*)[256]>(&cx_s[0][0]);
+    static_assert(sizeof(cx_s) >= (HN_THREADS / 64) * 256 * sizeof(unsigned), "histograms must fit cx_s");
     __shared__ float sb_s[HN_MAXK][4];                  // standup box x1,y1,x2,y2
     __shared__ float area_s[HN_MAXK];
     __shared__ int keep_s[128];
@@ -175,6 +178,8 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         for (int q = tid; q < 256; q += HN_THREADS) hist[q] = 0;
+        if (pass > 0)
+            for (int q = tid; q < (HN_THREADS / 64) * 256; q += HN_THREADS) (&hist_w[0][0])[q] = 0;
         __syncthreads();
         // four chunks of anchors per trip: the four loads are issued together (one L2 round trip per trip instead of
         // one per chunk -- the ballots below keep the compiler from overlapping trips by itself)
@@ -193,16 +198,37 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
             // scores of one task share their leading bits (all in (0.1, 1)): a plain per-thread atomicAdd serialises
             // ~A deep on one LDS word.  Aggregate per wave: one atomic per distinct bin and wave.
             unsigned long long pending = __ballot(bin >= 0);
-            while (pending) {
+            if (pass == 0) {
+                while (pending) {
+                    const int leader = (int)__builtin_ctzll(pending);
+                    const int lb = __builtin_amdgcn_readlane(bin, leader);
+                    const unsigned long long same = __ballot(bin == lb);
+                    if ((tid & 63) == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+                    pending &= ~same;
+                }
+            } else if (pending) {
+                // Later bytes are mantissa bits: a wave's 64 entries spread over ~50 distinct bins, and the aggregation loop
+                // above would run once per distinct bin (it was most of this kernel's time on a pool where every anchor
+                // passes the score threshold).  One aggregated round for the first lane's bin (covers the massive-tie
+                // case), the other lanes add to their wave's private histogram with plain LDS atomics.
                 const int leader = (int)__builtin_ctzll(pending);
                 const int lb = __builtin_amdgcn_readlane(bin, leader);
                 const unsigned long long same = __ballot(bin == lb);
-                if ((tid & 63) == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
-                pending &= ~same;
+                if ((tid & 63) == leader) atomicAdd(&hist_w[tid >> 6][lb], (unsigned)__popcll(same));
+                if (bin >= 0 && bin != lb) atomicAdd(&hist_w[tid >> 6][bin], 1u);
             }
           }
         }
         __syncthreads();
+        if (pass > 0) {                                  // fold the per-wave histograms
+            for (int q = tid; q < 256; q += HN_THREADS) {
+                unsigned tot = 0;
+#pragma unroll
+                for (int w = 0; w < HN_THREADS / 64; ++w) tot += hist_w[w][q];
+                hist[q] = tot;
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
             unsigned acc = 0; int bin = 255;
             for (; bin >= 0; --bin) { if (acc + hist[bin] >= need) break; acc += hist[bin]; }
