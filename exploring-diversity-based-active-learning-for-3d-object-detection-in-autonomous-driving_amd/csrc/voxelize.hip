@@ -57,14 +57,17 @@ __global__ void vox_first_kernel(const float* __restrict__ pts, const int64_t* _
 }
 
 // pass 2: leader flags
+// also records every point's leader (plead: pass 4 then needs no second random probe of the 22 GB grid)
 __global__ void vox_flag_kernel(const int64_t* __restrict__ off, int B, int64_t cells,
                                 const int* __restrict__ first, const int* __restrict__ pframe,
-                                const int* __restrict__ pcell, int* __restrict__ flag)
+                                const int* __restrict__ pcell, int* __restrict__ flag, int* __restrict__ plead)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= off[B]) return;
     const int cell = pcell[i], b = pframe[i];
-    flag[i] = (cell >= 0 && first[(int64_t)b * cells + cell] == (int)(i - off[b])) ? 1 : 0;
+    const int lead = cell >= 0 ? first[(int64_t)b * cells + cell] : -1;
+    plead[i] = lead;
+    flag[i] = (cell >= 0 && lead == (int)(i - off[b])) ? 1 : 0;
 }
 
 // pass 3: voxels per frame, row bases (frames are concatenated in the outputs)
@@ -87,8 +90,9 @@ __global__ void vox_base_kernel(const int64_t* __restrict__ off, int B, const in
 }
 
 // pass 4: output row per point (or -1), coordinates of kept voxels, points per voxel
+// prow holds the point's leader on entry (vox_flag_kernel) and its output row on exit (same thread, same word)
 __global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg c, int64_t cells,
-                                  const int* __restrict__ first, const int* __restrict__ pframe,
+                                  const int* __restrict__ pframe,
                                   const int* __restrict__ pcell, const int* __restrict__ lscan,
                                   const int* __restrict__ row_base, int* __restrict__ prow,
                                   int* __restrict__ ppos, int* __restrict__ coords, int* __restrict__ cnt)
@@ -98,7 +102,7 @@ __global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg
     const int cell = pcell[i], b = pframe[i];
     int row = -1, pos = 0;
     if (cell >= 0) {
-        const int lead = first[(int64_t)b * cells + cell];
+        const int lead = prow[i];
         const int vid = lscan[off[b] + lead] - lscan[off[b]];
         if (vid < c.max_voxels) {
             row = row_base[b] + vid;
@@ -217,13 +221,13 @@ __global__ void vox_gather_kernel(const float* __restrict__ pts, VoxCfg c, int r
 }
 
 // pass 7: put the touched cells of the first-index grid back to EMPTY
+// one write per occupied cell: its leader restores it (every point of the cell used to)
 __global__ void vox_restore_kernel(int64_t npts, int64_t cells, const int* __restrict__ pframe,
-                                   const int* __restrict__ pcell, int* __restrict__ first)
+                                   const int* __restrict__ pcell, const int* __restrict__ flag, int* __restrict__ first)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npts) return;
-    const int cell = pcell[i];
-    if (cell >= 0) first[(int64_t)pframe[i] * cells + cell] = VX_EMPTY;
+    if (flag[i]) first[(int64_t)pframe[i] * cells + pcell[i]] = VX_EMPTY;
 }
 
 __global__ void vox_fill_i32(int* p, int64_t n, int v)
@@ -296,12 +300,12 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
     hipLaunchKernelGGL(vox_first_kernel, dim3(pb), dim3(256), 0, s, points, point_offsets, B, c, cells,
                        first, pframe, pcell);
     hipLaunchKernelGGL(vox_flag_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, cells, first, pframe,
-                       pcell, flag);
+                       pcell, flag, prow);
     int rc = al3d_exclusive_scan_i32(flag, lscan, npts, scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_base_kernel, dim3(1), dim3(64), 0, s, point_offsets, B, lscan, flag, max_voxels,
                        num_voxels, row_base);
-    hipLaunchKernelGGL(vox_assign_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, c, cells, first,
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, c, cells,
                        pframe, pcell, lscan, row_base, prow, ppos, coords, cnt);
     rc = al3d_exclusive_scan_i32(cnt, boff, rows + 1, scan_ws, s);
     if (rc) return rc;
@@ -312,7 +316,7 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
     else
         hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s, points, c,
                            (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);
-    hipLaunchKernelGGL(vox_restore_kernel, dim3(pb), dim3(256), 0, s, npts, cells, pframe, pcell, first);
+    hipLaunchKernelGGL(vox_restore_kernel, dim3(pb), dim3(256), 0, s, npts, cells, pframe, pcell, flag, first);
     AL3D_CHECK_LAUNCH("voxelize");
     return AL3D_OK;
 }
