@@ -32,6 +32,18 @@ from .bevfusion_camera import _versions
 from .registry import BACKBONES
 
 
+import os as _os
+SWIN_STREAMS = int(_os.environ.get("AL3D_SWIN_STREAMS", "1"))
+_STREAMS = {}
+
+
+def _stream_pool(device, i):
+    key = (torch.device(device).index or 0, i)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device)
+    return _STREAMS[key]
+
+
 class _Packed:
     """Per-module cache of kernel-format weights, rebuilt when the device or a parameter changes."""
 
@@ -245,6 +257,27 @@ class SwinTransformer(nn.Module):
     def forward(self, x):
         if self.training:
             raise RuntimeError("al3d SwinTransformer implements the eval() path only")
+        n = SWIN_STREAMS
+        if n > 1 and x.is_cuda and x.shape[0] >= 2 * n:
+            # Images are independent: run the batch as n chunks on n streams.  The stage-0 / stage-1 GEMMs spend ~40 % of
+            # their time in a store tail that keeps a workgroup's LDS and registers but no pipe busy; with a
+            # second launch queue the other chunk's kernels run in those holes.
+            main = torch.cuda.current_stream(x.device)
+            chunks = torch.chunk(x, n, dim=0)
+            outs = []
+            for i, c in enumerate(chunks):
+                st = _stream_pool(x.device, i)
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs.append(self._forward_one(c.contiguous()))
+            for i, o in enumerate(outs):
+                main.wait_stream(_stream_pool(x.device, i))
+                for t in o:
+                    t.record_stream(main)
+            return tuple(torch.cat([o[l] for o in outs], dim=0) for l in range(len(outs[0])))
+        return self._forward_one(x)
+
+    def _forward_one(self, x):
         B = x.shape[0]
         x, hw_shape = self.patch_embed(x)
         outs = []
