@@ -1,5 +1,5 @@
 """Dev tool: the token GEMM on the Swin-T layer shapes (4 samples = 24 images of 256 x 704).
-  [AL3D_TOK_ABLATE=1|2] python tools/bench_tok_gemm.py"""
+  python tools/bench_tok_gemm.py     (the ablation numbers in DESIGN.md 5.3 came from dev builds of csrc/tokens.hip)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
