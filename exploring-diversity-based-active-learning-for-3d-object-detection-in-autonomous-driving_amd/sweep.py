@@ -82,6 +82,18 @@ _SIDE = {}
 SIDE_AFTER_SPARSE = _os.environ.get("AL3D_SIDE_AFTER_SPARSE", "0") == "1"
 
 
+# AL3D_MAIN_PRIORITY=1: the main (convolution) work runs on a high-priority HIP stream
+MAIN_PRIORITY = _os.environ.get("AL3D_MAIN_PRIORITY", "0") == "1"
+_HP = {}
+
+
+def _hp_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _HP:
+        _HP[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _HP[key]
+
+
 # AL3D_SIDE_CUS=n: the side stream may use only n compute units (hipExtStreamCreateWithCUMask); 0 = all
 SIDE_CUS = int(_os.environ.get("AL3D_SIDE_CUS", "0"))
 
@@ -172,7 +184,13 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
             # stream is enqueued FIRST (it contains no host synchronisation), then the host turns to
             # the side stream, whose row-count read-backs it may wait on while the device keeps
             # working on the main stream.
-            main = torch.cuda.current_stream(device)
+            caller = torch.cuda.current_stream(device)
+            main = caller
+            if MAIN_PRIORITY:
+                # the convolutions on a HIGH-priority stream: the hardware then hands CU slots to their waves first and the
+                # side stream's index work fills what is left, instead of both competing at equal priority
+                main = _hp_stream(device)
+                main.wait_stream(caller)
             side = _side_stream(device)
             side.wait_stream(main)
             pending = None
@@ -180,6 +198,7 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
             it = iter(dataloader)
             while True:
                 if pending is not None:
+                  with torch.cuda.stream(main):
                     example, ahead, ev = pending
                     main.wait_event(ev)
                     if mode == "ahead" and SIDE_AFTER_SPARSE and hasattr(detector, "dense_stage"):
@@ -218,6 +237,10 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                     ev.record(side)
                 pending = (example, ahead, ev)
             main.wait_stream(side)
+            if main is not caller:
+                caller.wait_stream(main)
+                for t in feats + ents:
+                    t.record_stream(caller)
     local = torch.cat(feats, dim=0)
     idx = torch.as_tensor(index, dtype=torch.int64, device=local.device)
     n = num_frames if num_frames is not None else int(idx.max().item()) + 1
