@@ -171,6 +171,101 @@ __global__ __launch_bounds__(256) void bev_sum_kernel(const float* __restrict__ 
     (void)nz;
 }
 
+// The same sums with lanes = float4 channel groups and SEVERAL cells per wave (C % 4 == 0: the shipped shapes, C = 80).
+// G = C / 4 lanes own one cell (three cells per wave at C = 80), so one wave-instruction adds one member to up to
+// four cells instead of 64 lanes adding one member to one cell in ceil(C / 64) rounds; the member list of a cell is
+// put in ascending point order in LDS (rank counting inside the lane group; long lists arrive sorted from
+// bev_sort_long_kernel, 128 at a time) together with what the inner loop needs per member -- the context row and
+// the depth value -- computed ONCE per member by one lane (the generic kernel above divides p by D*fH*fW and fH*fW
+// in every lane for every member: it is bound by those integer divisions).  Same products, same order of additions
+// per (cell, channel): bit-identical to bev_sum_kernel.
+#define BEV_CPW 4                                                // cells per wave at most
+template <int LSS>
+__global__ __launch_bounds__(256) void bev_sum_vec_kernel(const float* __restrict__ x, const float* __restrict__ depth,
+                                                          int C, int G, int CPW, int Dd, int fHW,
+                                                          const int* __restrict__ count, const int* __restrict__ start,
+                                                          const int* __restrict__ list, const int* __restrict__ sorted,
+                                                          int ncell, float* __restrict__ out)
+{
+    __shared__ int s_key[4][BEV_CPW][BEV_SHORT];
+    __shared__ int s_row[4][BEV_CPW][BEV_SHORT];
+    __shared__ float s_dep[4][BEV_CPW][BEV_SHORT];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int grp = lane / G, sub = lane - grp * G;
+    const int64_t cell = ((int64_t)blockIdx.x * 4 + w) * CPW + grp;
+    const bool own = grp < CPW && cell < ncell;
+    const int len = own ? count[cell] : 0, base = own ? start[cell] : 0;
+    int maxlen = 0;
+    for (int g = 0; g < CPW; ++g) { const int l = __shfl(len, g * G); maxlen = l > maxlen ? l : maxlen; }
+    const int gi = grp < CPW ? grp : 0;
+    int* key = s_key[w][gi];
+    int* rowv = s_row[w][gi];
+    float* depv = s_dep[w][gi];
+    const int ddfhw = Dd * fHW;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = 0; c0 < maxlen; c0 += BEV_SHORT) {
+        int clen = len - c0;
+        clen = clen < 0 ? 0 : (clen > BEV_SHORT ? BEV_SHORT : clen);
+        if (len <= BEV_SHORT) {
+            for (int e = sub; e < clen; e += G) key[e] = list[base + e];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int e = sub; e < clen; e += G) {
+                const int v = key[e];
+                int rank = 0;
+                for (int j = 0; j < clen; ++j) rank += key[j] < v ? 1 : 0;
+                if (LSS) {
+                    const int bn = v / ddfhw, pix = v % fHW;
+                    rowv[rank] = bn * fHW + pix;
+                    depv[rank] = depth[v];
+                } else {
+                    rowv[rank] = v;
+                }
+            }
+        } else {
+            for (int e = sub; e < clen; e += G) {
+                const int v = sorted[base + c0 + e];
+                if (LSS) {
+                    const int bn = v / ddfhw, pix = v % fHW;
+                    rowv[e] = bn * fHW + pix;
+                    depv[e] = depth[v];
+                } else {
+                    rowv[e] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        int cmax = 0;
+        for (int g = 0; g < CPW; ++g) { const int l = __shfl(clen, g * G); cmax = l > cmax ? l : cmax; }
+        for (int i = 0; i < cmax; i += 4) {
+            float4 t[4];
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                d[u] = 0.f;
+                if (i + u < clen) {
+                    t[u] = *reinterpret_cast<const float4*>(x + (int64_t)rowv[i + u] * C + sub * 4);
+                    if (LSS) d[u] = depv[i + u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u < clen) {
+                    if (LSS) {
+                        acc.x += d[u] * t[u].x; acc.y += d[u] * t[u].y; acc.z += d[u] * t[u].z; acc.w += d[u] * t[u].w;
+                    } else {
+                        acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w;
+                    }
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (own) *reinterpret_cast<float4*>(out + cell * C + sub * 4) = acc;
+}
+
 extern "C" int64_t al3d_bev_pool_workspace_bytes(int64_t n_points, int64_t n_cells)
 {
     const int64_t p = n_points > 0 ? n_points : 1, c = n_cells > 0 ? n_cells : 1;
@@ -213,7 +308,16 @@ static int bev_pool_run(const float* x, const float* depth, int lss, int Dd, int
     hipLaunchKernelGGL(bev_scatter_kernel, dim3(pblocks), dim3(256), 0, s, cell, P, start, fill, list);
     const unsigned cblocks = (unsigned)al3d_cdiv(ncell, 4);
     hipLaunchKernelGGL(bev_sort_long_kernel, dim3(1024), dim3(256), 0, s, count, start, list, sorted, ncell);
-    if (lss)
+    if (C % 4 == 0 && C / 4 <= 64 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        const int G = C / 4, CPW = 64 / G < BEV_CPW ? 64 / G : BEV_CPW;
+        const unsigned vblocks = (unsigned)al3d_cdiv(ncell, 4 * CPW);
+        if (lss)
+            hipLaunchKernelGGL(bev_sum_vec_kernel<1>, dim3(vblocks), dim3(256), 0, s, x, depth, C, G, CPW, Dd, fHW, count, start,
+                               list, sorted, ncell, out);
+        else
+            hipLaunchKernelGGL(bev_sum_vec_kernel<0>, dim3(vblocks), dim3(256), 0, s, x, depth, C, G, CPW, Dd, fHW, count, start,
+                               list, sorted, ncell, out);
+    } else if (lss)
         hipLaunchKernelGGL(bev_sum_kernel<1>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, count, start, list,
                            sorted, ncell, nx[2], out);
     else

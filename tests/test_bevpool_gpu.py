@@ -18,11 +18,12 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
+@pytest.mark.parametrize("C", [80, 6, 128, 256, 4])          # float4 lane groups (3 / 2 / 1 / 4 cells per wave) and the generic kernel (6)
 @pytest.mark.parametrize("case", ["random", "crowded", "empty", "all_outside"])
-def test_bev_pool_bit_exact_vs_oracle(oracle, case):
+def test_bev_pool_bit_exact_vs_oracle(oracle, case, C):
     from al3d.models.bevfusion_camera import bev_pool
     rng = np.random.default_rng(5)
-    B, C = 2, 80
+    B = 2
     nx, dx, bx = np.array([24, 20, 2]), np.array([0.5, 0.5, 4.0], np.float32), np.array([-5.75, -4.75, -2.0], np.float32)
     P = {"random": 40000, "crowded": 9000, "empty": 0, "all_outside": 64}[case]
     geom = np.stack([rng.uniform(-7, 7, P), rng.uniform(-6, 6, P), rng.uniform(-5, 5, P)], 1).astype(np.float32)
