@@ -315,7 +315,7 @@ def from_files_leg(cfg, model, anchors, n_frames, batch, dev):
 SWIN_T_GFLOP_PER_SAMPLE = 194.0   # 6 cameras of 256 x 704: token GEMMs 187 + window attention 7 (2*MAC)
 
 
-def bevfusion_lidar_leg(dev, frames=48, batch=16):
+def bevfusion_lidar_leg(dev, frames=96, batch=32):
     """BASELINE configs[3] on one GPU (pattern: bevfusion/tools/benchmark.py:52-84, warm-up then timed iterations):
     the BEVFusion lidar-only voxelnet_0p075 embedding sweep -- 0.075 m voxels, 1440 x 1440 x 41 grid, 160k-voxel cap --
     over a small resident synthetic pool; frames/s of the sweep (no selection)."""
@@ -344,7 +344,7 @@ def bevfusion_lidar_leg(dev, frames=48, batch=16):
                     "synthetic frames resident in HBM, AL3D_PIPELINE as the headline"}
 
 
-def bevfusion_camera_lidar_leg(dev, frames=16, batch=4):
+def bevfusion_camera_lidar_leg(dev, frames=48, batch=16):
     """BASELINE configs[4] on one GPU: the registered ``BEVFusion`` detector (Swin-T -> LSS-FPN -> depth LSS view transform;
     sparse lidar encoder; ConvFuser; SECOND/SECONDFPN decoder; 512-d fused-BEV embedding; examples/active/
     bevfusion_camera_lidar_spatial_temporal_feature.py) swept by ``sweep_embeddings`` over ``CameraLidarSweepLoader`` batches
