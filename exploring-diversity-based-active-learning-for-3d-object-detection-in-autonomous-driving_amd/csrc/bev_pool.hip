@@ -456,6 +456,75 @@ extern "C" int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW
     return AL3D_OK;
 }
 
+// ------------------------------------------------------------------ first two layers of the depth branch, fused
+// depth_lss.py:38-44: dtransform = Conv2d(1, 8, 1) + BN + ReLU -> Conv2d(8, 32, 5, stride 4, padding 2) + BN + ReLU on
+// the [BN, 1, iH, iW] lidar depth image.  As two convolutions that is a 554 MB eight-channel map per 16 samples written,
+// padded to the matrix-core kernels' 16 input channels and read back; here one thread owns one output pixel and all C1
+// output channels: the 1x1 layer is re-evaluated from the depth value of each of the 25 taps (4 flops per channel), the
+// 5x5 weights are wave-uniform (scalar loads) and the accumulation is a plain fp32 FMA chain (taps, then channels).
+// Zero padding applies to the FIRST layer's output (a tap outside the image contributes 0, not layer0(0)).
+// p0 = [w0 | scale0 | shift0] (C0 each), w1 [KS*KS][C0][C1], p1 = [scale1 | shift1] (C1 each); out [BN][oH][oW][C1].
+template <int C0, int C1, int KS, int ST, int PD>
+__global__ __launch_bounds__(256) void lss_dtransform01_kernel(const float* __restrict__ depth, int64_t total, int iH, int iW,
+                                                               int oH, int oW, const float* __restrict__ p0,
+                                                               const float* __restrict__ w1, const float* __restrict__ p1,
+                                                               float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < total;
+    const int64_t tt = live ? t : 0;
+    const int ox = (int)(tt % oW), oy = (int)((tt / oW) % oH);
+    const int64_t n = tt / ((int64_t)oW * oH);
+    const float* img = depth + n * iH * iW;
+    float acc[C1];
+#pragma unroll
+    for (int co = 0; co < C1; ++co) acc[co] = 0.f;
+    for (int ky = 0; ky < KS; ++ky) {
+        const int y = oy * ST - PD + ky;
+        for (int kx = 0; kx < KS; ++kx) {
+            const int x = ox * ST - PD + kx;
+            const bool inb = y >= 0 && y < iH && x >= 0 && x < iW;
+            const float d = inb ? img[(int64_t)y * iW + x] : 0.f;
+            const float* w = w1 + (ky * KS + kx) * (C0 * C1);
+#pragma unroll
+            for (int c = 0; c < C0; ++c) {
+                float a = (p0[c] * d) * p0[C0 + c] + p0[2 * C0 + c];
+                a = a <= 0.f ? 0.f : a;                                  // NaN propagates, like torch.relu
+                a = inb ? a : 0.f;
+#pragma unroll
+                for (int co = 0; co < C1; ++co) acc[co] = __builtin_fmaf(w[c * C1 + co], a, acc[co]);
+            }
+        }
+    }
+    if (!live) return;
+    float* o = out + t * C1;
+#pragma unroll
+    for (int co = 0; co < C1; co += 4) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = acc[co + e] * p1[co + e] + p1[C1 + co + e];
+            v[e] = v[e] <= 0.f ? 0.f : v[e];
+        }
+        *reinterpret_cast<float4*>(o + co) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+extern "C" int al3d_lss_dtransform01_f32(const float* depth, int BN, int iH, int iW, const float* p0, const float* w1,
+                                         const float* p1, float* out, void* stream)
+{
+    AL3D_REQUIRE(depth && p0 && w1 && p1 && out, "al3d_lss_dtransform01_f32: null pointer");
+    AL3D_REQUIRE(BN >= 0 && iH >= 1 && iW >= 1, "al3d_lss_dtransform01_f32: bad shape");
+    AL3D_REQUIRE(((uintptr_t)out & 15) == 0, "al3d_lss_dtransform01_f32: out must be 16-byte aligned");
+    const int oH = (iH + 2 * 2 - 5) / 4 + 1, oW = (iW + 2 * 2 - 5) / 4 + 1;
+    const int64_t total = (int64_t)BN * oH * oW;
+    if (total == 0) return AL3D_OK;
+    hipLaunchKernelGGL((lss_dtransform01_kernel<8, 32, 5, 4, 2>), dim3((unsigned)al3d_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, depth, total, iH, iW, oH, oW, p0, w1, p1, out);
+    AL3D_CHECK_LAUNCH("lss_dtransform01_kernel");
+    return AL3D_OK;
+}
+
 // ------------------------------------------------------------------ lidar depth image of the depth-aware LSS transform
 // BaseDepthTransform.forward (bevfusion/mmdet3d/models/vtransforms/base.py:225-262): every lidar point of a sample is
 // taken back through the lidar augmentation, projected into each camera (lidar2image), through the image

@@ -121,6 +121,13 @@ class LSSViewTransform(nn.Module):
         else:
             self.downsample, self._ds = nn.Identity(), []
 
+    def grid_numpy(self):
+        """(dx, bx, nx) as numpy arrays, copied off the device once (they are constants of the configuration)."""
+        key = (self.dx._version, self.bx._version, self.nx._version, self.dx.data_ptr())
+        if getattr(self, "_grid_np", None) is None or self._grid_np[0] != key:
+            self._grid_np = (key, self.dx.detach().cpu().numpy(), self.bx.detach().cpu().numpy(), self.nx.detach().cpu().numpy())
+        return self._grid_np[1:]
+
     def create_frustum(self):
         """base.py:56-77."""
         iH, iW = self.image_size
@@ -152,17 +159,18 @@ class LSSViewTransform(nn.Module):
         products per camera stay torch (B*N tiny matrices), the 2 M frustum points per sample do not."""
         B, N, _ = camera2lidar_trans.shape
         dev = self.frustum.device
-        rows = torch.zeros((B * N, 44), dtype=torch.float32, device=dev)
-        rows[:, 0:9] = torch.inverse(post_rots).reshape(B * N, 9)
-        rows[:, 9:12] = post_trans.reshape(B * N, 3)
-        rows[:, 12:21] = _mat3(camera2lidar_rots, torch.inverse(intrins)).reshape(B * N, 9)
-        rows[:, 21:24] = camera2lidar_trans.reshape(B * N, 3)
-        if "extra_rots" in kwargs:
-            rows[:, 24:33] = kwargs["extra_rots"].reshape(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)
-            rows[:, 36] = 1.0
-        if "extra_trans" in kwargs:
-            rows[:, 33:36] = kwargs["extra_trans"].reshape(B, 1, 3).expand(B, N, 3).reshape(B * N, 3)
-            rows[:, 37] = 1.0
+        f = lambda t, k: t.reshape(B * N, k).to(dev, torch.float32)
+        zeros = torch.zeros((B * N, 9), dtype=torch.float32, device=dev)
+        has_rot, has_trans = "extra_rots" in kwargs, "extra_trans" in kwargs
+        # one row of 44 floats per camera, assembled with ONE concatenation (slice assignments are a launch each)
+        rows = torch.cat([
+            f(torch.inverse(post_rots), 9), f(post_trans, 3),
+            f(_mat3(camera2lidar_rots, torch.inverse(intrins)), 9), f(camera2lidar_trans, 3),
+            f(kwargs["extra_rots"].reshape(B, 1, 9).expand(B, N, 9), 9) if has_rot else zeros,
+            f(kwargs["extra_trans"].reshape(B, 1, 3).expand(B, N, 3), 3) if has_trans else zeros[:, :3],
+            torch.full((B * N, 1), 1.0 if has_rot else 0.0, dtype=torch.float32, device=dev),
+            torch.full((B * N, 1), 1.0 if has_trans else 0.0, dtype=torch.float32, device=dev),
+            zeros[:, :6]], dim=1).contiguous()
         Dd, fH, fW, _ = self.frustum.shape
         geom = torch.empty((B, N, Dd, fH, fW, 3), dtype=torch.float32, device=dev)
         ws = torch.empty(lib.load().al3d_lss_geometry_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
@@ -173,8 +181,8 @@ class LSSViewTransform(nn.Module):
     def forward(self, depth, ctx, camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs):
         B, N, Dd, fH, fW = depth.shape
         geom = self.geometry_device(camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs)
-        x = bev_pool(ctx.reshape(B * N, fH, fW, self.C).contiguous(), geom, B, self.dx.cpu().numpy(),
-                     self.bx.cpu().numpy(), self.nx.cpu().numpy(), depth=depth.reshape(B * N, Dd, fH, fW).contiguous())
+        x = bev_pool(ctx.reshape(B * N, fH, fW, self.C).contiguous(), geom, B, *self.grid_numpy(),
+                     depth=depth.reshape(B * N, Dd, fH, fW).contiguous())
         for layer in self._ds:
             x = layer(x)
         return x
@@ -310,26 +318,59 @@ class DepthLSSTransform(LSSViewTransform):
         dev = self.frustum.device
         out = torch.empty((B, N, iH, iW), dtype=torch.float32, device=dev)
         ws = torch.empty(lib.load().al3d_lss_depth_image_workspace_bytes(N, iH, iW), dtype=torch.uint8, device=dev)
+        # per-camera / per-sample matrices of the whole batch in two small tensors (one inverse, two concatenations)
+        rows = torch.cat([lidar2image[..., :3, :3].reshape(B, N, 9), lidar2image[..., :3, 3],
+                          img_aug_matrix[..., :3, :3].reshape(B, N, 9), img_aug_matrix[..., :3, 3]], dim=-1)
+        rows = rows.to(dev, torch.float32).contiguous()                                       # [B, N, 24]
+        aug = torch.cat([torch.inverse(lidar_aug_matrix[:, :3, :3]).reshape(B, 9), lidar_aug_matrix[:, :3, 3]], dim=-1)
+        aug = aug.to(dev, torch.float32).contiguous()                                         # [B, 12]
         for b in range(B):
             pts = _dev(points[b].float().contiguous(), torch.float32, "points")
-            rows = torch.empty((N, 24), dtype=torch.float32, device=dev)
-            rows[:, 0:9] = lidar2image[b, :, :3, :3].reshape(N, 9)
-            rows[:, 9:12] = lidar2image[b, :, :3, 3]
-            rows[:, 12:21] = img_aug_matrix[b, :, :3, :3].reshape(N, 9)
-            rows[:, 21:24] = img_aug_matrix[b, :, :3, 3]
-            aug = torch.empty((12,), dtype=torch.float32, device=dev)
-            aug[0:9] = torch.inverse(lidar_aug_matrix[b, :3, :3]).reshape(9)
-            aug[9:12] = lidar_aug_matrix[b, :3, 3]
-            lib.call("al3d_lss_depth_image_f32", _ptr(pts), pts.shape[0], pts.shape[1], _ptr(rows), N, _ptr(aug), iH, iW,
+            lib.call("al3d_lss_depth_image_f32", _ptr(pts), pts.shape[0], pts.shape[1], _ptr(rows[b]), N, _ptr(aug[b]), iH, iW,
                      _ptr(out[b]), _ptr(ws), _stream())
+        return out
+
+    def _dt01_fusable(self):
+        c0, c1 = self.dtransform[0], self.dtransform[3]
+        return (c0.in_channels, c0.out_channels, c0.kernel_size, c0.stride, c0.padding) == (1, 8, (1, 1), (1, 1), (0, 0)) and \
+            (c1.in_channels, c1.out_channels, c1.kernel_size, c1.stride, c1.padding) == (8, 32, (5, 5), (4, 4), (2, 2))
+
+    def _dtransform01(self, d):
+        """dtransform[0:6] (1x1 conv + BN + ReLU -> 5x5 / stride 4 conv + BN + ReLU) as ONE kernel on the depth image
+        [BN, iH, iW] -> [BN, oH, oW, 32] (``al3d_lss_dtransform01_f32``): the eight-channel full-resolution map -- 554 MB per
+        16 samples, written, zero-padded to 16 channels and read back by the matrix-core path -- is never formed."""
+        c0, b0, c1, b1 = self.dtransform[0], self.dtransform[1], self.dtransform[3], self.dtransform[4]
+        key = (d.device, _versions(c0, b0, c1, b1))
+        if getattr(self, "_dt01", None) is None or self._dt01[0] != key:
+            def affine(conv, bn):
+                scale, shift = D.fold_bn(bn)
+                scale, shift = scale.cpu().float(), shift.cpu().float()
+                if conv.bias is not None:
+                    shift = shift + conv.bias.detach().float().cpu() * scale
+                return scale, shift
+            s0, t0 = affine(c0, b0)
+            s1, t1 = affine(c1, b1)
+            p0 = torch.cat([c0.weight.detach().float().cpu().reshape(8), s0, t0]).contiguous().to(d.device)
+            w1 = c1.weight.detach().float().cpu().permute(2, 3, 1, 0).contiguous().to(d.device)      # [ky][kx][c][co]
+            p1 = torch.cat([s1, t1]).contiguous().to(d.device)
+            self._dt01 = (key, p0, w1, p1)
+        _, p0, w1, p1 = self._dt01
+        BN, iH, iW = d.shape
+        d = _dev(d, torch.float32, "depth image")
+        out = torch.empty((BN, (iH - 1) // 4 + 1, (iW - 1) // 4 + 1, 32), dtype=torch.float32, device=d.device)
+        lib.call("al3d_lss_dtransform01_f32", _ptr(d), BN, iH, iW, _ptr(p0), _ptr(w1), _ptr(p1), _ptr(out), _stream())
         return out
 
     def get_cam_feats(self, x, d):
         """x [B,N,fH,fW,Cin], d [B,N,iH,iW] -> (depth probabilities [B*N,D,fH,fW], context [B*N,fH,fW,C])."""
         B, N, fH, fW, Cin = x.shape
-        d = d.reshape(B * N, *d.shape[2:]).unsqueeze(-1)
-        for layer in self._dt:
-            d = layer(d)
+        d = d.reshape(B * N, *d.shape[2:])
+        if self._dt01_fusable():
+            d = self._dt[2](self._dtransform01(d))
+        else:
+            d = d.unsqueeze(-1)
+            for layer in self._dt:
+                d = layer(d)
         assert d.shape[1:3] == (fH, fW), (d.shape, fH, fW)
         y = torch.cat([d, x.reshape(B * N, fH, fW, Cin)], dim=-1).contiguous()
         for layer in self._dn:
@@ -346,7 +387,7 @@ class DepthLSSTransform(LSSViewTransform):
         geom = self.geometry_device(camera2lidar[..., :3, :3], camera2lidar[..., :3, 3], cam_intrinsic[..., :3, :3],
                                     img_aug_matrix[..., :3, :3], img_aug_matrix[..., :3, 3],
                                     extra_rots=lidar_aug_matrix[..., :3, :3], extra_trans=lidar_aug_matrix[..., :3, 3])
-        x = bev_pool(ctx, geom, B, self.dx.cpu().numpy(), self.bx.cpu().numpy(), self.nx.cpu().numpy(), depth=depth)
+        x = bev_pool(ctx, geom, B, *self.grid_numpy(), depth=depth)
         for layer in self._ds:
             x = layer(x)
         return x

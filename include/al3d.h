@@ -499,12 +499,19 @@ int al3d_lss_geometry_f32(const float* frustum, int64_t points_per_camera, const
  * LAST in point order stays (the reference's indexed assignment on the CPU).  cam_rows [ncam][24] = lidar2image[:3,:3]
  * | lidar2image[:3,3] | img_aug[:3,:3] | img_aug[:3,3]; aug_rows [12] = inverse(lidar_aug[:3,:3]) | lidar_aug[:3,3]
  * (device memory).  workspace: al3d_lss_depth_image_workspace_bytes. */
-/* depth_lss.py:93-96: softmax over the D depth logits of the depth net's channels-last output y [BN][fH][fW][ldy] (logits
- * in channels 0 .. D-1), written as [BN][D][fH][fW] probabilities for the pooling; D <= 256. */
-int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW, int D, int ldy, float* out, void* stream);
 int64_t al3d_lss_depth_image_workspace_bytes(int ncam, int iH, int iW);
 int al3d_lss_depth_image_f32(const float* points, int64_t npts, int stride, const float* cam_rows, int ncam,
                              const float* aug_rows, int iH, int iW, float* depth, void* workspace, void* stream);
+/* depth_lss.py:93-96: softmax over the D depth logits of the depth net's channels-last output y [BN][fH][fW][ldy] (logits
+ * in channels 0 .. D-1), written as [BN][D][fH][fW] probabilities for the pooling; D <= 256. */
+int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW, int D, int ldy, float* out, void* stream);
+/* depth_lss.py:38-44, the first two layers of `dtransform` as one kernel: Conv2d(1, 8, 1) + BN + ReLU -> Conv2d(8, 32, 5,
+ * stride 4, padding 2) + BN + ReLU on the depth image [BN][iH][iW] -> out [BN][oH][oW][32] (channels-last, oH =
+ * (iH - 1) / 4 + 1).  p0 = [w0[8] | scale0[8] | shift0[8]] with layer 0 = relu((w0 d) scale0 + shift0) (bias and BN folded:
+ * shift0 = bn_shift + bias * bn_scale); w1 [25][8][32] = conv.weight[co][c][ky][kx] at [(ky*5+kx)][c][co];
+ * p1 = [scale1[32] | shift1[32]].  fp32 FMA chain over (tap, channel); zero padding applies to layer 0's OUTPUT. */
+int al3d_lss_dtransform01_f32(const float* depth, int BN, int iH, int iW, const float* p0, const float* w1, const float* p1,
+                              float* out, void* stream);
 int64_t al3d_bev_pool_workspace_bytes(int64_t n_points, int64_t n_cells);
 int al3d_bev_pool_f32(const float* x, const float* geom, int64_t n_points, int C, int B, const float* lo,
                       const float* dx, const int* nx, float* out, void* workspace, void* stream);

@@ -158,3 +158,28 @@ def test_depth_image_without_points_is_all_zero():
     K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = _camera_setup(1, 6, 3, (64, 176))
     d = vt.depth_image([torch.zeros((0, 5), device=DEV)], lidar2image.to(DEV), img_aug.to(DEV), lidar_aug.to(DEV))
     assert d.shape == (1, 6, 64, 176) and float(d.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("size", [(64, 176), (37, 53), (5, 4)])
+def test_fused_dtransform_head_matches_float64(size):
+    """``al3d_lss_dtransform01_f32`` (1x1 conv + BN + ReLU -> 5x5 / stride 4 / padding 2 conv + BN + ReLU as one fp32
+    kernel, depth_lss.py:38-44) against the two torch layers evaluated in float64: the bound is fp32 rounding of a
+    200-term sum, 1e-5 of the largest output; image sizes that are not multiples of the stride exercise the zero
+    padding of the FIRST layer's output (a tap outside the image adds 0, not relu(shift0))."""
+    from al3d.models.bevfusion_camera import DepthLSSTransform
+    vt = _seed_(DepthLSSTransform(32, 16, (64, 176), (8, 22), [-54.0, 54.0, 0.6], [-54.0, 54.0, 0.6], [-10.0, 10.0, 20.0],
+                                  [1.0, 60.0, 1.0], downsample=2), 11)
+    with torch.no_grad():
+        vt.dtransform[0].bias.copy_(torch.linspace(-0.5, 0.8, 8))          # relu(shift0) != 0 on empty pixels
+    vt = vt.to(DEV).eval()
+    assert vt._dt01_fusable()
+    g = torch.Generator().manual_seed(2)
+    d = torch.rand(3, *size, generator=g) * 60.0
+    d[torch.rand(3, *size, generator=g) < 0.7] = 0.0                        # lidar depth images are mostly empty
+    with torch.no_grad():
+        got = vt._dtransform01(d.to(DEV))
+        ref = vt.dtransform[:6].double()(d.double().unsqueeze(1).to(DEV)).permute(0, 2, 3, 1)
+        vt.dtransform.float()
+    assert got.shape == ref.shape and got.shape[-1] == 32
+    assert float(ref.abs().max()) > 0
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
