@@ -163,6 +163,48 @@ __global__ __launch_bounds__(256) void head_score_kernel(HeadParams p)
     p.sbits[(int64_t)b * p.sample_stride + p.task_soff[t] + a] = best >= p.score_thresh ? __float_as_uint(best) : 0u;
 }
 
+// The same pre-pass with the class logits of 256 locations staged through LDS: the fused head output keeps all class
+// logits of a location in ONE contiguous window [cls_lo, cls_lo + cls_w) of its CH-float record (bbox_heads.py orders it
+// [all box regressions | all class logits]), so the workgroup fetches 256 x cls_w floats with consecutive lanes on
+// consecutive addresses (2-3 cache lines per wave-load instead of 64 with one anchor per thread) and then one thread
+// per location takes the sigmoid / max of every (task, anchor).  Same sigmoid, same order of comparisons: same bits.
+#define HS_LOCS 64
+#define HS_MAXW 128
+__global__ __launch_bounds__(256) void head_score_rows_kernel(HeadParams p, int cls_lo, int cls_w)
+{
+    extern __shared__ float lg[];                                      // HS_LOCS x (cls_w + 1) floats
+    const int b = blockIdx.y, loc0 = blockIdx.x * HS_LOCS;
+    const int nloc = p.HW - loc0 < HS_LOCS ? p.HW - loc0 : HS_LOCS;
+    const float* hb = p.hout + ((int64_t)b * p.HW + loc0) * p.CH + cls_lo;
+    const int pitch = cls_w + 1;
+    if (((cls_lo | cls_w | p.CH) & 3) == 0) {                          // 16-byte pieces (the shipped head: 180 | 56 of 236)
+        const int q4 = cls_w >> 2;
+        for (int e = threadIdx.x; e < nloc * q4; e += 256) {
+            const int l = e / q4, k = (e - l * q4) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(hb + (int64_t)l * p.CH + k);
+            float* d = lg + l * pitch + k;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < nloc * cls_w; e += 256) {
+            const int l = e / cls_w, k = e - l * cls_w;
+            lg[l * pitch + k] = hb[(int64_t)l * p.CH + k];
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < nloc * p.ntasks; w += 256) {          // one (task, location) per thread, locations fastest
+        const int t = w / nloc, l = w - t * nloc;
+        const HeadTask tk = p.task[t];
+        unsigned* o = p.sbits + (int64_t)b * p.sample_stride + p.task_soff[t] + (int64_t)(loc0 + l) * tk.na;
+        for (int j = 0; j < tk.na; ++j) {
+            const float* c = lg + l * pitch + (tk.cls_off - cls_lo) + j * tk.nc;
+            float best = sigmoidf_(c[0]);
+            for (int q = 1; q < tk.nc; ++q) { const float s2 = sigmoidf_(c[q]); if (s2 > best) best = s2; }
+            o[j] = best >= p.score_thresh ? __float_as_uint(best) : 0u;
+        }
+    }
+}
+
 __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
 {
     const int b = blockIdx.x / p.ntasks, t = blockIdx.x % p.ntasks;
@@ -518,8 +560,17 @@ extern "C" int al3d_head_decode_nms(const float* hout, int B, int HW, int CH, in
     int amax = 0;
     for (int t = 0; t < ntasks; ++t) { p.task_soff[t] = soff; soff += task_A[t]; if (task_A[t] > amax) amax = task_A[t]; }
     p.sample_stride = soff;
-    hipLaunchKernelGGL(head_score_kernel, dim3((unsigned)al3d_cdiv(amax, 256), (unsigned)ntasks, (unsigned)B), dim3(256),
-                       0, (hipStream_t)stream, p);
+    int cls_lo = CH, cls_hi = 0;
+    for (int t = 0; t < ntasks; ++t) {
+        if (cls_off[t] < cls_lo) cls_lo = cls_off[t];
+        if (cls_off[t] + task_na[t] * task_nc[t] > cls_hi) cls_hi = cls_off[t] + task_na[t] * task_nc[t];
+    }
+    if (cls_hi - cls_lo <= HS_MAXW)      // all class logits of a location in one window of its record: staged pre-pass
+        hipLaunchKernelGGL(head_score_rows_kernel, dim3((unsigned)al3d_cdiv(HW, HS_LOCS), (unsigned)B), dim3(256),
+                           (size_t)HS_LOCS * (cls_hi - cls_lo + 1) * sizeof(float), (hipStream_t)stream, p, cls_lo, cls_hi - cls_lo);
+    else
+        hipLaunchKernelGGL(head_score_kernel, dim3((unsigned)al3d_cdiv(amax, 256), (unsigned)ntasks, (unsigned)B), dim3(256),
+                           0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(head_nms_kernel, dim3((unsigned)(B * ntasks)), dim3(HN_THREADS), 0,
                        (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("head_nms_kernel");
