@@ -2,6 +2,7 @@
 
   python tools/rocpd_summary.py stats  <kernel-trace.db> <out.csv>
   python tools/rocpd_summary.py hbm    <FETCH_SIZE.db> <WRITE_SIZE.db> <out.json> [note] [bench-line.json]
+  python tools/rocpd_summary.py seq    <kernel-trace.db> <out.csv> [last_n]      (one line per dispatch, launch order)
 
 ``stats`` reproduces rocprofv3 --stats' kernel table (calls, total/avg/min/max ns, share).
 ``hbm`` sums the two single-counter passes per kernel and applies the gfx950 correction from
@@ -30,6 +31,19 @@ def stats(db, out):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for n, calls, tot, avg, mn, mx in rows:
             w.writerow([n, calls, tot, round(avg, 3), round(100.0 * tot / total, 2), mn, mx])
+
+
+def seq(db, out, last_n=0):
+    """Per-dispatch durations in launch order (the last ``last_n`` dispatches, all when 0): which layer costs what."""
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, duration, grid_x, workgroup_x from kernels order by start").fetchall()
+    if last_n:
+        rows = rows[-last_n:]
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Index", "Name", "DurationUs", "GridX", "WorkgroupX"])
+        for i, (n, _, d, gx, wx) in enumerate(rows):
+            w.writerow([i, short(n), round(d / 1e3, 2), gx, wx])
 
 
 def per_kernel(db, counter):
@@ -110,6 +124,8 @@ def hbm(fdb, wdb, out, note, bench_line=None):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "seq":
+        seq(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     else:
         note = sys.argv[5] if len(sys.argv) > 5 else ""
         hbm(sys.argv[2], sys.argv[3], sys.argv[4], note, sys.argv[6] if len(sys.argv) > 6 else None)
