@@ -200,6 +200,26 @@ __global__ void sp_down_table_kernel(const int* __restrict__ coords_out, int n_o
     }
 }
 
+// three adjacent cells of a grid row with ONE 12-byte load (dword-aligned): the texture addresser then handles one request
+// per lane instead of three (the lookups of a wave are 64 different lines either way)
+__device__ __forceinline__ void sp_probe3(const int* __restrict__ grid, int64_t base, int x0, int W, bool row_ok, int (&v)[3])
+{
+    v[0] = v[1] = v[2] = -1;
+    if (!row_ok) return;
+    if (x0 >= 0 && x0 + 2 < W) {
+        typedef int sp_i32x3 __attribute__((ext_vector_type(3)));
+        sp_i32x3 t;
+        asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(t) : "v"(grid + base + x0) : "memory");
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2];
+    } else {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int x = x0 + kx;
+            if (x >= 0 && x < W) v[kx] = grid[base + x];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ tiled rulebook (csrc/spconv_glds.hip)
 // The same tables with a row pitch that is a multiple of 64 (rows >= n hold -1), so that the 32 entries of
 // one (tap, 32-row tile) are one aligned 128-byte line, plus tmask[tile] = the set of taps with at least
@@ -220,10 +240,13 @@ __global__ void sp_subm_table_tiles_kernel(const int* __restrict__ coords, int n
     }
     const int64_t base = row_ok ? sp_cell(g, b, z, y, 0) : 0;
     const int lane = threadIdx.x & 63;
+    int v3[3];
+    if (kw == 3) sp_probe3(grid, base, x0, g.W, row_ok, v3);
     for (int kx = 0; kx < kw; ++kx) {
         const int x = x0 + kx;
         int v = -1;
-        if (row_ok && x >= 0 && x < g.W) v = grid[base + x];
+        if (kw == 3) v = v3[kx];
+        else if (row_ok && x >= 0 && x < g.W) v = grid[base + x];
         const int k = kzy * kw + kx;
         nbr[(int64_t)k * pitch + i] = v;
         const unsigned long long bal = __ballot(v >= 0);                    // the wave's 64 rows = tiles i/32, i/32 + 1
@@ -248,10 +271,13 @@ __global__ void sp_down_table_tiles_kernel(const int* __restrict__ coords_out, i
     }
     const int64_t base = row_ok ? sp_cell(gi, b, z, y, 0) : 0;
     const int lane = threadIdx.x & 63;
+    int v3[3];
+    if (q.kw == 3) sp_probe3(grid_in, base, x0, gi.W, row_ok, v3);
     for (int kx = 0; kx < q.kw; ++kx) {
         const int x = x0 + kx;
         int v = -1;
-        if (row_ok && x >= 0 && x < gi.W) v = grid_in[base + x];
+        if (q.kw == 3) v = v3[kx];
+        else if (row_ok && x >= 0 && x < gi.W) v = grid_in[base + x];
         const int k = kzy * q.kw + kx;
         nbr[(int64_t)k * pitch + o] = v;
         const unsigned long long bal = __ballot(v >= 0);
