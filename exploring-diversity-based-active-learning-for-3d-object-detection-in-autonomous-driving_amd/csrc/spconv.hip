@@ -255,6 +255,73 @@ __global__ void sp_subm_table_tiles_kernel(const int* __restrict__ coords, int n
     }
 }
 
+// 3 x 3 x 3 tables, ONE thread per output row (both the submanifold and the strided form: input position of tap
+// (kz, ky, kx) = o * stride - pad + k).  The nine (kz, ky) probes of a row are nine independent 12-byte loads issued
+// back to back (one wait), its coordinates are read once instead of nine times, and the per-tile tap masks come from
+// ballots kept in scalar registers and are stored with plain writes: no atomics, no memset of the mask array.  Loads
+// are unconditional -- a probe outside the grid (or of a padding row) reads the three cells at a clamped position and
+// is discarded -- so that hipcc keeps them together.  Same table, same masks as the (row, kz, ky)-per-thread kernels.
+typedef int sp_i32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ int sp_pick3(const sp_i32x3& t, int idx)
+{
+    return idx <= 0 ? t[0] : (idx == 1 ? t[1] : t[2]);
+}
+__global__ __launch_bounds__(256) void sp_table_rows27_kernel(const int* __restrict__ coords, int n, int pitch, SpConvGeom q,
+                                                              SpDims g, const int* __restrict__ grid,
+                                                              int* __restrict__ nbr, unsigned* __restrict__ tmask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;                        // exact grid: pitch threads
+    const int lane = threadIdx.x & 63;
+    int b = 0, z0 = 0, y0 = 0, x0 = 0;
+    const bool live = i < n;
+    if (live) {
+        const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)i);
+        b = c.x; z0 = c.y * q.sd - q.pd; y0 = c.z * q.sh - q.ph; x0 = c.w * q.sw - q.pw;
+    }
+    const int xc = x0 < 0 ? 0 : (x0 > g.W - 3 ? g.W - 3 : x0);
+    const int shift = x0 - xc;
+    const int* addr[9];
+    bool ok[9];
+#pragma unroll
+    for (int kzy = 0; kzy < 9; ++kzy) {
+        const int z = z0 + kzy / 3, y = y0 + kzy % 3;
+        ok[kzy] = live && z >= 0 && z < g.D && y >= 0 && y < g.H;
+        addr[kzy] = grid + (ok[kzy] ? sp_cell(g, b, z, y, xc) : 0);
+    }
+    sp_i32x3 t[9];
+    asm volatile("global_load_dwordx3 %0, %9, off\n\t"
+                 "global_load_dwordx3 %1, %10, off\n\t"
+                 "global_load_dwordx3 %2, %11, off\n\t"
+                 "global_load_dwordx3 %3, %12, off\n\t"
+                 "global_load_dwordx3 %4, %13, off\n\t"
+                 "global_load_dwordx3 %5, %14, off\n\t"
+                 "global_load_dwordx3 %6, %15, off\n\t"
+                 "global_load_dwordx3 %7, %16, off\n\t"
+                 "global_load_dwordx3 %8, %17, off\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+                   "=&v"(t[8])
+                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]),
+                   "v"(addr[7]), "v"(addr[8])
+                 : "memory");
+    unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+    for (int kzy = 0; kzy < 9; ++kzy) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int x = x0 + kx;
+            const int v = (ok[kzy] && x >= 0 && x < g.W) ? sp_pick3(t[kzy], kx + shift) : -1;
+            const int k = kzy * 3 + kx;
+            nbr[(int64_t)k * pitch + i] = v;
+            const unsigned long long bal = __ballot(v >= 0);
+            mlo |= (bal & 0xffffffffull) ? 1u << k : 0u;
+            mhi |= (bal >> 32) ? 1u << k : 0u;
+        }
+    }
+    if (lane == 0) tmask[i >> 5] = mlo;
+    if (lane == 32) tmask[i >> 5] = mhi;
+}
+
 __global__ void sp_down_table_tiles_kernel(const int* __restrict__ coords_out, int n_out, int pitch, SpConvGeom q,
                                            SpDims gi, const int* __restrict__ grid_in, int* __restrict__ nbr,
                                            unsigned* __restrict__ tmask)
@@ -424,9 +491,16 @@ extern "C" int al3d_sp_subm_table_tiles(const int* coords, int n, int B, int D, 
                  "al3d_sp_subm_table_tiles: odd kernel sizes, at most 27 taps");
     AL3D_REQUIRE(((uintptr_t)coords & 15) == 0, "al3d_sp_subm_table_tiles: coords must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    SpDims g = {B, D, H, W};
+    if (kd == 3 && kh == 3 && kw == 3 && W >= 3 && n > 0) {
+        const SpConvGeom q1 = {3, 3, 3, 1, 1, 1, 1, 1, 1};
+        hipLaunchKernelGGL(sp_table_rows27_kernel, dim3((unsigned)(pitch / 256)), dim3(256), 0, s, coords, n, pitch, q1, g, grid,
+                           nbr, tile_mask);
+        AL3D_CHECK_LAUNCH("sp_table_rows27_kernel");
+        return AL3D_OK;
+    }
     if (hipMemsetAsync(tile_mask, 0, (size_t)(pitch / 32) * 4, s) != hipSuccess)
         return al3d_fail(AL3D_ELAUNCH, "al3d_sp_subm_table_tiles: memset failed");
-    SpDims g = {B, D, H, W};
     hipLaunchKernelGGL(sp_subm_table_tiles_kernel, dim3((unsigned)((int64_t)pitch * kd * kh / 256)), dim3(256), 0, s,
                        coords, n, pitch, g, grid, kd, kh, kw, nbr, tile_mask);
     AL3D_CHECK_LAUNCH("sp_subm_table_tiles_kernel");
@@ -520,10 +594,16 @@ extern "C" int al3d_sp_down_table_tiles(const int* coords_out, int n_out, const 
     AL3D_REQUIRE(((uintptr_t)coords_out & 15) == 0, "al3d_sp_down_table_tiles: coords_out must be 16-byte aligned");
     AL3D_REQUIRE(ksize[0] * ksize[1] * ksize[2] <= 27, "al3d_sp_down_table_tiles: at most 27 taps");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(tile_mask, 0, (size_t)(pitch / 32) * 4, s) != hipSuccess)
-        return al3d_fail(AL3D_ELAUNCH, "al3d_sp_down_table_tiles: memset failed");
     SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
     SpDims gi = {B, ID, IH, IW};
+    if (q.kd == 3 && q.kh == 3 && q.kw == 3 && IW >= 3 && n_out > 0) {
+        hipLaunchKernelGGL(sp_table_rows27_kernel, dim3((unsigned)(pitch / 256)), dim3(256), 0, s, coords_out, n_out, pitch, q, gi,
+                           grid_in, nbr, tile_mask);
+        AL3D_CHECK_LAUNCH("sp_table_rows27_kernel");
+        return AL3D_OK;
+    }
+    if (hipMemsetAsync(tile_mask, 0, (size_t)(pitch / 32) * 4, s) != hipSuccess)
+        return al3d_fail(AL3D_ELAUNCH, "al3d_sp_down_table_tiles: memset failed");
     hipLaunchKernelGGL(sp_down_table_tiles_kernel, dim3((unsigned)((int64_t)pitch * q.kd * q.kh / 256)), dim3(256), 0, s,
                        coords_out, n_out, pitch, q, gi, grid_in, nbr, tile_mask);
     AL3D_CHECK_LAUNCH("sp_down_table_tiles_kernel");
