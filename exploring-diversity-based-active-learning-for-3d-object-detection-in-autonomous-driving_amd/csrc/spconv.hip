@@ -30,8 +30,8 @@ __global__ void sp_scatter_index_kernel(const int* __restrict__ coords, int n, S
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int* c = coords + 4 * i;
-    grid[sp_cell(g, c[0], c[1], c[2], c[3])] = mode ? i : -1;
+    const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)i);
+    grid[sp_cell(g, c.x, c.y, c.z, c.w)] = mode ? i : -1;
 }
 
 // Output-major rulebook for a submanifold conv: nbr[i][k] = row at coords[i] + (k - k/2).
@@ -456,6 +456,7 @@ extern "C" int al3d_sp_scatter_index(const int* coords, int n, int B, int D, int
 {
     if (n == 0) return AL3D_OK;
     AL3D_REQUIRE(coords && grid && n > 0, "al3d_sp_scatter_index: bad arguments");
+    AL3D_REQUIRE(((uintptr_t)coords & 15) == 0, "al3d_sp_scatter_index: coords must be 16-byte aligned");
     SpDims g = {B, D, H, W};
     hipLaunchKernelGGL(sp_scatter_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        coords, n, g, grid, mode);

@@ -47,9 +47,22 @@ __global__ void vox_first_kernel(const float* __restrict__ pts, const int64_t* _
                                  int* __restrict__ pcell_lo)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= off[B]) return;
-    const int b = frame_of(off, B, i);
-    const int64_t cell = vox_cell(pts + i * c.nfeat, c);
+    const int64_t npts = off[B];
+    // frame of the wave's FIRST point by a wave-uniform search (scalar loads), then a step forward for the lanes beyond a
+    // frame boundary: seven dependent vector loads per point otherwise
+    const int64_t iw = i - (threadIdx.x & 63);
+    const int64_t i0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(iw >> 32)) << 32) |
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)iw);
+    if (i0 >= npts) return;
+    int b = frame_of(off, B, i0);
+    if (i >= npts) return;
+    while (b + 1 < B && off[b + 1] <= i) ++b;
+    // x, y, z with one 12-byte load (points are nfeat floats apart: dword-aligned)
+    typedef float vx_f32x3 __attribute__((ext_vector_type(3)));
+    vx_f32x3 xyz;
+    asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(xyz) : "v"(pts + i * c.nfeat) : "memory");
+    const float p3[3] = {xyz[0], xyz[1], xyz[2]};
+    const int64_t cell = vox_cell(p3, c);
     // cells < 2^31 is checked on the host, so one int carries the cell id
     pcell_lo[i] = cell < 0 ? -1 : (int)cell;
     pcell_hi[i] = b;
@@ -109,8 +122,7 @@ __global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg
             pos = atomicAdd(&cnt[row], 1);          // arrival position inside the voxel: the bucket slot (pass 5)
             if (lead == (int)(i - off[b])) {
                 const int x = cell % c.gx, y = (cell / c.gx) % c.gy, z = cell / (c.gx * c.gy);
-                coords[4 * row + 0] = b; coords[4 * row + 1] = z;
-                coords[4 * row + 2] = y; coords[4 * row + 3] = x;
+                *reinterpret_cast<int4*>(coords + 4 * (int64_t)row) = make_int4(b, z, y, x);
             }
         }
     }
@@ -272,6 +284,8 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
     AL3D_REQUIRE(B >= 1 && nfeat >= 3 && npts >= 0 && npts < (1LL << 31), "al3d_voxelize_mean_f32: bad sizes");
     AL3D_REQUIRE(max_points >= 1 && max_points <= VX_MAXP, "al3d_voxelize_mean_f32: max_points must be in [1,%d]", VX_MAXP);
     AL3D_REQUIRE(max_voxels >= 1, "al3d_voxelize_mean_f32: max_voxels must be >= 1");
+    AL3D_REQUIRE(((uintptr_t)coords & 15) == 0 && ((uintptr_t)points & 3) == 0,
+                 "al3d_voxelize_mean_f32: coords must be 16-byte aligned (one int4 per voxel), points 4-byte aligned");
     VoxCfg c;
     c.min_x = range_min[0]; c.min_y = range_min[1]; c.min_z = range_min[2];
     c.vs_x = voxel_size[0]; c.vs_y = voxel_size[1]; c.vs_z = voxel_size[2];
