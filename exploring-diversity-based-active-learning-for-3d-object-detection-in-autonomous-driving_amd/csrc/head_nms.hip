@@ -15,6 +15,13 @@
 
 #define HN_THREADS 1024
 #define HN_MAXK 1024            // nms_pre_max_size <= 1024
+#ifndef HN_G
+#define HN_G 8                  // tentative survivors per super-round of the greedy loop (<= 16)
+#endif
+#define HN_GB (HN_G <= 8 ? 8 : 16)                  // verdict bits kept per candidate
+#define HN_GPW (32 / HN_GB)                          // candidates per verdict word
+#define HN_GSH(j) (((j) % HN_GPW) * HN_GB)
+#define HN_GMASK ((1u << HN_GB) - 1u)
 
 struct HeadTask {
     const float* anchors;   // [A, 9] x y z w l h vx vy r
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
     __shared__ float sb_s[HN_MAXK][4];                  // standup box x1,y1,x2,y2
     __shared__ float area_s[HN_MAXK];
     __shared__ int keep_s[128];
-    __shared__ int s_next3[3], s_kept;
+    __shared__ int s_kept;
 
     // score of anchor a: max over classes of sigmoid(cls); label = first argmax
     auto anchor_score = [&](int a, int& label) -> float {
@@ -425,51 +432,81 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
     return;
 #endif
     // ---- greedy rotated NMS; only the first post_max survivors are needed.
-    // One barrier per survivor: the "next unsuppressed candidate" word is triple-buffered (read r,
-    // min-reduce into r+1, reset r+2), each wave contributes its lowest live lane with one LDS
-    // atomicMin (a same-address atomic per thread serialised ~1000 deep), and a candidate's
-    // suppressed flag lives in its own thread's register.
+    // The sequential rule -- the best live candidate survives and suppresses what overlaps it, repeat -- is evaluated HN_G
+    // candidates at a time: a super-round takes the next HN_G live candidates t_0 < t_1 < .. in rank order as TENTATIVE
+    // survivors, tests every later live candidate against each of them (the tentatives against each other included),
+    // and then resolves in rank order: t_g stands iff no STANDING t_h (h < g) suppresses it, and a candidate dies iff a
+    // standing tentative suppresses it.  That is the sequential outcome exactly (between two consecutive tentatives there
+    // is no other live candidate; verdicts of tentatives that fall are discarded), with one exact-clip phase -- the part
+    // whose latency bounds this kernel, ~10 us per phase -- per HN_G candidates instead of per survivor.
+    // The exact clips of a super-round are COMPACTED: the (candidate, tentative) pairs that survive the cheap tests (standup
+    // boxes overlap, the three IoU bounds allow a suppression) are appended to a work list and the first c threads clip them
+    // -- ceil(c / 64) waves run the ~3k-instruction clip instead of every wave that owns such a candidate.  Same clips,
+    // same arithmetic, same decisions as one survivor at a time.
     const int post = p.post_max < 128 ? p.post_max : 128;
-    // The exact clips of a round are COMPACTED: the candidates that survive the cheap tests against the new survivor (their
-    // standup boxes overlap, the two IoU bounds allow a suppression) are appended to a work list, and the first c threads
-    // of the workgroup clip them -- ceil(c / 64) waves run the ~3k-instruction clip instead of every wave that owns at
-    // least one such candidate (with 32 resident waves per CU all clipping, a round cost ~40k cycles; measured 2.8 of the
-    // kernel's 3.45 ms).  Same clips, same arithmetic, same decisions; two more barriers per round.
     int* work_s = eq_list;                             // selection is over: its tie list's storage holds the work list
-    unsigned char* dead_s = reinterpret_cast<unsigned char*>(hist);      // 1024 flags in the histogram's 1 KB
-    __shared__ int s_wcnt[2];
-    dead_s[tid] = 0;
-    if (tid == 0) { s_next3[0] = n > 0 ? 0 : n; s_next3[1] = n; s_next3[2] = n; s_wcnt[0] = 0; s_wcnt[1] = 0; }
-    __syncthreads();
-    bool dead = tid >= n;                              // this thread's candidate is suppressed / absent
-    int kept = 0, r = 0, wb = 0;
+    __shared__ unsigned long long live_m[HN_THREADS / 64];
+    __shared__ unsigned supm[HN_MAXK / HN_GPW];        // per candidate: HN_GB bits, bit g = "tentative g suppresses it"
+    __shared__ int s_wcnt;
+    for (int q = tid; q < HN_MAXK / HN_GPW; q += HN_THREADS) supm[q] = 0u;
+    if (tid == 0) s_wcnt = 0;
+    bool dead = tid >= n;                              // this thread's candidate is suppressed / kept / absent
+    int kept = 0;
     const float lim = 0.999f * p.iou_thresh;
     while (kept < post) {
-        const int i = s_next3[r];
-        if (i >= n) break;
-        const int r1 = r == 2 ? 0 : r + 1, r2 = r1 == 2 ? 0 : r1 + 1;
-        if (tid == 0) { keep_s[kept] = i; s_next3[r2] = n; }
-        ++kept;
-        if (!dead && tid > i) {
-            // standup-box prefilter (iou_jit, eps = 0): overlap must be strictly positive
-            const float iw = fminf(sb_s[i][2], sb_s[tid][2]) - fmaxf(sb_s[i][0], sb_s[tid][0]);
-            const float ih = fminf(sb_s[i][3], sb_s[tid][3]) - fmaxf(sb_s[i][1], sb_s[tid][1]);
-            if (iw > 0.f && ih > 0.f) {
-                // Two bounds that cannot change the outcome but spare exact clips: the intersection is at most the smaller
-                // box, the union at least the larger, so IoU <= min / max of the two areas; and the intersection is at most
-                // the overlap of the standup boxes, so IoU <= o / (A + B - o).  Both with a 0.1 % margin for their own
-                // rounding; NaN / inf areas compare false here exactly where the tests after the clip would.
-                const float ai = area_s[i], at = area_s[tid], o = iw * ih;
-                bool maybe = fminf(ai, at) >= lim * fmaxf(ai, at) && o >= lim * (ai + at - o);
-                if (maybe) maybe = obb_bound(cx_s[i], cy_s[i], ai, cx_s[tid], cy_s[tid], at, lim) &&
-                                   obb_bound(cx_s[tid], cy_s[tid], at, cx_s[i], cy_s[i], ai, lim);
-                if (maybe) work_s[atomicAdd(&s_wcnt[wb], 1)] = tid;
+        const unsigned long long live = __ballot(!dead);
+        if ((tid & 63) == 0) live_m[tid >> 6] = live;
+        __syncthreads();                               // live masks (and the previous super-round's clean-up) visible
+        int tg[HN_G];
+        int nt = 0;
+#pragma unroll
+        for (int g = 0; g < HN_G; ++g) tg[g] = HN_MAXK;
+        for (int w = 0; w < HN_THREADS / 64 && nt < HN_G; ++w) {
+            unsigned long long m = live_m[w];
+            while (m && nt < HN_G) {
+                const int idx = w * 64 + (int)__builtin_ctzll(m);
+                m &= m - 1ull;
+#pragma unroll
+                for (int g = 0; g < HN_G; ++g) if (g == nt) tg[g] = idx;
+                ++nt;
             }
         }
-        __syncthreads();                               // the round's work list is complete
-        const int c = s_wcnt[wb];
-        if (tid < c) {
-            const int j = work_s[tid];
+        if (nt == 0) break;                            // workgroup-uniform
+        if (nt > post - kept) nt = post - kept;
+        if (!dead && tid > tg[0]) {
+            unsigned gm = 0u;                          // tentatives this candidate has to be clipped against
+#pragma unroll
+            for (int g = 0; g < HN_G; ++g) {
+                const int i = tg[g];
+                if (g >= nt || tid <= i) continue;
+                // standup-box prefilter (iou_jit, eps = 0): overlap must be strictly positive
+                const float iw = fminf(sb_s[i][2], sb_s[tid][2]) - fmaxf(sb_s[i][0], sb_s[tid][0]);
+                const float ih = fminf(sb_s[i][3], sb_s[tid][3]) - fmaxf(sb_s[i][1], sb_s[tid][1]);
+                if (iw > 0.f && ih > 0.f) {
+                    // Bounds that cannot change the outcome but spare exact clips: the intersection is at most the smaller
+                    // box, the union at least the larger, so IoU <= min / max of the two areas; the intersection is at most
+                    // the overlap of the standup boxes, so IoU <= o / (A + B - o); and at most the overlap in either box's
+                    // own frame.  All with a 0.1 % margin for their own rounding; NaN / inf areas compare false here exactly
+                    // where the tests after the clip would.
+                    const float ai = area_s[i], at = area_s[tid], o = iw * ih;
+                    bool maybe = fminf(ai, at) >= lim * fmaxf(ai, at) && o >= lim * (ai + at - o);
+                    if (maybe) maybe = obb_bound(cx_s[i], cy_s[i], ai, cx_s[tid], cy_s[tid], at, lim) &&
+                                       obb_bound(cx_s[tid], cy_s[tid], at, cx_s[i], cy_s[i], ai, lim);
+                    if (maybe) gm |= 1u << g;
+                }
+            }
+            if (gm) work_s[atomicAdd(&s_wcnt, 1)] = (int)((unsigned)tid | (gm << 16));      // one entry per candidate: <= n <= HN_MAXK
+        }
+        __syncthreads();                               // the super-round's work list is complete
+        const int c = s_wcnt;
+        // one (entry, tentative) slot per thread, so that a candidate that meets several tentatives has its clips side by
+        // side in different lanes instead of one after the other in one lane
+        for (int w = tid; w < c * HN_G; w += HN_THREADS) {
+            const int pr = work_s[w / HN_G], j = pr & 0xffff, g = w % HN_G;
+            if (!(((unsigned)pr >> (16 + g)) & 1u)) continue;
+            int i = tg[0];
+#pragma unroll
+            for (int h = 1; h < HN_G; ++h) if (h == g) i = tg[h];
 #if defined(AL3D_NMS_STOP) && AL3D_NMS_STOP == 3
             const float inter = 0.f;
 #else
@@ -477,17 +514,30 @@ __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
 #endif
             if (inter > 0.f) {
                 const float uni = area_s[i] + area_s[j] - inter;
-                if (uni > 0.f && inter / uni >= p.iou_thresh) dead_s[j] = 1;
+                if (uni > 0.f && inter / uni >= p.iou_thresh) atomicOr(&supm[j / HN_GPW], (1u << g) << HN_GSH(j));
             }
         }
-        if (tid == 0) s_wcnt[wb ^ 1] = 0;              // next round's counter (last read before the previous round's end)
         __syncthreads();                               // the verdicts are visible
-        if (!dead && dead_s[tid]) dead = true;
-        const unsigned long long live = __ballot(!dead && tid > i);
-        if (live && (tid & 63) == 0) atomicMin(&s_next3[r1], (tid & ~63) + (int)__builtin_ctzll(live));
-        __syncthreads();
-        r = r1;
-        wb ^= 1;
+        unsigned standing = 1u;                        // t_0 always stands
+#pragma unroll
+        for (int g = 1; g < HN_G; ++g) {
+            if (g >= nt) continue;
+            const unsigned mg = (supm[tg[g] / HN_GPW] >> HN_GSH(tg[g])) & HN_GMASK;
+            if (!(mg & standing)) standing |= 1u << g;
+        }
+        const unsigned mine = (supm[tid / HN_GPW] >> HN_GSH(tid)) & HN_GMASK;
+        if (mine & standing) dead = true;
+#pragma unroll
+        for (int g = 0; g < HN_G; ++g) if (g < nt && tid == tg[g]) dead = true;      // kept or fallen: no longer a candidate
+        if (tid == 0) {
+            int k2 = kept;
+#pragma unroll
+            for (int g = 0; g < HN_G; ++g) if (g < nt && ((standing >> g) & 1u)) keep_s[k2++] = tg[g];
+        }
+        kept += __builtin_popcount(standing);
+        __syncthreads();                               // everybody has read supm / s_wcnt
+        if (tid % HN_GPW == 0) supm[tid / HN_GPW] = 0u;
+        if (tid == 0) s_wcnt = 0;
     }
     if (tid == 0) s_kept = kept;
     __syncthreads();
