@@ -64,9 +64,21 @@ __global__ void vox_first_kernel(const float* __restrict__ pts, const int64_t* _
     const float p3[3] = {xyz[0], xyz[1], xyz[2]};
     const int64_t cell = vox_cell(p3, c);
     // cells < 2^31 is checked on the host, so one int carries the cell id
-    pcell_lo[i] = cell < 0 ? -1 : (int)cell;
+    const int ci = cell < 0 ? -1 : (int)cell;
+    pcell_lo[i] = ci;
     pcell_hi[i] = b;
-    if (cell >= 0) atomicMin(&first[(int64_t)b * cells + cell], (int)(i - off[b]));
+    // A ring scan puts neighbouring returns into the same voxel: a lane whose (frame, cell) also sits in one of the four
+    // lanes below it has the larger point index, so its atomicMin could not change the cell's minimum -- it is skipped
+    // (the lowest lane of such a group always issues).  Lanes past the end of the list have left; their shuffles return the
+    // reader's own value, which the lane test discards.
+    const int lane = threadIdx.x & 63;
+    bool dup = false;
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) {
+        const int c2 = __shfl_up(ci, k), b2 = __shfl_up(b, k);
+        dup = dup || (lane >= k && c2 == ci && b2 == b);
+    }
+    if (ci >= 0 && !dup) atomicMin(&first[(int64_t)b * cells + ci], (int)(i - off[b]));
 }
 
 // pass 2: leader flags
@@ -78,7 +90,14 @@ __global__ void vox_flag_kernel(const int64_t* __restrict__ off, int B, int64_t 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= off[B]) return;
     const int cell = pcell[i], b = pframe[i];
-    const int lead = cell >= 0 ? first[(int64_t)b * cells + cell] : -1;
+    // runs of adjacent lanes in one (frame, cell): the run's first lane probes the grid, the others take its answer
+    const int lane = threadIdx.x & 63;
+    const int c1 = __shfl_up(cell, 1), b1 = __shfl_up(b, 1);
+    const bool same = lane > 0 && cell >= 0 && c1 == cell && b1 == b;
+    const unsigned long long starts = __ballot(!same);
+    const int start = 63 - __builtin_clzll(starts & ((2ull << lane) - 1ull));
+    int lead = (cell >= 0 && !same) ? first[(int64_t)b * cells + cell] : -1;
+    lead = __shfl(lead, start);
     plead[i] = lead;
     flag[i] = (cell >= 0 && lead == (int)(i - off[b])) ? 1 : 0;
 }
@@ -114,12 +133,29 @@ __global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg
     if (i >= off[B]) return;
     const int cell = pcell[i], b = pframe[i];
     int row = -1, pos = 0;
-    if (cell >= 0) {
-        const int lead = prow[i];
+    const int lead = cell >= 0 ? prow[i] : -1;
+    // runs of adjacent lanes of one voxel (same frame and leader): the run's first lane looks the row up and takes the
+    // run's slots with ONE atomicAdd, the others derive theirs (slot order inside a voxel is irrelevant: pass 6 sorts)
+    const int lane = threadIdx.x & 63;
+    const int l1 = __shfl_up(lead, 1), b1 = __shfl_up(b, 1);
+    const bool same = lane > 0 && cell >= 0 && l1 == lead && b1 == b;
+    const unsigned long long act = __ballot(true), starts = __ballot(!same);
+    const unsigned long long upto = (2ull << lane) - 1ull;
+    const int start = 63 - __builtin_clzll(starts & upto);
+    const unsigned long long later = starts & ~upto;
+    const int end = later ? (int)__builtin_ctzll(later) : 64 - (int)__builtin_clzll(act);
+    if (cell >= 0 && !same) {
         const int vid = lscan[off[b] + lead] - lscan[off[b]];
         if (vid < c.max_voxels) {
             row = row_base[b] + vid;
-            pos = atomicAdd(&cnt[row], 1);          // arrival position inside the voxel: the bucket slot (pass 5)
+            pos = atomicAdd(&cnt[row], end - start);   // arrival positions inside the voxel: the bucket slots (pass 5)
+        }
+    }
+    row = __shfl(row, start);
+    pos = __shfl(pos, start) + (lane - start);
+    if (row < 0) pos = 0;
+    if (cell >= 0) {
+        if (row >= 0) {
             if (lead == (int)(i - off[b])) {
                 const int x = cell % c.gx, y = (cell / c.gx) % c.gy, z = cell / (c.gx * c.gy);
                 *reinterpret_cast<int4*>(coords + 4 * (int64_t)row) = make_int4(b, z, y, x);
