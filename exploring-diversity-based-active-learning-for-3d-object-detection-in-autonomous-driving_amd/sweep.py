@@ -77,9 +77,11 @@ PIPELINE = {"1": "split", "split": "split", "0": None, "off": None, "none": None
 _SIDE = {}
 
 
-# AL3D_SIDE_AFTER_SPARSE=1: in "ahead" mode the side stream starts batch i+1's voxelizer + rulebook when batch i's sparse
-# encoder has finished (beside the dense neck) instead of right away (beside the level-0 sparse convolutions)
-SIDE_AFTER_SPARSE = _os.environ.get("AL3D_SIDE_AFTER_SPARSE", "0") == "1"
+# AL3D_SIDE_AFTER_SPARSE (default 1): in "ahead" mode the side stream starts batch i+1's voxelizer + rulebook when batch i's
+# sparse encoder has finished (beside the dense neck) instead of right away (beside the level-0 sparse convolutions, the
+# kernels that suffer most from it); 0 = release it at once.  +1.3 % at the round-3 kernels (it was +-0 while the side work
+# was twice as long: DESIGN.md 5.3)
+SIDE_AFTER_SPARSE = _os.environ.get("AL3D_SIDE_AFTER_SPARSE", "1") == "1"
 
 
 # AL3D_MAIN_PRIORITY=1: the main (convolution) work runs on a high-priority HIP stream
