@@ -18,9 +18,23 @@ class LazyDetections:
     """``list[dict(box3d_lidar, scores, label_preds, metadata)]`` whose device->host hand-off
     (one copy of the per-(sample, task) counts) happens on first access."""
 
-    def __init__(self, boxes, scores, labels, counts, done, meta):
-        self._raw = (boxes, scores, labels, counts, done, meta)
+    def __init__(self, boxes=None, scores=None, labels=None, counts=None, done=None, meta=None, launch=None, batch=0):
+        # ``launch``: the decode + NMS launch itself, not issued yet (the sweep releases it beside the next batch's dense
+        # neck: MultiGroupHead.flush_deferred); anything that reads the detections issues it first
+        self._launch = launch
+        self._batch = batch
+        self._raw_ = None if launch is not None else (boxes, scores, labels, counts, done, meta)
         self._list = None
+
+    def launch(self, gate=None):
+        if self._raw_ is None:
+            self._raw_ = self._launch(gate)
+            self._launch = None
+
+    @property
+    def _raw(self):
+        self.launch()
+        return self._raw_
 
     def _materialize(self):
         if self._list is None:
@@ -58,7 +72,7 @@ class LazyDetections:
         return ops.frame_weighted_entropy(scores, labels, counts, class_weight)
 
     def __len__(self):
-        return self._raw[3].shape[0]
+        return self._batch if self._raw_ is None else self._raw_[3].shape[0]
 
     def __getitem__(self, i):
         return self._materialize()[i]
@@ -198,8 +212,13 @@ class MultiGroupHead(nn.Module):
                                        int(os.environ.get("AL3D_NMS_CU0", "0")))
         ready = torch.cuda.Event()
         ready.record(main)
-        with torch.cuda.stream(self._side):
+        meta = example.get("metadata") or [None] * B
+
+        def launch(gate=None):
+          with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
+            if gate is not None:
+                self._side.wait_event(gate)
             boxes = torch.empty((B, nt, post, 9), dtype=torch.float32, device=dev)
             scores = torch.empty((B, nt, post), dtype=torch.float32, device=dev)
             labels = torch.empty((B, nt, post), dtype=torch.int32, device=dev)
@@ -219,5 +238,16 @@ class MultiGroupHead(nn.Module):
                      _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), _ptr(ws), self._side.cuda_stream)
             done = torch.cuda.Event()
             done.record(self._side)
-        meta = example.get("metadata") or [None] * B
-        return LazyDetections(boxes, scores, labels, counts, done, meta)
+          return boxes, scores, labels, counts, done, meta
+
+        if getattr(self, "defer_nms", False):
+            det = LazyDetections(launch=launch, batch=B)
+            self._deferred = getattr(self, "_deferred", []) + [det]
+            return det
+        return LazyDetections(*launch())
+
+    def flush_deferred(self, gate=None):
+        """Issue the decode + NMS launches that ``predict`` held back (``defer_nms``), after ``gate`` (an event) if given."""
+        pending, self._deferred = getattr(self, "_deferred", []), []
+        for det in pending:
+            det.launch(gate)
