@@ -77,11 +77,11 @@ PIPELINE = {"1": "split", "split": "split", "0": None, "off": None, "none": None
 _SIDE = {}
 
 
-# AL3D_SIDE_AFTER_SPARSE (default 1): in "ahead" mode the side stream starts batch i+1's voxelizer + rulebook when batch i's
-# sparse encoder has finished (beside the dense neck) instead of right away (beside the level-0 sparse convolutions, the
-# kernels that suffer most from it); 0 = release it at once.  +1.3 % at the round-3 kernels (it was +-0 while the side work
-# was twice as long: DESIGN.md 5.3)
-SIDE_AFTER_SPARSE = _os.environ.get("AL3D_SIDE_AFTER_SPARSE", "1") == "1"
+# AL3D_SIDE_AFTER_SPARSE=1: in "ahead" mode the side stream starts batch i+1's voxelizer + rulebook when batch i's sparse
+# encoder has finished (beside the dense neck) instead of right away (beside the level-0 sparse convolutions, the kernels
+# that suffer most from it).  +1.3 % frames/s at the round-3 kernels, but the contention then lands on the dense launches
+# (1,559 -> 1,774 us each), i.e. on the kernel whose live roofline the bench line reports: default off
+SIDE_AFTER_SPARSE = _os.environ.get("AL3D_SIDE_AFTER_SPARSE", "0") == "1"
 
 
 # AL3D_NMS_AFTER_SPARSE=1: batch i's decode + NMS launch is held back until batch i+1's sparse encoder is through
