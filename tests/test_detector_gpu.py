@@ -824,3 +824,52 @@ def test_round2_sparse_entry_points_accept_empty_inputs():
     sp = SparseTensor(D.rows_convert(x, True), torch.zeros((64, 4), dtype=torch.int32, device=DEV), [1, 8, 8], 1, pair_rows=True)
     assert float((sp.features - x).abs().max()) <= 2.0 ** -21 * float(x.abs().max())
     assert sp.features is sp.features                                  # converted once
+
+
+@pytest.mark.parametrize("W", [2, 3, 11])                     # 2: narrower than a 12-byte probe (the per-(row, kz, ky) kernel runs)
+@pytest.mark.parametrize("strided", [False, True])
+def test_tiled_27_tap_table_equals_plain_table(W, strided):
+    """`sp_table_rows27_kernel` (one thread per row, nine 12-byte probes, ballot-built tap masks) against the plain
+    (row, kz, ky)-per-thread tables on a small, densely filled grid -- every border case of the clamped probes (x0 = -1,
+    x0 = W - 2, rows beyond n) occurs -- and the tap masks against the table itself."""
+    import ctypes
+    from al3d import lib
+    rng = np.random.default_rng(W * 2 + int(strided))
+    B, D, H = 2, 5, 7
+    cells = np.array([(b, z, y, x) for b in range(B) for z in range(D) for y in range(H) for x in range(W)], np.int32)
+    coords = cells[rng.permutation(len(cells))[: max(3, int(0.7 * len(cells)))]].copy()
+    n = len(coords)
+    grid = torch.full((B * D * H * W,), -1, dtype=torch.int32, device=DEV)
+    c_dev = _t(coords)
+    st = torch.cuda.current_stream().cuda_stream
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    lib.call("al3d_sp_scatter_index", ptr(c_dev), n, B, D, H, W, ptr(grid), 1, st)
+    i3 = lambda *v: (ctypes.c_int * 3)(*v)
+    if strided:                                               # output sites: every cell of the stride-2 output grid
+        OD, OH, OW = (D + 2 - 3) // 2 + 1, (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        out = np.array([(b, z, y, x) for b in range(B) for z in range(OD) for y in range(OH) for x in range(OW)], np.int32)
+        o_dev, m = _t(out), len(out)
+        pitch = lib.load().al3d_sp_table_pitch(m)
+        plain = torch.empty((27, m), dtype=torch.int32, device=DEV)
+        tiled = torch.full((27, pitch), 12345, dtype=torch.int32, device=DEV)
+        tmask = torch.full((pitch // 32,), -1, dtype=torch.int32, device=DEV)
+        lib.call("al3d_sp_down_table", ptr(o_dev), m, i3(3, 3, 3), i3(2, 2, 2), i3(1, 1, 1), B, D, H, W, ptr(grid), ptr(plain), st)
+        lib.call("al3d_sp_down_table_tiles", ptr(o_dev), m, i3(3, 3, 3), i3(2, 2, 2), i3(1, 1, 1), B, D, H, W, ptr(grid),
+                 ptr(tiled), pitch, ptr(tmask), st)
+    else:
+        m = n
+        pitch = lib.load().al3d_sp_table_pitch(m)
+        plain = torch.empty((27, m), dtype=torch.int32, device=DEV)
+        tiled = torch.full((27, pitch), 12345, dtype=torch.int32, device=DEV)
+        tmask = torch.full((pitch // 32,), -1, dtype=torch.int32, device=DEV)
+        lib.call("al3d_sp_subm_table", ptr(c_dev), m, B, D, H, W, ptr(grid), 3, 3, 3, ptr(plain), st)
+        lib.call("al3d_sp_subm_table_tiles", ptr(c_dev), m, B, D, H, W, ptr(grid), 3, 3, 3, ptr(tiled), pitch, ptr(tmask), st)
+    torch.cuda.synchronize()
+    plain, tiled, tmask = plain.cpu().numpy(), tiled.cpu().numpy(), tmask.cpu().numpy().view(np.uint32)
+    assert np.array_equal(tiled[:, :m], plain)
+    assert np.all(tiled[:, m:] == -1)                         # rows beyond n: no neighbour
+    assert (plain >= 0).any() and (plain < 0).any()
+    want = np.zeros(pitch // 32, np.uint32)
+    for k in range(27):
+        want |= ((tiled[k].reshape(-1, 32) >= 0).any(1).astype(np.uint32) << np.uint32(k))
+    assert np.array_equal(tmask, want)
