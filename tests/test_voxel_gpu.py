@@ -70,3 +70,42 @@ def test_hip_voxelizer_out_of_range_and_nan():
                  dtype=np.float32)
     out = run_hip([p], 10, 100)
     assert out["coords"].tolist() == [[0, 0, 0, 0], [0, 39, 1023, 1023]]
+
+
+def test_hip_voxelizer_runs_of_identical_cells(oracle):
+    """The wave-level aggregation of the voxelizer (one first-index atomic / grid probe / slot request per run of adjacent
+    lanes in a cell) on the patterns that stress it: one cell for hundreds of consecutive points (runs across whole waves,
+    far beyond max_points), two cells alternating point by point (no run at all, duplicates one lane apart from the
+    run test), short runs, out-of-range points inside runs, and frame boundaries in the middle of a wave.  Bit-exact
+    against the oracle per frame."""
+    rng = np.random.default_rng(3)
+
+    def cell_point(ix, iy, iz, k):
+        base = np.array([-51.2 + 0.1 * ix, -51.2 + 0.1 * iy, -5.0 + 0.2 * iz], np.float32)
+        jit = rng.uniform(0.01, 0.09, (k, 3)).astype(np.float32) * np.array([1, 1, 2], np.float32)
+        return np.concatenate([base + jit, rng.uniform(0, 255, (k, 1)).astype(np.float32), np.zeros((k, 1), np.float32)], 1)
+
+    a = cell_point(500, 500, 10, 300)                                        # one cell, 300 points in a row
+    b = np.stack([cell_point(100, 200, 5, 1)[0] if i % 2 else cell_point(101, 200, 5, 1)[0] for i in range(150)])
+    c = np.concatenate([cell_point(10 + i, 20, 3, int(r)) for i, r in enumerate(rng.integers(1, 7, 60))])
+    d = cell_point(700, 300, 20, 40)
+    d[5:9, 0] = 1e4                                                          # out of range inside a run
+    d[20, 1] = np.nan
+    f0 = np.concatenate([a, b, c, d]).astype(np.float32)                     # 300 + 150 + ~200 + 40 points: ends mid-wave
+    f1 = np.concatenate([cell_point(500, 500, 10, 70), c[::-1], a[:33]]).astype(np.float32)   # same cells, next frame
+    f2 = cell_point(1, 1, 1, 5)
+    frames = [f0, f1, np.zeros((0, 5), np.float32), f2]
+    out = run_hip(frames, 10, 9000)
+    row = 0
+    for bidx, pts in enumerate(frames):
+        v, co, n, f = oracle.voxelize(pts, RANGE_MIN, VSIZE, GRID, 10, 9000)
+        m = len(co)
+        assert out["num_voxels"][bidx] == m
+        sl = slice(row, row + m)
+        assert np.all(out["coords"][sl, 0] == bidx)
+        assert np.array_equal(out["coords"][sl, 1:], co)
+        assert np.array_equal(out["num_points"][sl], n)
+        assert np.array_equal(out["voxels"][sl].view(np.int32), v.view(np.int32))
+        assert np.array_equal(out["feat"][sl].view(np.int32), f.view(np.int32))
+        row += m
+    assert row == len(out["coords"]) and out["num_points"].max() == 10
