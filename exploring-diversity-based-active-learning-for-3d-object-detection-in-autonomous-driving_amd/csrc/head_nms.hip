@@ -46,6 +46,7 @@ struct HeadParams {
     unsigned* sbits;        // workspace: per (sample, task, anchor) score bit pattern, 0 = below threshold
     int64_t task_soff[8];   // offset of task t inside one sample's block of sbits
     int64_t sample_stride;  // sum of A over the tasks
+    int order[8];           // tasks by anchor count, largest first: the long problems of a launch start first
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(256) void head_score_rows_kernel(HeadParams p, int 
 
 __global__ __launch_bounds__(HN_THREADS) void head_nms_kernel(HeadParams p)
 {
-    const int b = blockIdx.x / p.ntasks, t = blockIdx.x % p.ntasks;
+    // 768 problems on 512 resident workgroups (two per CU): the ones that start late should be the short ones
+    const int t = p.order[blockIdx.x / p.B], b = blockIdx.x % p.B;
     const HeadTask tk = p.task[t];
     const int tid = threadIdx.x;
     const float* hb = p.hout + (int64_t)b * p.HW * p.CH;
@@ -610,6 +612,11 @@ extern "C" int al3d_head_decode_nms(const float* hout, int B, int HW, int CH, in
     int amax = 0;
     for (int t = 0; t < ntasks; ++t) { p.task_soff[t] = soff; soff += task_A[t]; if (task_A[t] > amax) amax = task_A[t]; }
     p.sample_stride = soff;
+    for (int t = 0; t < 8; ++t) p.order[t] = t;
+    for (int a = 1; a < ntasks; ++a)                   // insertion sort by anchor count, descending, stable
+        for (int q = a; q > 0 && task_A[p.order[q]] > task_A[p.order[q - 1]]; --q) {
+            const int tmp = p.order[q]; p.order[q] = p.order[q - 1]; p.order[q - 1] = tmp;
+        }
     int cls_lo = CH, cls_hi = 0;
     for (int t = 0; t < ntasks; ++t) {
         if (cls_off[t] < cls_lo) cls_lo = cls_off[t];
