@@ -47,8 +47,14 @@ __device__ __forceinline__ int tk_swz(int r) { return (r & 1) | (((r >> 3) & 1) 
 
 __device__ __forceinline__ void tk_split(float x, _Float16& h, _Float16& l)
 {
+    // x is pinned to ONE rounded fp32 value first: with the producer's arithmetic visible (x = a * b), the compiler may
+    // otherwise feed the residual below from the unrounded product while h rounds the rounded one -- at an f16 tie the
+    // two then disagree by a whole f16 ulp (seen in the fused MLP: GELU output 0.27600098, low part with the wrong sign)
+    asm volatile("" : "+v"(x));
     h = (_Float16)x;
-    l = (_Float16)__builtin_fmaf((float)h, -2048.0f, x * 2048.0f);   // (x - h) * 2^11 exactly
+    float hf = (float)h;
+    asm volatile("" : "+v"(hf));                                     // the residual is taken against THIS h
+    l = (_Float16)__builtin_fmaf(hf, -2048.0f, x * 2048.0f);         // (x - h) * 2^11 exactly
 }
 __device__ __forceinline__ void tk_split8(const float (&v)[8], f16x8& ph, f16x8& pl)
 {
@@ -474,6 +480,200 @@ extern "C" int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt
     default: hipLaunchKernelGGL(tok_linear_f16x3_kernel<3>, grid, dim3(256), 0, s, p); break;
     }
     AL3D_CHECK_LAUNCH("tok_linear_f16x3_kernel");
+    return AL3D_OK;
+}
+
+// ------------------------------------------------------------------ fused MLP half of a Swin block (C = 96, 192)
+// x += fc2(gelu(fc1(LN2(x)))) as ONE kernel: the [tokens, 4 C] hidden activation -- 8 C of the 26 C floats a block moves
+// per token when its six GEMM / LN launches run separately, and these layers are bandwidth-bound -- never leaves the
+// registers.  Everything is computed TRANSPOSED so that one GEMM's accumulator is the next one's operand as it stands:
+// a wave owns 32 tokens (the n dimension of every product); LN2 runs on the lane's half row, its split (xh, xl') IS the B
+// operand of H^T = W1 xn^T; a 32 x 32 tile of H^T (hidden units down the accumulator registers, tokens across the lanes)
+// gets bias + exact GELU + the f16 split in place and IS the B operand of out^T += W2 H^T -- the hidden index inside a
+// 16-chunk is then the accumulator's row order (e&3) + 8 (e>>2) + 4 fh + 16 q, which the host bakes into the W2 image.
+// The weights are the A operands: per hidden tile t the image holds W1's K/16 x (wh, wl) fragments and W2's
+// (C/32) x 2 x (wh, wl) fragments in MFMA lane order (C/4 KB), brought in by LDS-DMA into a two-stage ring shared by the
+// workgroup's four waves, one barrier per hidden tile.  f16x3 arithmetic as everywhere (three products per MAC:
+// wd xl' + wl xh + wh xh, wd = wh 2^-11).  The result leaves through a per-wave LDS transposition (32 tokens x 32 channels
+// at a time) so that residual loads and stores are 16-byte pieces of 128-byte row segments.
+struct TokMlpParams {
+    float* x;                // [T][C] residual stream, updated in place
+    const _Float16* image;   // [NT][C/4 KB]: per hidden tile W1 fragments [C/16][2][64][8], then W2 fragments [C/32][2][2][64][8]
+    const float* gamma;      // [C] LN2
+    const float* beta;       // [C]
+    const float* bias1;      // [32 NT]
+    const float* bias2;      // [C]
+    float scale1, scale2, eps;     // 2^-s of the two weight splits
+    int64_t T;
+    int NT;                  // hidden / 32
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void tok_mlp_f16x3_kernel(TokMlpParams p)
+{
+    constexpr int KC = C / 16, U = C / 32, TILE = C * 256, W2OFF = KC * 2048;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char mlp_smem[];
+    unsigned char* ring = mlp_smem;                                     // 2 x TILE
+    float* b1s = reinterpret_cast<float*>(mlp_smem + 2 * TILE);         // [32 NT]
+    float* gs = b1s + 32 * p.NT;                                        // gamma [C] | beta [C] | bias2 [C]
+    float* scr = gs + 3 * C + (threadIdx.x >> 6) * (32 * 33);           // per wave: 32 tokens x 33
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned ring_base = (unsigned)(size_t)(tk_lds_void*)ring;
+
+    auto issue = [&](int t) {                                           // hidden tile t -> ring stage t & 1
+        const char* src = reinterpret_cast<const char*>(p.image) + (int64_t)t * TILE + wave * 1024 + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (t & 1) * TILE + wave * 1024);
+#pragma unroll
+        for (int r = 0; r < TILE / 4096; ++r)
+            __builtin_amdgcn_global_load_lds((tk_gbl_void*)(src + r * 4096), (tk_lds_void*)(size_t)(dst + r * 4096), 16, 0, 0);
+    };
+    issue(0);
+    for (int i = tid; i < 32 * p.NT; i += 256) b1s[i] = p.bias1[i];
+    for (int i = tid; i < C; i += 256) { gs[i] = p.gamma[i]; gs[C + i] = p.beta[i]; gs[2 * C + i] = p.bias2[i]; }
+    __syncthreads();
+
+    // ---- LN2 of the wave's 32 tokens: lane (fr, fh) holds channels kc * 16 + fh * 8 + e of token fr
+    const int64_t tok = (int64_t)blockIdx.x * 128 + wave * 32 + fr;
+    const bool live = tok < p.T;
+    const float* xrow = p.x + (live ? tok : 0) * C + fh * 8;
+    float xv[KC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (live) { a = *reinterpret_cast<const float4*>(xrow + kc * 16); b = *reinterpret_cast<const float4*>(xrow + kc * 16 + 4); }
+        xv[kc][0] = a.x; xv[kc][1] = a.y; xv[kc][2] = a.z; xv[kc][3] = a.w;
+        xv[kc][4] = b.x; xv[kc][5] = b.y; xv[kc][6] = b.z; xv[kc][7] = b.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += xv[kc][e];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[kc][e] - mean; sq += d * d; }
+    sq += __shfl_xor(sq, 32);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + p.eps);
+    f16x8 xh[KC], xl[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = kc * 16 + fh * 8 + e;
+            v[e] = (xv[kc][e] - mean) * rstd * gs[ch] + gs[C + ch];
+        }
+        tk_split8(v, xh[kc], xl[kc]);
+    }
+
+    f32x16 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    for (int t = 0; t < p.NT; ++t) {
+        tk_wait_vm<0>();                                   // this wave's share of tile t has landed ...
+        __syncthreads();                                   // ... everyone's has, and nobody reads tile t - 1 any more
+        if (t + 1 < p.NT) issue(t + 1);
+        const unsigned char* st = ring + (t & 1) * TILE + lane * 16;
+        f32x16 h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(st + (kc * 2) * 1024);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(st + (kc * 2 + 1) * 1024);
+            const f16x8 wd = tk_lift_down(wh);
+            h = TK_MFMA(wd, xl[kc], h);
+            h = TK_MFMA(wl, xh[kc], h);
+            h = TK_MFMA(wh, xh[kc], h);
+        }
+        // bias + GELU + split: registers 8 q .. 8 q + 7 are B-operand chunk q (hidden unit (e&3) + 8 (e>>2) + 4 fh + 16 q)
+        f16x8 hh[2], hl[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(b1s + 32 * t + 16 * q + 8 * g + 4 * fh);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = tk_gelu(h[8 * q + 4 * g + e] * p.scale1 + bb[e]);
+            }
+            tk_split8(v, hh[q], hl[q]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(st + W2OFF + ((u * 2 + q) * 2) * 1024);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(st + W2OFF + ((u * 2 + q) * 2 + 1) * 1024);
+                const f16x8 wd = tk_lift_down(wh);
+                acc[u] = TK_MFMA(wd, hl[q], acc[u]);
+                acc[u] = TK_MFMA(wl, hh[q], acc[u]);
+                acc[u] = TK_MFMA(wh, hh[q], acc[u]);
+            }
+    }
+
+    // ---- out^T tiles -> rows: 32 tokens x 32 channels at a time through the wave's scratch
+    const int64_t tok0 = (int64_t)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = (r & 3) + 8 * (r >> 2) + 4 * fh;             // channel inside the tile; token = fr
+            scr[fr * 33 + cl] = acc[u][r] * p.scale2 + gs[2 * C + 32 * u + cl];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q, tk = i >> 3, g = i & 7;        // token tk, channels 4 g .. 4 g + 3
+            if (tok0 + tk < p.T) {
+                float* o = p.x + (tok0 + tk) * C + 32 * u + 4 * g;
+                float4 v = *reinterpret_cast<const float4*>(o);
+                v.x += scr[tk * 33 + 4 * g]; v.y += scr[tk * 33 + 4 * g + 1];
+                v.z += scr[tk * 33 + 4 * g + 2]; v.w += scr[tk * 33 + 4 * g + 3];
+                *reinterpret_cast<float4*>(o) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int64_t al3d_tok_mlp_image_bytes(int C, int hidden) { return (int64_t)(hidden / 32) * C * 256; }
+
+extern "C" int al3d_tok_mlp_f16x3(float* x, int64_t T, int C, int hidden, const float* gamma, const float* beta, float eps,
+                                  const void* image, float scale1, const float* bias1, float scale2, const float* bias2,
+                                  void* stream)
+{
+    AL3D_REQUIRE(x && gamma && beta && image && bias1 && bias2, "al3d_tok_mlp_f16x3: null pointer");
+    AL3D_REQUIRE(C == 96 || C == 192, "al3d_tok_mlp_f16x3: C must be 96 or 192 (the stages whose MLP is bandwidth-bound), got %d", C);
+    AL3D_REQUIRE(hidden >= 32 && hidden % 32 == 0 && T >= 0, "al3d_tok_mlp_f16x3: hidden must be a multiple of 32");
+    AL3D_REQUIRE((((uintptr_t)x | (uintptr_t)image) & 15) == 0, "al3d_tok_mlp_f16x3: x / image must be 16-byte aligned");
+    if (T == 0) return AL3D_OK;
+    TokMlpParams p;
+    p.x = x; p.image = (const _Float16*)image; p.gamma = gamma; p.beta = beta; p.bias1 = bias1; p.bias2 = bias2;
+    p.scale1 = scale1; p.scale2 = scale2; p.eps = eps; p.T = T; p.NT = hidden / 32;
+    const size_t lds = (size_t)2 * C * 256 + ((size_t)hidden + 3 * C + 4 * 32 * 33) * 4;
+    const dim3 grid((unsigned)al3d_cdiv(T, 128));
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 96) {
+        hipLaunchKernelGGL(tok_mlp_f16x3_kernel<96>, grid, dim3(256), lds, s, p);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)tok_mlp_f16x3_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return al3d_fail(AL3D_ELAUNCH, "al3d_tok_mlp_f16x3: cannot raise the dynamic LDS limit");
+            attr = true;
+        }
+        hipLaunchKernelGGL(tok_mlp_f16x3_kernel<192>, grid, dim3(256), lds, s, p);
+    }
+    AL3D_CHECK_LAUNCH("tok_mlp_f16x3_kernel");
     return AL3D_OK;
 }
 

@@ -11,7 +11,8 @@ relative_position_bias_table}, norm2, ffn.layers.0.0, ffn.layers.1}``; ``stages.
 with the ``nn.Unfold`` channel order (c * 4 + kh * 2 + kw); ``norm<i>`` on the output levels; the relative position
 index built by mmdet's ``double_step_seq``.  **Parity unpinned** (no source, no checkpoint, no fixture).
 
-How a block runs (seven launches, no torch op touches an activation):
+How a block runs (seven launches -- five at embed dim 96, where LN2 / fc1 / fc2 are ONE kernel, al3d_tok_mlp_f16x3 --; no torch
+op touches an activation):
   LN1 gathered into (shifted) window order, padding rows zero, pair rows   al3d_tok_layernorm_f32
   qkv projection                                                           al3d_tok_linear_f16x3
   49 x 49 attention per (window, head) with bias + region mask, pair rows  al3d_tok_window_attention_f32
@@ -92,6 +93,13 @@ class ShiftWindowMSA(nn.Module):
         self.w_msa = WindowMSA(embed_dims, num_heads, (window_size, window_size), qkv_bias, qk_scale)
 
 
+# AL3D_SWIN_MLP=split: LN2 / fc1 / fc2 as three launches everywhere (default "fused": one kernel where it is faster)
+FUSED_MLP = _os.environ.get("AL3D_SWIN_MLP", "fused") != "split"
+# measured at 16 samples per launch: C = 96 0.87 ms fused against 1.50 ms for LN2 + fc1 + fc2; C = 192 1.09 against 0.94 (the
+# 255-register, one-workgroup-per-CU instance loses to the three launches): AL3D_SWIN_MLP_DIMS=96,192 to force both
+FUSED_MLP_DIMS = tuple(int(v) for v in _os.environ.get("AL3D_SWIN_MLP_DIMS", "96").split(","))
+
+
 class _FFN(nn.Module):
     """mmcv FFN(num_fcs=2): layers = [Sequential(Linear, GELU, Dropout), Linear, Dropout]; residual outside."""
 
@@ -105,6 +113,14 @@ class _FFN(nn.Module):
         fc1, fc2 = self.layers[0][0], self.layers[1]
         return self._pk.get(device, (fc1, fc2), lambda: (T.PackedLinear(fc1.weight, fc1.bias),
                                                          T.PackedLinear(fc2.weight, fc2.bias)))
+
+    def packed_fused(self, device, norm):
+        """LN2 + fc1 + fc2 in the fused kernel's format (``al3d_tok_mlp_f16x3``; embed dims 96 / 192)."""
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        if getattr(self, "_pkf", None) is None:
+            object.__setattr__(self, "_pkf", _Packed())
+        return self._pkf.get(device, (fc1, fc2, norm), lambda: T.PackedMlp(
+            norm.weight.to(device), norm.bias.to(device), norm.eps, fc1.weight.to(device), fc1.bias, fc2.weight.to(device), fc2.bias))
 
 
 class SwinBlock(nn.Module):
@@ -120,12 +136,16 @@ class SwinBlock(nn.Module):
         msa = self.attn.w_msa
         rowmap, (nwy, nwx) = geom.window_map(self.attn.shift_size)
         qkv_w, proj_w, table = msa.packed(x.device)
-        fc1_w, fc2_w = self.ffn.packed(x.device)
         n1, n2 = self.norm1, self.norm2
         xw = T.layernorm(x, n1.weight, n1.bias, n1.eps, rowmap=rowmap, zero_out=True, pair=True)
         qkv = T.linear(xw, qkv_w, a_pair=True)
         ao = T.window_attention(qkv, table, msa.num_heads, nwy, nwx, self.attn.shift_size, msa.scale, pair=True)
         T.linear(ao, proj_w, a_pair=True, residual=x, rowmap=rowmap, out=x)
+        if FUSED_MLP and x.shape[-1] in FUSED_MLP_DIMS:
+            # stage 0: LN2 + fc1 + GELU + fc2 + residual as one kernel (the hidden activation stays in registers)
+            T.mlp(x, self.ffn.packed_fused(x.device, n2))
+            return x
+        fc1_w, fc2_w = self.ffn.packed(x.device)
         xn = T.layernorm(x, n2.weight, n2.bias, n2.eps, pair=True)
         hid = T.linear(xn, fc1_w, a_pair=True, act="gelu", out_pair=True)
         T.linear(hid, fc2_w, a_pair=True, residual=x, out=x)

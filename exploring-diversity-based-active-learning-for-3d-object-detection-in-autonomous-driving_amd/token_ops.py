@@ -39,6 +39,44 @@ class PackedLinear:
             self.bias = torch.nn.functional.pad(bias.detach().float(), (0, pad_n - n)).to(w.device).contiguous()
 
 
+class PackedMlp:
+    """fc1 / fc2 of a Swin block in the fused MLP kernel's format (``al3d_tok_mlp_f16x3``): per 32 hidden units the MFMA
+    A-operand fragments of both matrices in lane order, (wh, wl) planes of the f16x3 split, one power-of-two scale per
+    matrix; LayerNorm parameters and biases as f32 vectors."""
+
+    def __init__(self, norm_weight, norm_bias, eps, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
+        w1 = fc1_weight.detach().float().contiguous()            # [hidden, C]
+        w2 = fc2_weight.detach().float().contiguous()            # [C, hidden]
+        hidden, C = w1.shape
+        if C not in (96, 192) or hidden % 32 or tuple(w2.shape) != (C, hidden):
+            raise lib.Al3dError(f"PackedMlp: C={C} (96 or 192), hidden={hidden} (multiple of 32), fc2 {tuple(w2.shape)}")
+        p1, s1 = split_f16x3(w1.view(hidden, 1, C))
+        p2, s2 = split_f16x3(w2.view(C, 1, hidden))
+        NT, KC, U = hidden // 32, C // 16, C // 32
+        # fc1: [plane, t, fr, kc, fh, e] -> [t, kc, plane, fh, fr, e]  (lane = fh * 32 + fr)
+        a = p1.view(2, NT, 32, KC, 2, 8).permute(1, 3, 0, 4, 2, 5).reshape(NT, KC * 2 * 64 * 8)
+        # fc2: hidden unit inside tile = 16 q + 8 e_hi + 4 fh + e_lo: [plane, u, fr, t, q, e_hi, fh, e_lo] -> [t, u, q, plane, fh, fr, e_hi, e_lo]
+        b = p2.view(2, U, 32, NT, 2, 2, 2, 4).permute(3, 1, 4, 0, 6, 2, 5, 7).reshape(NT, U * 2 * 2 * 64 * 8)
+        self.image = torch.cat([a, b], dim=1).contiguous()
+        assert self.image.numel() * 2 == lib.load().al3d_tok_mlp_image_bytes(C, hidden)
+        self.C, self.hidden, self.eps = C, hidden, float(eps)
+        self.scale1, self.scale2 = float(s1[0]), float(s2[0])
+        dev = self.image.device
+        f = lambda v, n: (torch.zeros(n) if v is None else v.detach().float()).to(dev).contiguous()
+        self.gamma, self.beta = f(norm_weight, C), f(norm_bias, C)
+        self.bias1, self.bias2 = f(fc1_bias, hidden), f(fc2_bias, C)
+
+
+def mlp(x, packed):
+    """``x += fc2(gelu(fc1(LN(x))))`` in place on f32 token rows ``[T, C]`` (one launch; C = 96 / 192)."""
+    x = _dev(x, torch.float32, "x")
+    if x.shape[-1] != packed.C:
+        raise lib.Al3dError(f"mlp: x has {x.shape[-1]} channels, the weights {packed.C}")
+    lib.call("al3d_tok_mlp_f16x3", _ptr(x), x.shape[0], packed.C, packed.hidden, _ptr(packed.gamma), _ptr(packed.beta),
+             packed.eps, _ptr(packed.image), packed.scale1, _ptr(packed.bias1), packed.scale2, _ptr(packed.bias2), _stream())
+    return x
+
+
 def patch_rows(img, pair=True):
     """img ``[B, H, W, 3]`` channels-last -> 4 x 4 patch rows ``[B * ceil(H/4) * ceil(W/4), 48]`` (k = (ky*4 + kx)*3 + c)."""
     img = _dev(img, torch.float32, "img")

@@ -571,12 +571,21 @@ int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const fl
  *   N % 4 == 0 (8 for pair output).
  * al3d_tok_window_attention_f32: qkv [nwin*49][3C] (q | k | v, each [heads][32]) -> softmax(q scale k^T + B + mask) v,
  *   [nwin*49][C]; B = table[(yq-yk+6)*13 + (xq-xk+6)][head]; mask = -100 between tokens of different shifted-window
- *   regions, derived from the window's position in its win_rows x win_cols grid and `shift` (0 = none). */
+ *   regions, derived from the window's position in its win_rows x win_cols grid and `shift` (0 = none).
+ * al3d_tok_mlp_f16x3: the MLP half of a block as one kernel, x[t] += fc2(GELU(fc1(LN(x[t])))) in place, for C = 96 / 192
+ *   (the stages whose separate LN / fc1 / fc2 launches are bandwidth-bound; the [T, hidden] activation stays in registers).
+ *   image (al3d_tok_mlp_image_bytes): per 32 hidden units t the MFMA A-operand fragments [64 lanes][8 halves] of
+ *   fc1.weight[32t + lane%32][16kc + 8(lane/32) + e], kc < C/16, planes (wh, wl) of al3d_split_f16x3, then of
+ *   fc2.weight[32u + lane%32][32t + 16q + 8(e/4) + 4(lane/32) + e%4], u < C/32, q < 2, planes (wh, wl);
+ *   scale1 / scale2 = 2^-s of the two splits; bias1 [hidden], bias2 [C]; hidden % 32 == 0. */
 /* img [B][H][W][3] f32 -> patch rows [B*ceil(H/4)*ceil(W/4)][48], k = (ky*4 + kx)*3 + c, zeros beyond the image: the A
  * matrix of the 4x4 / stride-4 patch embedding (mmdet PatchEmbed: Conv2d(3, 96, 4, 4)) as a token GEMM with K = 48. */
 int al3d_tok_patch_rows_f32(const float* img, int B, int H, int W, int out_pair, float* out, void* stream);
 int al3d_tok_layernorm_f32(const float* x, const int* rowmap, int64_t rows_out, int C, int G, int zero_out,
                            const float* gamma, const float* beta, float eps, int out_pair, float* out, void* stream);
+int64_t al3d_tok_mlp_image_bytes(int C, int hidden);
+int al3d_tok_mlp_f16x3(float* x, int64_t T, int C, int hidden, const float* gamma, const float* beta, float eps,
+                       const void* image, float scale1, const float* bias1, float scale2, const float* bias2, void* stream);
 int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt_image, const float* scale, const float* bias,
                           int64_t M, int K, int N, int act, const float* residual, int ldr, const int* rowmap,
                           float* out, int ldc, int out_pair, void* stream);

@@ -371,3 +371,53 @@ def test_assembled_camera_lidar_model_runs_and_is_deterministic():
     assert torch.equal(emb, emb2)
     assert not torch.equal(emb, emb_cam)
     assert len(preds) == 1 and preds[0]["bboxes"].shape[1] == 9 and len(preds[0]["scores"]) > 0
+
+
+@pytest.mark.parametrize("T_,C", [(1000, 96), (129, 96), (700, 192), (32, 192)])
+def test_fused_mlp_kernel_matches_float64_and_the_split_path(T_, C):
+    """``al3d_tok_mlp_f16x3`` (LN2 + fc1 + exact GELU + fc2 + residual as one kernel, hidden activation in registers,
+    everything transposed so an accumulator is the next product's operand) against the same formula in float64, at the
+    bound the three-launch path meets -- it must not be further from float64 than 3x the split path (LN kernel + two token
+    GEMMs), and within 2e-6 of the output scale; row counts that are not multiples of the 128-token tile."""
+    from al3d import token_ops as Tk
+    g = torch.Generator().manual_seed(T_ + C)
+    x = (torch.randn(T_, C, generator=g) * 1.7 + 0.3)
+    ln_w, ln_b = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
+    w1, b1 = torch.randn(4 * C, C, generator=g) / C ** 0.5, torch.randn(4 * C, generator=g) * 0.1
+    w2, b2 = torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5, torch.randn(C, generator=g) * 0.1
+    xd = x.double()
+    xn = F.layer_norm(xd, (C,), ln_w.double(), ln_b.double(), 1e-5)
+    ref = xd + F.gelu(xn @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    dev = lambda t: t.to(DEV)
+    pk = Tk.PackedMlp(dev(ln_w), dev(ln_b), 1e-5, dev(w1), dev(b1), dev(w2), dev(b2))
+    got = Tk.mlp(dev(x).clone(), pk).cpu().double()
+    f1, f2 = Tk.PackedLinear(dev(w1), dev(b1)), Tk.PackedLinear(dev(w2), dev(b2))
+    xs = dev(x).clone()
+    hid = Tk.linear(Tk.layernorm(xs, dev(ln_w), dev(ln_b), 1e-5, pair=True), f1, a_pair=True, act="gelu", out_pair=True)
+    split = Tk.linear(hid, f2, a_pair=True, residual=xs, out=xs).cpu().double()
+    scale = float(ref.abs().max())
+    e_fused, e_split = float((got - ref).abs().max()), float((split - ref).abs().max())
+    print("fused", e_fused / scale, "split", e_split / scale)
+    assert e_fused <= 3.0 * e_split + 1e-7 * scale, (e_fused, e_split, scale)
+    assert e_fused <= 1e-5 * scale, (e_fused, scale)
+
+
+def test_swin_block_fused_and_split_mlp_agree():
+    """A whole block with the fused MLP (default at embed dims 96 / 192) against the same block with AL3D_SWIN_MLP=split
+    semantics: agreement at fp32 rounding level of the residual stream."""
+    from al3d.models import swin as S
+    from al3d.synthetic import seed_modules_
+    blk = seed_modules_(S.SwinBlock(96, 3, 384, 7, shift=True), 5).to(DEV)
+    B, H, W = 2, 14, 21
+    x = torch.randn(B * H * W, 96, generator=torch.Generator().manual_seed(1)).to(DEV)
+    geom = S._Geometry.of(B, H, W, 7, torch.device(DEV))
+    saved = S.FUSED_MLP
+    try:
+        with torch.no_grad():
+            S.FUSED_MLP = True
+            a = blk(x.clone(), geom)
+            S.FUSED_MLP = False
+            b = blk(x.clone(), geom)
+    finally:
+        S.FUSED_MLP = saved
+    assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
