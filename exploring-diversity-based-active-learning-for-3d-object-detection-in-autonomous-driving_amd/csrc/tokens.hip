@@ -240,9 +240,36 @@ __device__ __forceinline__ bool tk_tile_of_block(const TokGemmParams& p, int& ti
     return tile < p.ntiles;
 }
 
+// erf to fp32 rounding level, branch-free: the two minimax pieces of N. Juffa's single-precision erf (x + x P(x^2) below
+// 475/512, 1 - exp(Q(|x|)) above; each < 1 ulp with an exact exp) are both evaluated and one is selected -- the library erff
+// costs ~45 vector instructions and a divergent branch per element, and the GELU epilogues are bound by exactly that.
+// exp through v_exp_f32 (2^x): its argument is <= -0.9, so the result is <= 0.41 and the error it adds to 1 - exp stays
+// below 1e-7.  Measured against float64 over [-8, 8]: see tests/test_swin_gpu.py::test_gelu_epilogue_accuracy.
+__device__ __forceinline__ float tk_erf(float a)
+{
+    const float t = fabsf(a), s = a * a;
+    float r = __builtin_fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = __builtin_fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = __builtin_fmaf(r, s, u);
+    r = __builtin_fmaf(r, t, -1.06777877e-1f);
+    r = __builtin_fmaf(r, t, -6.34846687e-1f);
+    r = __builtin_fmaf(r, t, -1.28717512e-1f);
+    r = __builtin_fmaf(r, t, -t);
+    float big = 1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f);
+    big = __builtin_copysignf(big, a);
+    float q = -5.96761703e-4f;
+    q = __builtin_fmaf(q, s, 4.99119423e-3f);
+    q = __builtin_fmaf(q, s, -2.67681349e-2f);
+    q = __builtin_fmaf(q, s, 1.12819925e-1f);
+    q = __builtin_fmaf(q, s, -3.76125336e-1f);
+    q = __builtin_fmaf(q, s, 1.28379166e-1f);
+    q = __builtin_fmaf(q, a, a);
+    return t > 0.927734375f ? big : q;
+}
+
 __device__ __forceinline__ float tk_gelu(float v)
 {
-    return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f));
+    return (v * 0.5f) * (1.0f + tk_erf(v * 0.70710678118654752440f));
 }
 
 struct TkOps {
@@ -483,7 +510,7 @@ extern "C" int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt
     return AL3D_OK;
 }
 
-// ------------------------------------------------------------------ fused MLP half of a Swin block (C = 96, 192)
+// ------------------------------------------------------------------ fused MLP half of a Swin block (C = 96)
 // x += fc2(gelu(fc1(LN2(x)))) as ONE kernel: the [tokens, 4 C] hidden activation -- 8 C of the 26 C floats a block moves
 // per token when its six GEMM / LN launches run separately, and these layers are bandwidth-bound -- never leaves the
 // registers.  Everything is computed TRANSPOSED so that one GEMM's accumulator is the next one's operand as it stands:
@@ -508,33 +535,34 @@ struct TokMlpParams {
     int NT;                  // hidden / 32
 };
 
-template <int C>
-__global__ __launch_bounds__(256, 2) void tok_mlp_f16x3_kernel(TokMlpParams p)
+// NW waves per workgroup (32 tokens each) share a ring of NS stages; a tile is requested NS - 1 tiles ahead
+template <int C, int NW, int NS>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void tok_mlp_f16x3_kernel(TokMlpParams p)
 {
     constexpr int KC = C / 16, U = C / 32, TILE = C * 256, W2OFF = KC * 2048;
     extern __shared__ __attribute__((aligned(1024))) unsigned char mlp_smem[];
-    unsigned char* ring = mlp_smem;                                     // 2 x TILE
-    float* b1s = reinterpret_cast<float*>(mlp_smem + 2 * TILE);         // [32 NT]
+    constexpr int NTHR = NW * 64, DMA_ROUND = NW * 1024, RPT = TILE / DMA_ROUND;      // DMA instructions per tile and wave
+    unsigned char* ring = mlp_smem;                                     // NS x TILE
+    float* b1s = reinterpret_cast<float*>(mlp_smem + NS * TILE);        // [32 NT]
     float* gs = b1s + 32 * p.NT;                                        // gamma [C] | beta [C] | bias2 [C]
     float* scr = gs + 3 * C + (threadIdx.x >> 6) * (32 * 33);           // per wave: 32 tokens x 33
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned ring_base = (unsigned)(size_t)(tk_lds_void*)ring;
 
-    auto issue = [&](int t) {                                           // hidden tile t -> ring stage t & 1
+    auto issue = [&](int t) {                                           // hidden tile t -> ring stage t % NS
         const char* src = reinterpret_cast<const char*>(p.image) + (int64_t)t * TILE + wave * 1024 + lane * 16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (t & 1) * TILE + wave * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (t % NS) * TILE + wave * 1024);
 #pragma unroll
-        for (int r = 0; r < TILE / 4096; ++r)
-            __builtin_amdgcn_global_load_lds((tk_gbl_void*)(src + r * 4096), (tk_lds_void*)(size_t)(dst + r * 4096), 16, 0, 0);
+        for (int r = 0; r < RPT; ++r)
+            __builtin_amdgcn_global_load_lds((tk_gbl_void*)(src + r * DMA_ROUND), (tk_lds_void*)(size_t)(dst + r * DMA_ROUND), 16, 0, 0);
     };
-    issue(0);
-    for (int i = tid; i < 32 * p.NT; i += 256) b1s[i] = p.bias1[i];
-    for (int i = tid; i < C; i += 256) { gs[i] = p.gamma[i]; gs[C + i] = p.beta[i]; gs[2 * C + i] = p.bias2[i]; }
+    for (int i = tid; i < 32 * p.NT; i += NTHR) b1s[i] = p.bias1[i];
+    for (int i = tid; i < C; i += NTHR) { gs[i] = p.gamma[i]; gs[C + i] = p.beta[i]; gs[2 * C + i] = p.bias2[i]; }
     __syncthreads();
 
     // ---- LN2 of the wave's 32 tokens: lane (fr, fh) holds channels kc * 16 + fh * 8 + e of token fr
-    const int64_t tok = (int64_t)blockIdx.x * 128 + wave * 32 + fr;
+    const int64_t tok = (int64_t)blockIdx.x * (NW * 32) + wave * 32 + fr;
     const bool live = tok < p.T;
     const float* xrow = p.x + (live ? tok : 0) * C + fh * 8;
     float xv[KC][8];
@@ -575,11 +603,16 @@ __global__ __launch_bounds__(256, 2) void tok_mlp_f16x3_kernel(TokMlpParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 
+    // the x loads above have been consumed (their data was used): only DMA requests are in flight from here on
+#pragma unroll
+    for (int t0 = 0; t0 < NS - 1; ++t0) if (t0 < p.NT) issue(t0);
     for (int t = 0; t < p.NT; ++t) {
-        tk_wait_vm<0>();                                   // this wave's share of tile t has landed ...
+        // tiles t .. t + NS - 2 are in flight (fewer at the end): this wave's share of tile t has landed when at most the
+        // younger tiles' requests remain
+        if (t + NS - 2 < p.NT) tk_wait_vm<(NS - 2) * RPT>(); else tk_wait_vm<0>();
         __syncthreads();                                   // ... everyone's has, and nobody reads tile t - 1 any more
-        if (t + 1 < p.NT) issue(t + 1);
-        const unsigned char* st = ring + (t & 1) * TILE + lane * 16;
+        if (t + NS - 1 < p.NT) issue(t + NS - 1);
+        const unsigned char* st = ring + (t % NS) * TILE + lane * 16;
         f32x16 h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[r] = 0.f;
@@ -620,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void tok_mlp_f16x3_kernel(TokMlpParams p)
     }
 
     // ---- out^T tiles -> rows: 32 tokens x 32 channels at a time through the wave's scratch
-    const int64_t tok0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t tok0 = (int64_t)blockIdx.x * (NW * 32) + wave * 32;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -652,27 +685,30 @@ extern "C" int al3d_tok_mlp_f16x3(float* x, int64_t T, int C, int hidden, const 
                                   void* stream)
 {
     AL3D_REQUIRE(x && gamma && beta && image && bias1 && bias2, "al3d_tok_mlp_f16x3: null pointer");
-    AL3D_REQUIRE(C == 96 || C == 192, "al3d_tok_mlp_f16x3: C must be 96 or 192 (the stages whose MLP is bandwidth-bound), got %d", C);
+    AL3D_REQUIRE(C == 96, "al3d_tok_mlp_f16x3: built for C = 96 (at 192 the instance needs 255 registers and a 96 KB ring and measured slower than the three launches), got %d", C);
     AL3D_REQUIRE(hidden >= 32 && hidden % 32 == 0 && T >= 0, "al3d_tok_mlp_f16x3: hidden must be a multiple of 32");
     AL3D_REQUIRE((((uintptr_t)x | (uintptr_t)image) & 15) == 0, "al3d_tok_mlp_f16x3: x / image must be 16-byte aligned");
     if (T == 0) return AL3D_OK;
     TokMlpParams p;
     p.x = x; p.image = (const _Float16*)image; p.gamma = gamma; p.beta = beta; p.bias1 = bias1; p.bias2 = bias2;
     p.scale1 = scale1; p.scale2 = scale2; p.eps = eps; p.T = T; p.NT = hidden / 32;
-    const size_t lds = (size_t)2 * C * 256 + ((size_t)hidden + 3 * C + 4 * 32 * 33) * 4;
-    const dim3 grid((unsigned)al3d_cdiv(T, 128));
+    // four waves (128 tokens) on a two-stage ring, two workgroups per CU (default), or eight waves on a three-stage ring, one
+    // workgroup per CU (AL3D_TOK_MLP=8x3: tiles requested two ahead; measured the same: the DMA round trip is not the bound)
+    static int wide = -1;
+    if (wide < 0) { const char* e = getenv("AL3D_TOK_MLP"); wide = e && e[0] == '8'; }
+    const int nw = wide ? 8 : 4, ns = wide ? 3 : 2;
+    const size_t lds = (size_t)ns * C * 256 + ((size_t)hidden + 3 * C + nw * 32 * 33) * 4;
+    const dim3 grid((unsigned)al3d_cdiv(T, nw * 32));
     hipStream_t s = (hipStream_t)stream;
-    if (C == 96) {
-        hipLaunchKernelGGL(tok_mlp_f16x3_kernel<96>, grid, dim3(256), lds, s, p);
-    } else {
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void*)tok_mlp_f16x3_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return al3d_fail(AL3D_ELAUNCH, "al3d_tok_mlp_f16x3: cannot raise the dynamic LDS limit");
-            attr = true;
-        }
-        hipLaunchKernelGGL(tok_mlp_f16x3_kernel<192>, grid, dim3(256), lds, s, p);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)tok_mlp_f16x3_kernel<96, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tok_mlp_f16x3_kernel<96, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return al3d_fail(AL3D_ELAUNCH, "al3d_tok_mlp_f16x3: cannot raise the dynamic LDS limit");
+        attr = true;
     }
+    if (wide) hipLaunchKernelGGL((tok_mlp_f16x3_kernel<96, 8, 3>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((tok_mlp_f16x3_kernel<96, 4, 2>), grid, dim3(256), lds, s, p);
     AL3D_CHECK_LAUNCH("tok_mlp_f16x3_kernel");
     return AL3D_OK;
 }

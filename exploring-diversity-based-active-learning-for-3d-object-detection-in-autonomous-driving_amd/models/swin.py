@@ -95,9 +95,8 @@ class ShiftWindowMSA(nn.Module):
 
 # AL3D_SWIN_MLP=split: LN2 / fc1 / fc2 as three launches everywhere (default "fused": one kernel where it is faster)
 FUSED_MLP = _os.environ.get("AL3D_SWIN_MLP", "fused") != "split"
-# measured at 16 samples per launch: C = 96 0.87 ms fused against 1.50 ms for LN2 + fc1 + fc2; C = 192 1.09 against 0.94 (the
-# 255-register, one-workgroup-per-CU instance loses to the three launches): AL3D_SWIN_MLP_DIMS=96,192 to force both
-FUSED_MLP_DIMS = tuple(int(v) for v in _os.environ.get("AL3D_SWIN_MLP_DIMS", "96").split(","))
+# (embed dim 96 only: at 192 the kernel needs 255 registers and a 96 KB ring and measured slower than the three launches)
+FUSED_MLP_DIMS = (96,)
 
 
 class _FFN(nn.Module):
@@ -115,7 +114,7 @@ class _FFN(nn.Module):
                                                          T.PackedLinear(fc2.weight, fc2.bias)))
 
     def packed_fused(self, device, norm):
-        """LN2 + fc1 + fc2 in the fused kernel's format (``al3d_tok_mlp_f16x3``; embed dims 96 / 192)."""
+        """LN2 + fc1 + fc2 in the fused kernel's format (``al3d_tok_mlp_f16x3``; embed dim 96)."""
         fc1, fc2 = self.layers[0][0], self.layers[1]
         if getattr(self, "_pkf", None) is None:
             object.__setattr__(self, "_pkf", _Packed())

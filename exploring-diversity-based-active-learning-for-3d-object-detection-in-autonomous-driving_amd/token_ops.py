@@ -48,8 +48,8 @@ class PackedMlp:
         w1 = fc1_weight.detach().float().contiguous()            # [hidden, C]
         w2 = fc2_weight.detach().float().contiguous()            # [C, hidden]
         hidden, C = w1.shape
-        if C not in (96, 192) or hidden % 32 or tuple(w2.shape) != (C, hidden):
-            raise lib.Al3dError(f"PackedMlp: C={C} (96 or 192), hidden={hidden} (multiple of 32), fc2 {tuple(w2.shape)}")
+        if C != 96 or hidden % 32 or tuple(w2.shape) != (C, hidden):
+            raise lib.Al3dError(f"PackedMlp: C={C} (the fused kernel is built for 96), hidden={hidden} (multiple of 32), fc2 {tuple(w2.shape)}")
         p1, s1 = split_f16x3(w1.view(hidden, 1, C))
         p2, s2 = split_f16x3(w2.view(C, 1, hidden))
         NT, KC, U = hidden // 32, C // 16, C // 32
@@ -68,7 +68,7 @@ class PackedMlp:
 
 
 def mlp(x, packed):
-    """``x += fc2(gelu(fc1(LN(x))))`` in place on f32 token rows ``[T, C]`` (one launch; C = 96 / 192)."""
+    """``x += fc2(gelu(fc1(LN(x))))`` in place on f32 token rows ``[T, 96]`` (one launch)."""
     x = _dev(x, torch.float32, "x")
     if x.shape[-1] != packed.C:
         raise lib.Al3dError(f"mlp: x has {x.shape[-1]} channels, the weights {packed.C}")

@@ -572,8 +572,8 @@ int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const fl
  * al3d_tok_window_attention_f32: qkv [nwin*49][3C] (q | k | v, each [heads][32]) -> softmax(q scale k^T + B + mask) v,
  *   [nwin*49][C]; B = table[(yq-yk+6)*13 + (xq-xk+6)][head]; mask = -100 between tokens of different shifted-window
  *   regions, derived from the window's position in its win_rows x win_cols grid and `shift` (0 = none).
- * al3d_tok_mlp_f16x3: the MLP half of a block as one kernel, x[t] += fc2(GELU(fc1(LN(x[t])))) in place, for C = 96 / 192
- *   (the stages whose separate LN / fc1 / fc2 launches are bandwidth-bound; the [T, hidden] activation stays in registers).
+ * al3d_tok_mlp_f16x3: the MLP half of a block as one kernel, x[t] += fc2(GELU(fc1(LN(x[t])))) in place, for C = 96
+ *   (stage 0, whose separate LN / fc1 / fc2 launches are bandwidth-bound; the [T, hidden] activation stays in registers).
  *   image (al3d_tok_mlp_image_bytes): per 32 hidden units t the MFMA A-operand fragments [64 lanes][8 halves] of
  *   fc1.weight[32t + lane%32][16kc + 8(lane/32) + e], kc < C/16, planes (wh, wl) of al3d_split_f16x3, then of
  *   fc2.weight[32u + lane%32][32t + 16q + 8(e/4) + 4(lane/32) + e%4], u < C/32, q < 2, planes (wh, wl);
