@@ -1,6 +1,6 @@
 """Per-layer time of the view transform's convolutions at B samples (HIP events, 5 reps)."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from al3d import synthetic
 from al3d.models.bevfusion_camera import DepthLSSTransform
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16

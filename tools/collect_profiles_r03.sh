@@ -19,6 +19,8 @@ python3 $R/tools/rocpd_summary.py stats $(find /tmp/p_clh -name "*.db" | head -1
 rocprofv3 --kernel-trace --stats -d /tmp/p_li -o l -- python3 $R/tools/bench_bevfusion_lidar.py 96 32 > $O/r03_bevfusion_lidar.log 2> $O/r03_prof_li.err
 python3 $R/tools/rocpd_summary.py stats $(find /tmp/p_li -name "*.db" | head -1) $O/r03_bevfusion_lidar_kernel_stats.csv
 echo "bevfusion done $(date +%T)" >> $O/r03_progress.log
+# STATS_ONLY=1: kernel stats only (the HBM counters: tools/collect_pmc_r03.sh)
+if [ -n "$STATS_ONLY" ]; then ls -la $O/r03_*; exit 0; fi
 ARGS="--scenes 16 --steps 1 --warmup 0 --no-cpu-baseline --no-extra-math --no-from-files --no-verify --no-bevfusion"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch -o f -- python3 $R/bench.py $ARGS > $O/r03_pmc_fetch_line.json 2> $O/r03_prof_fetch.err
 echo "fetch pass rc $? $(date +%T)" >> $O/r03_progress.log

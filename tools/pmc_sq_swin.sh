@@ -1,3 +1,5 @@
+# Dev tool (GPU box): SQ counters of the Swin-T token kernels (wave cycles, parked / issue-stalled / active shares, MFMA busy
+# cycles, VALU instructions) -- bash tools/pmc_sq_swin.sh under gpurun; prints per-kernel averages.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -1,3 +1,4 @@
+# Dev tool (GPU box): per-dispatch durations of one Swin-T forward at 16 samples (gpurun_out/swin16_seq.csv).
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
