@@ -456,6 +456,60 @@ extern "C" int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW
     return AL3D_OK;
 }
 
+// ------------------------------------------------------------------ top-down step of the LSS-FPN
+// generalized_lss.py:88-101: x = cat([laterals[i], interpolate(laterals[i + 1], size = laterals[i].shape, mode = bilinear,
+// align_corners = True)], channel).  One kernel writes the concatenated channels-last map: a thread owns four channels of one
+// output pixel -- the first C1 are copied from `lat`, the other C2 are the four-tap blend of `src` with torch's weights
+// (source position = o * (in - 1) / (out - 1) in float, the upper neighbour clamped at the border; blend as
+// h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11)).
+__global__ __launch_bounds__(256) void lss_upsample_cat_kernel(const float* __restrict__ lat, const float* __restrict__ src, int64_t total,
+                                                               int H, int W, int C1, int h, int w, int C2, float sh, float sw,
+                                                               float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int CQ = (C1 + C2) >> 2;
+    const int cq = (int)(t % CQ);
+    const int64_t px = t / CQ;
+    const int c = cq * 4;
+    float4 v;
+    if (c < C1) {
+        v = *reinterpret_cast<const float4*>(lat + px * C1 + c);
+    } else {
+        const int x = (int)(px % W), y = (int)((px / W) % H);
+        const int64_t n = px / ((int64_t)W * H);
+        const float yr = sh * (float)y, xr = sw * (float)x;
+        const int y0 = (int)yr, x0 = (int)xr;
+        const int yp = y0 < h - 1 ? 1 : 0, xp = x0 < w - 1 ? 1 : 0;
+        const float ly = yr - (float)y0, lx = xr - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* b = src + ((n * h + y0) * w + x0) * C2 + (c - C1);
+        const float4 v00 = *reinterpret_cast<const float4*>(b), v01 = *reinterpret_cast<const float4*>(b + (int64_t)xp * C2);
+        const float4 v10 = *reinterpret_cast<const float4*>(b + (int64_t)yp * w * C2);
+        const float4 v11 = *reinterpret_cast<const float4*>(b + ((int64_t)yp * w + xp) * C2);
+        v.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+        v.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+        v.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+        v.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    }
+    *reinterpret_cast<float4*>(out + px * (C1 + C2) + c) = v;
+}
+
+extern "C" int al3d_lss_upsample_cat_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2,
+                                         float* out, void* stream)
+{
+    AL3D_REQUIRE(lat && src && out, "al3d_lss_upsample_cat_f32: null pointer");
+    AL3D_REQUIRE(N >= 0 && H >= 1 && W >= 1 && h >= 1 && w >= 1 && C1 >= 4 && C2 >= 4 && C1 % 4 == 0 && C2 % 4 == 0,
+                 "al3d_lss_upsample_cat_f32: channel counts must be multiples of 4");
+    AL3D_REQUIRE((((uintptr_t)lat | (uintptr_t)src | (uintptr_t)out) & 15) == 0, "al3d_lss_upsample_cat_f32: 16-byte aligned maps");
+    const int64_t total = (int64_t)N * H * W * ((C1 + C2) / 4);
+    if (total == 0) return AL3D_OK;
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    hipLaunchKernelGGL(lss_upsample_cat_kernel, dim3((unsigned)al3d_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, lat, src,
+                       total, H, W, C1, h, w, C2, sh, sw, out);
+    AL3D_CHECK_LAUNCH("lss_upsample_cat_kernel");
+    return AL3D_OK;
+}
+
 // ------------------------------------------------------------------ first two layers of the depth branch, fused
 // depth_lss.py:38-44: dtransform = Conv2d(1, 8, 1) + BN + ReLU -> Conv2d(8, 32, 5, stride 4, padding 2) + BN + ReLU on
 // the [BN, 1, iH, iW] lidar depth image.  As two convolutions that is a 554 MB eight-channel map per 16 samples written,

@@ -256,8 +256,8 @@ class _ConvModule(nn.Module):
 class GeneralizedLSSFPN(nn.Module):
     """bevfusion/mmdet3d/models/necks/generalized_lss.py:13-110: top-down path of upsample (bilinear,
     align_corners=True) -> concat -> 1x1 ConvModule -> 3x3 ConvModule per level.  Channels-last maps
-    [BN, H_l, W_l, C_l] in, tuple of the ``used_backbone_levels`` outputs out.  The interpolation is a torch op (a
-    gather with four weights per pixel on maps of a few MB); the convolutions run on the dense conv kernels."""
+    [BN, H_l, W_l, C_l] in, tuple of the ``used_backbone_levels`` outputs out.  Upsample + concatenation are one kernel
+    (``al3d_lss_upsample_cat_f32``), the convolutions run on the dense conv kernels."""
 
     def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1):
         super().__init__()
@@ -278,9 +278,17 @@ class GeneralizedLSSFPN(nn.Module):
         laterals = [inputs[i + self.start_level] for i in range(len(inputs))]
         used = len(laterals) - 1
         for i in range(used - 1, -1, -1):
-            up = torch.nn.functional.interpolate(laterals[i + 1].permute(0, 3, 1, 2), size=laterals[i].shape[1:3],
-                                                 mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
-            x = torch.cat([laterals[i], up], dim=-1).contiguous()
+            lat, src = laterals[i].contiguous(), laterals[i + 1].contiguous()
+            if lat.is_cuda and lat.shape[-1] % 4 == 0 and src.shape[-1] % 4 == 0:
+                # upsample + concatenation as one kernel writing the channels-last concat map (al3d_lss_upsample_cat_f32)
+                x = torch.empty((*lat.shape[:3], lat.shape[-1] + src.shape[-1]), dtype=torch.float32, device=lat.device)
+                lib.call("al3d_lss_upsample_cat_f32", _ptr(_dev(lat, torch.float32, "lateral")), _ptr(_dev(src, torch.float32, "coarser level")),
+                         lat.shape[0], lat.shape[1], lat.shape[2], lat.shape[3], src.shape[1], src.shape[2], src.shape[3],
+                         _ptr(x), _stream())
+            else:
+                up = torch.nn.functional.interpolate(src.permute(0, 3, 1, 2), size=lat.shape[1:3], mode="bilinear",
+                                                     align_corners=True).permute(0, 2, 3, 1)
+                x = torch.cat([lat, up], dim=-1).contiguous()
             laterals[i] = self.fpn_convs[i](self.lateral_convs[i](x))
         return tuple(laterals[i] for i in range(used))
 

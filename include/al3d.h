@@ -505,6 +505,10 @@ int al3d_lss_depth_image_f32(const float* points, int64_t npts, int stride, cons
 /* depth_lss.py:93-96: softmax over the D depth logits of the depth net's channels-last output y [BN][fH][fW][ldy] (logits
  * in channels 0 .. D-1), written as [BN][D][fH][fW] probabilities for the pooling; D <= 256. */
 int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW, int D, int ldy, float* out, void* stream);
+/* necks/generalized_lss.py:88-101, one top-down step of the LSS-FPN: out [N][H][W][C1 + C2] (channels-last) =
+ * cat(lat [N][H][W][C1], bilinear upsample (align_corners = True, torch's weights) of src [N][h][w][C2]); C1, C2 % 4 == 0. */
+int al3d_lss_upsample_cat_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2, float* out,
+                              void* stream);
 /* depth_lss.py:38-44, the first two layers of `dtransform` as one kernel: Conv2d(1, 8, 1) + BN + ReLU -> Conv2d(8, 32, 5,
  * stride 4, padding 2) + BN + ReLU on the depth image [BN][iH][iW] -> out [BN][oH][oW][32] (channels-last, oH =
  * (iH - 1) / 4 + 1).  p0 = [w0[8] | scale0[8] | shift0[8]] with layer 0 = relu((w0 d) scale0 + shift0) (bias and BN folded:
