@@ -684,11 +684,11 @@ extern "C" int al3d_tok_mlp_f16x3(float* x, int64_t T, int C, int hidden, const 
                                   const void* image, float scale1, const float* bias1, float scale2, const float* bias2,
                                   void* stream)
 {
+    if (T == 0) return AL3D_OK;                      // an empty row matrix has no storage
     AL3D_REQUIRE(x && gamma && beta && image && bias1 && bias2, "al3d_tok_mlp_f16x3: null pointer");
     AL3D_REQUIRE(C == 96, "al3d_tok_mlp_f16x3: built for C = 96 (at 192 the instance needs 255 registers and a 96 KB ring and measured slower than the three launches), got %d", C);
     AL3D_REQUIRE(hidden >= 32 && hidden % 32 == 0 && T >= 0, "al3d_tok_mlp_f16x3: hidden must be a multiple of 32");
     AL3D_REQUIRE((((uintptr_t)x | (uintptr_t)image) & 15) == 0, "al3d_tok_mlp_f16x3: x / image must be 16-byte aligned");
-    if (T == 0) return AL3D_OK;
     TokMlpParams p;
     p.x = x; p.image = (const _Float16*)image; p.gamma = gamma; p.beta = beta; p.bias1 = bias1; p.bias2 = bias2;
     p.scale1 = scale1; p.scale2 = scale2; p.eps = eps; p.T = T; p.NT = hidden / 32;

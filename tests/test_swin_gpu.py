@@ -446,3 +446,27 @@ def test_gelu_epilogue_accuracy():
     spec = torch.tensor([[float("nan")] + [0.0] * (K - 1), [float("inf")] + [0.0] * (K - 1), [-float("inf")] + [0.0] * (K - 1)])
     out = Tk.linear(spec.to(DEV), pk, act="gelu").cpu()[:, 0]
     assert torch.isnan(out[0]) and (out[1] == float("inf") or torch.isnan(out[1]))
+
+
+def test_fused_mlp_edge_cases():
+    """Empty input, a non-finite token (its row becomes NaN, the other rows of the same wave are untouched: tokens are the
+    independent n dimension of every product) and the loud failures of the fused MLP entry point."""
+    from al3d import lib, token_ops as Tk
+    C = 96
+    g = torch.Generator().manual_seed(9)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    pk = Tk.PackedMlp(mk(C) * 0.1 + 1, mk(C) * 0.1, 1e-5, mk(4 * C, C) / C ** 0.5, mk(4 * C) * 0.1, mk(C, 4 * C) / (4 * C) ** 0.5, mk(C) * 0.1)
+    assert Tk.mlp(torch.empty(0, C, device=DEV), pk).shape == (0, C)
+    x = mk(70, C)
+    clean = Tk.mlp(x.clone(), pk)
+    bad = x.clone()
+    bad[5, 17] = float("nan")
+    bad[40, 3] = float("inf")
+    out = Tk.mlp(bad, pk)
+    assert bool(torch.isnan(out[5]).all()) and not bool(torch.isfinite(out[40]).any())
+    keep = [i for i in range(70) if i not in (5, 40)]
+    assert torch.equal(out[keep], clean[keep])
+    with pytest.raises(lib.Al3dError):
+        Tk.PackedMlp(mk(192), mk(192), 1e-5, mk(768, 192), mk(768), mk(192, 768), mk(192))      # built for C = 96
+    with pytest.raises(lib.Al3dError):
+        Tk.mlp(mk(8, 192), pk)
