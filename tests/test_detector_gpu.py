@@ -622,6 +622,32 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
         for mode in (None, "ahead", "split"):
             S.PIPELINE = mode
             assert torch.equal(run(2), ref), mode
+        # placement knobs of the "ahead" pipeline (side work released beside the dense neck, decode + NMS launch held
+        # back until the next batch's sparse encoder is through, convolutions on a high-priority stream): same bits
+        S.PIPELINE = "ahead"
+        knobs = (S.SIDE_AFTER_SPARSE, S.NMS_AFTER_SPARSE, S.MAIN_PRIORITY)
+        try:
+            for flags in ((True, False, False), (True, True, False), (False, False, True)):
+                S.SIDE_AFTER_SPARSE, S.NMS_AFTER_SPARSE, S.MAIN_PRIORITY = flags
+                assert torch.equal(run(2), ref), flags
+            assert not getattr(model.bbox_head, "defer_nms", False) and not getattr(model.bbox_head, "_deferred", [])
+        finally:
+            S.SIDE_AFTER_SPARSE, S.NMS_AFTER_SPARSE, S.MAIN_PRIORITY = knobs
+        # a deferred decode + NMS launch yields the detections of an immediate one, whether it is flushed or read first
+        ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, anchors, 2, device=DEV)))
+        with torch.no_grad():
+            now, _ = model(ex, return_loss=False, estimate=True)
+            model.bbox_head.defer_nms = True
+            try:
+                later, _ = model(ex, return_loss=False, estimate=True)
+                lazy, _ = model(ex, return_loss=False, estimate=True)
+                assert len(model.bbox_head._deferred) == 2
+                model.bbox_head.flush_deferred()
+            finally:
+                model.bbox_head.defer_nms = False
+        for b in range(2):
+            for k in ("box3d_lidar", "scores", "label_preds"):
+                assert torch.equal(later[b][k], now[b][k]) and torch.equal(lazy[b][k], now[b][k]), k
     finally:
         D.SPCONV, S.PIPELINE = saved
         D.DENSE = saved_dense
