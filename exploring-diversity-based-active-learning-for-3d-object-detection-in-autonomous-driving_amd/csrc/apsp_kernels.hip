@@ -154,12 +154,12 @@ __global__ void adj_fill_kernel(const double* __restrict__ knn_d, const int64_t*
 // ------------------------------------------------------------------ SSSP sweeps
 // One workgroup per source.  Labels are the f64 bit patterns (non-negative, so
 // unsigned integer order == numeric order) lowered with integer atomic-min.
-// Per round: the frontier flags (one byte per node, owned by the scanning thread) are
+// Per round: the frontier flags (one BIT per node: a thread scans whole 32-node words) are
 // compacted into a 16-bit node list, then 16-lane groups relax the edges of one
 // frontier node each (edge-parallel: the dependent atomic round trips of a node's ~16
 // edges overlap instead of queueing in one lane).  Two barriers per round.
-// LDS_DIST: labels live in LDS (12 B/node incl. flags + list); otherwise in the
-// output row itself (global atomics at L2), 4 B/node of LDS.
+// LDS_DIST: labels live in LDS (10.25 B/node incl. flags + list: up to 15.9k nodes); otherwise in
+// the output row itself (global atomics at L2), 2.25 B/node of LDS (two workgroups per CU at 28k nodes).
 #define SSSP_THREADS 256
 
 template <bool LDS_DIST>
@@ -174,34 +174,43 @@ __global__ __launch_bounds__(SSSP_THREADS) void sssp_kernel(const int* __restric
     const int tid = threadIdx.x;
     const int64_t src = row0 + blockIdx.x;
     double* orow = out + (int64_t)blockIdx.x * n;
+    const int words = (int)((n + 31) >> 5);
     unsigned long long* dist;
-    unsigned char* fl;
+    unsigned* fl;
     if (LDS_DIST) {
         dist = reinterpret_cast<unsigned long long*>(smem);
-        fl = smem + sizeof(unsigned long long) * (size_t)n;
+        fl = reinterpret_cast<unsigned*>(smem + sizeof(unsigned long long) * (size_t)n);
     } else {
         dist = reinterpret_cast<unsigned long long*>(orow);
-        fl = smem;
+        fl = reinterpret_cast<unsigned*>(smem);
     }
-    unsigned char* cur = fl;
-    unsigned char* nxt = fl + n;
-    unsigned short* list = reinterpret_cast<unsigned short*>(fl + 2 * n);
+    unsigned* cur = fl;
+    unsigned* nxt = fl + words;
+    unsigned short* list = reinterpret_cast<unsigned short*>(fl + 2 * words);
     const unsigned long long INF_BITS = 0x7ff0000000000000ULL;
     for (int64_t v = tid; v < n; v += SSSP_THREADS) {
         const unsigned long long init = v == src ? 0ULL : INF_BITS;
         if (LDS_DIST) dist[v] = init;
         else __hip_atomic_store(&dist[v], init, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cur[v] = v == src ? 1 : 0;
-        nxt[v] = 0;
+    }
+    for (int w = tid; w < words; w += SSSP_THREADS) {
+        cur[w] = (src >> 5) == w ? 1u << (src & 31) : 0u;
+        nxt[w] = 0u;
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     const int grp = tid >> 4, gl = tid & 15;          // 16 groups of 16 lanes
     for (int64_t round = 0; round <= n; ++round) {
-        for (int64_t v = tid; v < n; v += SSSP_THREADS) {
-            if (!cur[v]) continue;
-            cur[v] = 0;
-            list[atomicAdd(&s_cnt, 1)] = (unsigned short)v;
+        for (int w = tid; w < words; w += SSSP_THREADS) {
+            unsigned m = cur[w];
+            if (!m) continue;
+            cur[w] = 0u;
+            const int base = atomicAdd(&s_cnt, __popc(m));
+            int k = 0;
+            while (m) {
+                list[base + k++] = (unsigned short)(w * 32 + __builtin_ctz(m));
+                m &= m - 1u;
+            }
         }
         __syncthreads();
         const int cnt = s_cnt;
@@ -218,12 +227,12 @@ __global__ __launch_bounds__(SSSP_THREADS) void sssp_kernel(const int* __restric
                 const double nd = dv + adj_w[e];
                 const unsigned long long nb = (unsigned long long)__double_as_longlong(nd);
                 const unsigned long long old = atomicMin(&dist[u], nb);
-                if (nb < old) nxt[u] = 1;
+                if (nb < old) atomicOr(&nxt[u >> 5], 1u << (u & 31));
             }
         }
         __syncthreads();
         if (tid == 0) s_cnt = 0;
-        unsigned char* t = cur; cur = nxt; nxt = t;
+        unsigned* t = cur; cur = nxt; nxt = t;
         __syncthreads();
     }
     if (LDS_DIST) {
@@ -263,14 +272,17 @@ extern "C" int al3d_apsp_knn_rows_f64(const double* knn_d, const int64_t* knn_i,
     hipLaunchKernelGGL(adj_scan_kernel, dim3(1), dim3(1024), 0, s, deg, n, indptr, cursor);
     hipLaunchKernelGGL(adj_fill_kernel, dim3(eb), dim3(256), 0, s, knn_d, knn_i, n, kq, cursor, adj_v,
                        adj_w);
-    const size_t lds_full = (size_t)n * 12, lds_flags = (size_t)n * 4;
-    if (lds_full <= 150 * 1024) {
+    // flag words (two bit sets) + the 16-bit node list, 16-byte aligned after the labels
+    const size_t words = (size_t)((n + 31) / 32);
+    const size_t lds_flags = al3d_align(words * 8 + (size_t)n * 2, 16), lds_full = (size_t)n * 8 + lds_flags;
+    const size_t lds_cap = 158 * 1024;
+    if (lds_full <= lds_cap) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sssp_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
         hipLaunchKernelGGL(sssp_kernel<true>, dim3((unsigned)nrows), dim3(SSSP_THREADS), lds_full, s,
                            indptr, adj_v, adj_w, n, row0, out);
     } else {
-        AL3D_REQUIRE(lds_flags <= 150 * 1024, "al3d_apsp_knn_f64: n=%lld too large", (long long)n);
+        AL3D_REQUIRE(lds_flags <= lds_cap, "al3d_apsp_knn_f64: n=%lld too large", (long long)n);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sssp_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_flags);
         hipLaunchKernelGGL(sssp_kernel<false>, dim3((unsigned)nrows), dim3(SSSP_THREADS), lds_flags, s,
