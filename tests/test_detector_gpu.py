@@ -899,3 +899,43 @@ def test_tiled_27_tap_table_equals_plain_table(W, strided):
     for k in range(27):
         want |= ((tiled[k].reshape(-1, 32) >= 0).any(1).astype(np.uint32) << np.uint32(k))
     assert np.array_equal(tmask, want)
+
+
+@pytest.mark.parametrize("seed,score_bias,spread", [(21, 0.0, 0.25), (22, -1.0, 0.5), (23, 0.5, 1.0), (24, -2.0, 2.0), (25, 0.0, 4.0),
+                                                    (26, 1.0, 0.1)])
+def test_head_nms_super_rounds_equal_the_sequential_rule(oracle, seed, score_bias, spread):
+    """The greedy loop runs in super-rounds of eight tentative survivors whose verdicts are resolved in rank order
+    (csrc/head_nms.hip); the oracle applies the sequential rule one survivor at a time.  Box regressions of different
+    spread around dense anchors give suppression patterns from "almost every tentative falls" (tight clusters) to
+    "none does": kept boxes, their order, labels and scores must agree exactly / to rounding on every pattern."""
+    B, H, W = 2, 16, 16
+    cfg, head, anchors = _head_setup(seed, H, W, score_bias)
+    head._prepare(torch.device(DEV))
+    g = torch.Generator().manual_seed(seed)
+    fused = torch.randn(B, H, W, head._ch, generator=g)
+    for t in range(len(head.tasks)):                           # box regressions scaled: overlap structure changes with it
+        b0 = head._box_off[t]
+        fused[..., b0:b0 + head.num_anchor_per_locs[t] * 10] *= spread
+        c0 = head._cls_off[t]
+        fused[..., c0:c0 + head.num_anchor_per_locs[t] * head.num_classes[t]] += score_bias
+    tc = cfg.test_cfg
+    preds = [{"_fused": fused.to(DEV)}]
+    out = head.predict({"anchors": [_t(a) for a in anchors], "metadata": [None] * B}, preds, tc)
+    fz = fused.numpy().reshape(B, H * W, -1)
+    label_off = np.concatenate([[0], np.cumsum(head.num_classes)])
+    total = 0
+    for b in range(B):
+        bb, ss, ll = [], [], []
+        for t in range(len(head.tasks)):
+            bx, sc, lb = oracle.head_predict(fz[b], anchors[t], head.num_anchor_per_locs[t], head.num_classes[t],
+                                             head._box_off[t], head._cls_off[t], tc.score_threshold,
+                                             tc.nms.nms_iou_threshold, tc.nms.nms_pre_max_size, tc.nms.nms_post_max_size,
+                                             tc.post_center_limit_range)
+            bb.append(bx); ss.append(sc); ll.append(lb + label_off[t])
+        bb, ss, ll = np.concatenate(bb), np.concatenate(ss), np.concatenate(ll)
+        got = out[b]
+        assert got["label_preds"].cpu().numpy().tolist() == ll.tolist()
+        np.testing.assert_allclose(got["scores"].cpu().numpy(), ss, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got["box3d_lidar"].cpu().numpy()[:, :8], bb[:, :8], rtol=1e-4, atol=1e-4)
+        total += len(ss)
+    assert total > 0
