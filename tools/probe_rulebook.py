@@ -46,3 +46,16 @@ for name, coords, shape in levels:
     # 2-D blocked (8x8 in y,x) then z
     key3 = (((c[:, 0].long() * (H // 8 + 1) + c[:, 2] // 8) * (W // 8 + 1) + c[:, 3] // 8) * D + c[:, 1]) * 64 + (c[:, 2] % 8) * 8 + c[:, 3] % 8
     stats(table(c[torch.argsort(key3)].contiguous()), "blk8x8,z")
+    # orderings by the row's own tap mask (the executed (32-row, tap) units only depend on WHICH rows share a tile, so
+    # permuting the table's columns is enough to evaluate them): full 27-bit mask sort (ideal grouping), the six face
+    # neighbours as a 6-bit bucket key (a counting sort), popcount buckets
+    nbr = table(c)
+    valid = (nbr >= 0)
+    w = (1 << torch.arange(27, device=dev, dtype=torch.int64)).view(27, 1)
+    mask = (valid.long() * w).sum(0)
+    face = [4, 10, 12, 14, 16, 22]                                     # (kz,ky,kx) = centre +- one axis, k = (kz*3+ky)*3+kx
+    fkey = sum(((mask >> k) & 1) << i for i, k in enumerate(face))
+    pop = valid.sum(0)
+    for tag, key in (("mask-sort", mask), ("face6 bkt", fkey), ("popcount", pop), ("pop,mask", pop * (1 << 27) + mask)):
+        perm = torch.argsort(key, stable=True)
+        stats(nbr[:, perm], tag)
