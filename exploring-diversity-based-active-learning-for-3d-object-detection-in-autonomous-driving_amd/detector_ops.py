@@ -257,6 +257,85 @@ def sparse_rng(cin, cout):
     return (cin, cout) in (RNG_BUILT if SPCONV == "rng" else RNG_PAIRS & RNG_BUILT)
 
 
+# Level-0 layers (16 input channels, 27 taps) on raster-ordered rows (csrc/spconv_l0.hip): AL3D_L0 = "raster"
+# (default: the encoder renumbers the voxelizer's rows in raster order and runs these layers as item streams with
+# LDS-resident weights) | "off" (first-appearance order, register-gather kernel: round 3's path).  R16_COUTS: the output
+# widths that take the item-stream kernel (16: the five submanifold layers; 32: the strided 16 -> 32 layer)
+L0 = _os.environ.get("AL3D_L0", "raster")
+if L0 not in ("raster", "off"):
+    raise lib.Al3dError(f"AL3D_L0={L0!r}: expected raster or off")
+R16_COUTS = {16}
+if _os.environ.get("AL3D_R16_COUTS") is not None:    # dev override, e.g. "16,32" or "" for none
+    R16_COUTS = {int(v) for v in _os.environ["AL3D_R16_COUTS"].split(",") if v}
+R16_TPW = int(_os.environ.get("AL3D_R16_TPW", "0"))   # tiles per wave (0: the library's default)
+# row format between two item-stream layers of level 0: "pair" (the split runs once, in the producer) | "f32"
+L0_ROWS = _os.environ.get("AL3D_L0_ROWS", "pair")
+
+
+def sparse_raster():
+    """True when the encoder renumbers its level-0 rows in raster order."""
+    return MATH == "f16x3" and SPCONV == "auto" and L0 == "raster"
+
+
+def sparse_r16(cin, cout, K=27):
+    """True when the 27-tap f16x3 layer 16 -> cout runs on the item-stream kernel."""
+    return sparse_raster() and cin == 16 and K == 27 and cout in R16_COUTS
+
+
+class R16Packed:
+    """f16x3 weights of a 16-input-channel 27-tap layer as the item-stream kernel's LDS image
+    (al3d_sp_pack_r16_f16x3: [27][2 planes][2 k-halves][Cout][8] f16)."""
+    dtype = torch.float16
+
+    def __init__(self, data, cout):
+        self.data, self.cout, self.K, self.cin = data, cout, 27, 16
+
+
+def pack_r16_f16x3(planes):
+    """f16 planes [2,Cout,27,16] (split_f16x3 of the [Cout,27,16] weights) -> R16Packed."""
+    planes = _dev(planes, torch.float16, "planes")
+    _, cout, K, cin = planes.shape
+    n = lib.load().al3d_sp_pack_r16_f16x3_elems(cout)
+    if n <= 0 or K != 27 or cin != 16:
+        raise lib.Al3dError(f"pack_r16_f16x3: unsupported shape Cout={cout} K={K} Cin={cin}")
+    out = torch.empty((n,), dtype=torch.float16, device=planes.device)
+    lib.call("al3d_sp_pack_r16_f16x3", _ptr(planes), cout, _ptr(out), _stream())
+    return R16Packed(out, cout)
+
+
+def raster_perm(coords, batch, shape):
+    """coords [n,4] i32 (b,z,y,x) -> (perm [n] i32: raster position -> row, coords in raster order)."""
+    coords = _dev(coords, torch.int32, "coords")
+    n = coords.shape[0]
+    D_, H_, W_ = [int(v) for v in shape]
+    perm = torch.empty((n,), dtype=torch.int32, device=coords.device)
+    out = torch.empty_like(coords)
+    ws = torch.empty(max(int(lib.load().al3d_sp_raster_perm_workspace_bytes(n, batch, D_, H_)), 1), dtype=torch.uint8,
+                     device=coords.device)
+    lib.call("al3d_sp_raster_perm", _ptr(coords), n, batch, D_, H_, W_, _ptr(ws), _ptr(perm), _ptr(out), _stream())
+    return perm, out
+
+
+def rows_gather_pad(rows, perm, channels_out, to_pair=False):
+    """out[r] = rows[perm[r]] zero-padded to channels_out channels (f32 rows or pair rows)."""
+    rows = _dev(rows, torch.float32, "rows")
+    n, F = rows.shape
+    out = torch.empty((n, channels_out), dtype=torch.float32, device=rows.device)
+    lib.call("al3d_sp_rows_gather_pad_f32", _ptr(rows), _ptr(perm), n, F, channels_out, 1 if to_pair else 0, _ptr(out), _stream())
+    return out
+
+
+def tile_items(nbr, n_out, tmask):
+    """Item list of a tiled 27-tap table: (first [ntiles+1] i32, items [9*ntiles+1, 4] i32)."""
+    dev = nbr.device
+    ntiles = (max(n_out, 1) + 31) // 32
+    first = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)
+    items = torch.empty((9 * ntiles + 1, 4), dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.load().al3d_sp_tile_items_workspace_bytes(n_out)), dtype=torch.uint8, device=dev)
+    lib.call("al3d_sp_tile_items", _ptr(nbr), nbr.shape[1], 27, n_out, _ptr(tmask), _ptr(ws), _ptr(first), _ptr(items), _stream())
+    return first, items
+
+
 def sparse_glds(cin=None, cout=None):
     """True when the f16x3 sparse layer cin -> cout gets the LDS-DMA kernels' weight image (no arguments: any layer
     may): the per-tap gather kernel, or the range-gather kernel where sparse_rng says so."""
@@ -507,7 +586,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
     if mfma is None:
         mfma = (cin, cout) in MFMA_PAIRS and ({"bf16x6": "wave2", "f16x3": "glds_f16x3" if sparse_glds(cin, cout) else "wave2_f16x3"}
                                                .get(sparse_math(), True))
-    tiled = mfma in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3")     # pitched table + per-tile tap masks
+    tiled = mfma in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3", "r16_f16x3")     # pitched table + per-tile tap masks
     tmask = None
     if subm:
         if tiled:
@@ -544,7 +623,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
             lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
                      _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    if io and mfma not in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3"):
+    if io and mfma not in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3", "r16_f16x3"):
         raise lib.Al3dError("sparse_conv_layer: pair rows exist for the tiled f16x3 kernels only")
     if mfma == "glds_f16x3":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
@@ -560,6 +639,14 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
         lib.call("al3d_sp_tile_ranges", _ptr(nbr), nbr.shape[1], K, n_out, _ptr(trng), st)
         lib.call("al3d_sp_conv_rng_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), _ptr(trng), K,
                  _ptr(pk.data), cin, cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, io, st)
+    elif mfma == "r16_f16x3":
+        if K != 27 or cin != 16:
+            raise lib.Al3dError("sparse_conv_layer: the item-stream kernel serves 27-tap layers with 16 input channels")
+        w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
+        pk = pack_r16_f16x3(w3)
+        first, items = tile_items(nbr, n_out, tmask)
+        lib.call("al3d_sp_conv_r16_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(items), _ptr(first), K, _ptr(pk.data),
+                 cin, cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, io, R16_TPW, st)
     elif mfma == "wave2_f16x3_tiles":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
         lib.call("al3d_sp_conv_wave2_f16x3_tiles_io", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), K, _ptr(w3), cin,

@@ -85,6 +85,15 @@ SIGNATURES = {
     "al3d_sp_tile_ranges": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p]),
     "al3d_sp_conv_rng_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
                                        c_p, c_int, c_int, c_p]),
+    "al3d_sp_raster_perm_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "al3d_sp_raster_perm": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p]),
+    "al3d_sp_rows_gather_pad_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_sp_tile_items_workspace_bytes": (c_i64, [c_int]),
+    "al3d_sp_tile_items": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p]),
+    "al3d_sp_pack_r16_f16x3_elems": (c_i64, [c_int]),
+    "al3d_sp_pack_r16_f16x3": (c_int, [c_p, c_int, c_p, c_p]),
+    "al3d_sp_conv_r16_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
+                                       c_p, c_int, c_int, c_int, c_p]),
     "al3d_sp_rows_convert_f16x3": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p]),
     "al3d_sp_conv_glds_f16x3_io": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
                                            c_p, c_int, c_int, c_p]),

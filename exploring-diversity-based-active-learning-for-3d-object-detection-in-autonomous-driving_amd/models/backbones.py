@@ -100,9 +100,14 @@ class _SparseEncoderBase(nn.Module):
 
     def _prepare(self, device):
         """Pack weights / fold BN once per device (eval only)."""
-        if getattr(self, "_packed_dev", None) == (device, D.MATH, D.SPCONV):
+        if getattr(self, "_packed_dev", None) == (device, D.MATH, D.SPCONV, D.L0, tuple(sorted(D.R16_COUTS))):
             return
         plan = []
+        # The input level's rows may be renumbered (raster order, csrc/spconv_l0.hip) only if they never leave the encoder:
+        # a strided conv must come before the first stage output (true for every shipped encoder; a stage that ends on the
+        # input level keeps the caller's row order, like spconv's SubMConv3d)
+        first = list(self._stages()[0].children()) if len(self._stages()) else []
+        self._raster_ok = any(isinstance(m_, _SpConvParams) and not m_.subm for m_ in first)
         for seq in self._stages():
             mods = list(seq.children())
             i = 0
@@ -111,7 +116,7 @@ class _SparseEncoderBase(nn.Module):
                 if isinstance(m, _SpConvParams):
                     bn = mods[i + 1]
                     scale, shift = fold_bn(bn)
-                    w, scale = self._pack(m, device, scale.to(device))
+                    w, scale = self._pack(m, device, scale.to(device), self._raster_ok)
                     plan.append(dict(kind="subm" if m.subm else "down", mod=m, w=w,
                                      scale=scale, shift=shift.to(device), relu=True,
                                      residual=False))
@@ -121,7 +126,7 @@ class _SparseEncoderBase(nn.Module):
                         scale, shift = fold_bn(bn)
                         if conv.bias is not None:   # (x + b) * s + t
                             shift = shift + conv.bias.detach().float().to(scale.device) * scale
-                        w, scale = self._pack(conv, device, scale.to(device))
+                        w, scale = self._pack(conv, device, scale.to(device), self._raster_ok)
                         plan.append(dict(kind="subm", mod=conv, w=w,
                                          scale=scale, shift=shift.to(device), relu=True,
                                          residual=last, block_start=not last))
@@ -130,7 +135,7 @@ class _SparseEncoderBase(nn.Module):
                     i += 1
             plan.append(dict(kind="stage_end"))
         self._plan = plan
-        self._packed_dev = (device, D.MATH, D.SPCONV)
+        self._packed_dev = (device, D.MATH, D.SPCONV, D.L0, tuple(sorted(D.R16_COUTS)))
         self._levels = {}
 
     @staticmethod
@@ -142,7 +147,7 @@ class _SparseEncoderBase(nn.Module):
         return m.in_channels
 
     @staticmethod
-    def _pack(m, device, scale):
+    def _pack(m, device, scale, raster_ok=False):
         """[kz,ky,kx,Cin,Cout] -> [K,Cin,Cout] (VALU kernel) or [Cout,K,Cin] (MFMA kernels, split into
         bf16 / f16 planes for the split arithmetics).  Returns (weights, scale): the f16x3 split folds
         its weight exponent into the layer's BN scale."""
@@ -154,16 +159,24 @@ class _SparseEncoderBase(nn.Module):
             w = w.permute(2, 0, 1).contiguous().to(device)
             if D.sparse_math() == "f16x3":
                 planes, scale = D.split_f16x3(w, scale)
+                if raster_ok and D.sparse_r16(cin, m.out_channels, w.shape[1]):
+                    return D.pack_r16_f16x3(planes), scale
                 return (D.pack_glds_f16x3(planes) if D.sparse_glds(cin, m.out_channels) else planes), scale
             return (D.split_bf16x3(w) if D.sparse_math() == "bf16x6" else w), scale
         return w.contiguous().to(device), scale
 
     @staticmethod
-    def _conv(m, feats, nbr, K, step, residual, out, n, st, tmask=None, trng=None, io=0):
+    def _conv(m, feats, nbr, K, step, residual, out, n, st, tmask=None, trng=None, io=0, items=None):
         """One fused sparse layer (conv + folded BN + optional residual + ReLU)."""
         res_ptr = None if residual is None else _ptr(residual)
         cin = feats.shape[-1]                    # == m.in_channels, or 16 for a zero-padded narrow first layer
         mfma_pair = (cin, m.out_channels) in MFMA_PAIRS
+        if isinstance(step["w"], D.R16Packed):
+            # level-0 layer on raster rows: item stream, LDS-resident weights (csrc/spconv_l0.hip)
+            lib.call("al3d_sp_conv_r16_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(items[1]), _ptr(items[0]), K,
+                     _ptr(step["w"].data), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1,
+                     _ptr(out), n, io, D.R16_TPW, st)
+            return
         if mfma_pair and isinstance(step["w"], D.GldsPacked) and trng is not None and m.subm and K == 27 and \
                 D.sparse_rng(cin, m.out_channels):
             # f16x3 arithmetic, LDS-DMA range gather: one staged index range per (tile, kz, ky) serves three taps
@@ -223,11 +236,17 @@ class _SparseEncoderBase(nn.Module):
         coords = coords.to(torch.int32).contiguous()
         shape = [int(s) for s in spatial_shape]
         n = coords.shape[0]
+        perm = None
+        if D.sparse_raster() and any(isinstance(s_.get("w"), D.R16Packed) for s_ in self._plan):
+            # the input level's rows renumbered in raster order (b, z, y, x): the order of a level's rows is free inside
+            # the encoder (example["coordinates"] keeps the reference's first-appearance order), and raster order makes
+            # the neighbour sets of consecutive rows contiguous index ranges (csrc/spconv_l0.hip)
+            perm, coords = D.raster_perm(coords, batch_size, shape)
         lv = self._level(shape, batch_size, dev)
         lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W, _ptr(lv.grid),
                  1, st)
         used = [(lv, coords, n)]
-        nbr, nbr_key, trng = None, None, None
+        nbr, nbr_key, trng, items = None, None, None, None
         steps = []
         for step in self._plan:
             if step["kind"] == "stage_end":
@@ -236,8 +255,8 @@ class _SparseEncoderBase(nn.Module):
             m = step["mod"]
             K = int(np.prod(m.kernel_size))
             # f16x3 (both matrix-core kernels): pitched table + per-tile tap masks; other arithmetics: plain table
-            tiled = isinstance(step["w"], D.GldsPacked) or (isinstance(step["w"], torch.Tensor) and
-                                                            step["w"].dtype == torch.float16)
+            tiled = isinstance(step["w"], (D.GldsPacked, D.R16Packed)) or (isinstance(step["w"], torch.Tensor) and
+                                                                           step["w"].dtype == torch.float16)
             if step["kind"] == "subm":
                 key = (id(lv), m.kernel_size, tiled)
                 if nbr_key != key:
@@ -252,12 +271,15 @@ class _SparseEncoderBase(nn.Module):
                         lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
                                  _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
                     nbr_key = key
-                    trng = None
+                    trng, items = None, None
                 if tiled and trng is None and K == 27 and D.sparse_rng(self._pad_cin(m), m.out_channels):
                     # (lo, len) of every (tile, kz, ky) group: once per table, shared by the level's layers
                     trng = torch.empty((max(nbr.shape[1] // 32, 1), 9, 2), dtype=torch.int32, device=dev)
                     lib.call("al3d_sp_tile_ranges", _ptr(nbr), nbr.shape[1], K, n, _ptr(trng), st)
-                steps.append(dict(nbr=nbr, n=n, K=K, tmask=tmask, trng=trng))
+                if isinstance(step["w"], D.R16Packed) and items is None:
+                    items = D.tile_items(nbr, n, tmask)          # once per table, shared by the level's layers
+                steps.append(dict(nbr=nbr, n=n, K=K, tmask=tmask, trng=trng,
+                                  items=items if isinstance(step["w"], D.R16Packed) else None))
             else:
                 oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
                 olv = self._level(oshape, batch_size, dev)
@@ -282,7 +304,8 @@ class _SparseEncoderBase(nn.Module):
                     dnbr, dmask = torch.empty((K, max(n_out, 1)), dtype=torch.int32, device=dev), None
                     lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, ks, ss, ps, batch_size, lv.D, lv.H,
                              lv.W, _ptr(lv.grid), _ptr(dnbr), st)
-                steps.append(dict(nbr=dnbr, n=n_out, K=K, tmask=dmask))
+                steps.append(dict(nbr=dnbr, n=n_out, K=K, tmask=dmask,
+                                  items=D.tile_items(dnbr, n_out, dmask) if isinstance(step["w"], D.R16Packed) else None))
                 coords, n, shape, lv = ocoords, n_out, oshape, olv
                 nbr_key = None
         for g, c, cnt in used:      # leave every level grid clean for the next call
@@ -291,7 +314,7 @@ class _SparseEncoderBase(nn.Module):
         # coordinate-independent work that can be done ahead
         last_c = [st_["mod"].out_channels for st_ in self._plan if st_["kind"] != "stage_end"][-1]
         dense = torch.zeros((batch_size, shape[1], shape[2], last_c * shape[0]), dtype=torch.float32, device=dev)
-        return dict(steps=steps, batch_size=batch_size, dense=dense)
+        return dict(steps=steps, batch_size=batch_size, dense=dense, perm=perm)
 
     def _run(self, feats, coords, batch_size, spatial_shape, book=None):
         """Returns (final SparseTensor, [SparseTensor per stage]).  ``book``: a rulebook built earlier
@@ -309,31 +332,40 @@ class _SparseEncoderBase(nn.Module):
         def pairable(step_, b_):
             return (D.SPROWS == "pair" and step_["kind"] != "stage_end" and b_.get("tmask") is not None and
                     (self._pad_cin(step_["mod"]), step_["mod"].out_channels) in MFMA_PAIRS and
-                    (isinstance(step_["w"], D.GldsPacked) or (isinstance(step_["w"], torch.Tensor) and
-                                                              step_["w"].dtype == torch.float16)))
+                    (isinstance(step_["w"], (D.GldsPacked, D.R16Packed)) or (isinstance(step_["w"], torch.Tensor) and
+                                                                             step_["w"].dtype == torch.float16)))
         convs = [(s_, b_) for s_, b_ in zip(self._plan, book["steps"]) if s_["kind"] != "stage_end"]
         ci, pair = 0, False
+        perm = book.get("perm")
         for step, b in zip(self._plan, book["steps"]):
             if step["kind"] == "stage_end":
                 middle.append(SparseTensor(feats, b["coords"], b["shape"], batch_size, pair_rows=pair))
                 continue
             m = step["mod"]
-            if feats.shape[-1] != self._pad_cin(m):
+            if perm is not None or feats.shape[-1] != self._pad_cin(m):
                 assert not pair
-                feats = torch.nn.functional.pad(feats, (0, self._pad_cin(m) - feats.shape[-1]))
+                # the voxel features in the encoder's row order, zero-padded to the first layer's input width
+                # (as pair rows when the first layer is an item-stream layer: AL3D_L0_ROWS)
+                first_pair = D.L0_ROWS == "pair" and isinstance(step["w"], D.R16Packed) and pairable(step, b)
+                feats = D.rows_gather_pad(feats, perm, self._pad_cin(m), to_pair=first_pair)
+                perm, pair = None, first_pair
             if step.get("block_start"):
                 identity, identity_pair = feats, pair
             ok = pairable(step, b)
             assert ok or not pair, "pair rows reached a layer that cannot read them"
             # 16-channel rows stay f32: on the level-0 layers the pair-row epilogue costs more (+12 %) than the
             # consumers gain (-3 %); from 32 channels on the consumers are the LDS-DMA kernels (-5..10 %)
-            out_pair = ok and ci + 1 < len(convs) and pairable(*convs[ci + 1]) and m.out_channels >= 32
+            # (the item-stream kernels of level 0 are bound by instruction issue, the split is a third of their vector
+            # instructions: there 16-channel rows travel as pair rows too)
+            out_pair = ok and ci + 1 < len(convs) and pairable(*convs[ci + 1]) and (
+                m.out_channels >= 32 or (D.L0_ROWS == "pair" and isinstance(step["w"], D.R16Packed) and
+                                         isinstance(convs[ci + 1][0]["w"], D.R16Packed)))
             res = identity if step.get("residual") else None
             io = ((D.IO_IN_PAIR if pair else 0) | (D.IO_OUT_PAIR if out_pair else 0) |
                   (D.IO_RES_PAIR if (res is not None and identity_pair) else 0))
             out = torch.empty((b["n"], m.out_channels), dtype=torch.float32, device=dev)
             self._conv(m, feats, b["nbr"], b["K"], step, res, out, b["n"], st,
-                       tmask=b.get("tmask"), trng=b.get("trng"), io=io)
+                       tmask=b.get("tmask"), trng=b.get("trng"), io=io, items=b.get("items"))
             feats, pair = out, out_pair
             ci += 1
         assert not pair

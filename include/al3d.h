@@ -327,6 +327,42 @@ int al3d_sp_conv_rng_f16x3(const float* fin, const int* nbr, int nbr_pitch, cons
                            const float* shift, const float* residual, int relu, float* fout, int n_out, int io,
                            void* stream);
 
+/* Level-0 layers (16 input channels) on RASTER-ordered rows (csrc/spconv_l0.hip; the layers are
+ * det3d/models/backbones/scn.py:331-347, rulebook semantics geometry.h:248-298).  The voxelizer's rows arrive in
+ * first-appearance order (the reference's order of example["coordinates"]); inside the encoder the row order of a
+ * level is free, so the encoder renumbers level 0 in raster order (b, z, y, x):
+ *   al3d_sp_raster_perm: coords [n][4] (b, z, y, x; unique cells; W <= 2048) -> perm [n] (raster position ->
+ *     original row) and coords_raster [n][4]; a counting sort over the (b, z, y) lines + a bit-mask rank inside each
+ *     line.  workspace >= al3d_sp_raster_perm_workspace_bytes(n, B, D, H).
+ *   al3d_sp_rows_gather_pad_f32: out[r] = rows[perm[r]] (perm NULL: identity) zero-padded from channels_in to
+ *     channels_out (% 8 == 0) channels, as f32 rows or pair rows.
+ * In raster order the neighbours of 32 consecutive output rows under the three kx taps of a (kz, ky) group lie in one
+ * short contiguous index range, and every live (32-row tile, group) pair of a tiled 27-tap table becomes one ITEM:
+ *   al3d_sp_tile_items: first [ntiles + 1] (index of a tile's first item; first[ntiles] = item count), items
+ *     [9 ntiles + 1] int4 {lo, len | group << 16 | first-of-tile << 20 | last-of-tile << 21, tile tap mask, tile};
+ *     workspace >= al3d_sp_tile_items_workspace_bytes(n_out).  Works on submanifold and strided tables.
+ *   al3d_sp_pack_r16_f16x3: f16 planes [2][Cout][27][16] -> the kernel's LDS image [27][2][2 k-halves][Cout][8]
+ *     (Cout 16 or 32; al3d_sp_pack_r16_f16x3_elems elements).
+ *   al3d_sp_conv_r16_f16x3: the layer as a stream of items per wave: each item's index range is staged once by LDS-DMA
+ *     as whole lines and serves three taps; all 27 taps' weights stay in LDS; no barrier in the main loop.  Ranges
+ *     longer than the staged window are gathered row by row (any row order is correct, raster order is fast).
+ *     f16x3 arithmetic in al3d_sp_conv_wave2_f16x3's summation order: BIT-IDENTICAL to it.  residual only at Cout 16;
+ *     io as below; tiles_per_wave <= 0: default. */
+int64_t al3d_sp_raster_perm_workspace_bytes(int n, int B, int D, int H);
+int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H, int W, void* workspace, int* perm,
+                        int* coords_raster, void* stream);
+int al3d_sp_rows_gather_pad_f32(const float* rows, const int* perm, int64_t n, int channels_in, int channels_out,
+                                int to_pair, float* out, void* stream);
+int64_t al3d_sp_tile_items_workspace_bytes(int n_out);
+int al3d_sp_tile_items(const int* nbr, int64_t nbr_pitch, int K, int n_out, const unsigned* tile_mask, void* workspace,
+                       int* first, void* items, void* stream);
+int64_t al3d_sp_pack_r16_f16x3_elems(int cout);
+int al3d_sp_pack_r16_f16x3(const void* planes_f16x2, int cout, void* out_image, void* stream);
+int al3d_sp_conv_r16_f16x3(const float* fin, const int* nbr, int nbr_pitch, const void* items, const int* first, int K,
+                           const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
+                           const float* residual, int relu, float* fout, int n_out, int io, int tiles_per_wave,
+                           void* stream);
+
 /* Row formats of the sparse encoder's activations (csrc/sp_rows.h).  "pair rows" hold, per 8 channels, the two f16
  * planes the f16x3 arithmetic multiplies with (16 B xh = f16(x), 16 B xl' = f16((x - xh) 2^11)) in the 32 bytes of
  * the 8 floats: a consumer's fragment load is its MFMA operand pair and the split runs once, in the producer's
