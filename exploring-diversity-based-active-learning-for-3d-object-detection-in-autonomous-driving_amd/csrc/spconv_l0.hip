@@ -106,17 +106,135 @@ __global__ __launch_bounds__(256) void l0_rank_kernel(const int* __restrict__ cn
     }
 }
 
+// ---- the same permutation for frame-sorted inputs, one workgroup per frame, everything but the bucket arrays in LDS.
+// The voxelizer hands over the frames of a batch one after the other (coords[:, 0] ascending) with at most 65,535 rows
+// each; a frame's (z, y) lines then fit 16-bit counters in LDS (D H <= 43,008: 84 KB) and the three global passes above
+// (7.68 M returning atomics on a 21 MB counter array at the memory side, a 5.4 M-entry scan, one wave per 64 line slots
+// with two dependent global round trips per non-empty line: 0.95 ms per 128-frame batch) become LDS atomics, an LDS scan
+// and an LDS bit-mask rank over chunks of 512 lines.
+#define L0F_NT 1024
+#define L0F_MAXLINES 43008
+#define L0F_CHUNK 512
+__global__ __launch_bounds__(L0F_NT) void l0_frame_sort_kernel(const int* __restrict__ coords, int n, L0Dims g,
+                                                               unsigned short* __restrict__ slot_ws,
+                                                               unsigned short* __restrict__ bx, int* __restrict__ bl,
+                                                               int* __restrict__ bid, int* __restrict__ perm,
+                                                               int* __restrict__ coords_r)
+{
+    __shared__ unsigned cw[L0F_MAXLINES / 2 + 2];              // packed 16-bit line counters, then exclusive prefixes
+    __shared__ unsigned bits[L0F_CHUNK * 32];                  // x bit masks of one chunk of lines
+    __shared__ int s_part[L0F_NT / 64];
+    __shared__ int s_lo, s_hi;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int LH = g.D * g.H;
+    if (tid < 2) {                                             // frame range: lower bounds of b and b + 1 in coords[:, 0]
+        const int key = b + tid;
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (coords[4 * (int64_t)mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (tid == 0) s_lo = lo; else s_hi = lo;
+    }
+    for (int i = tid; i < L0F_MAXLINES / 2 + 2; i += L0F_NT) cw[i] = 0u;
+    __syncthreads();
+    const int lo = s_lo, cnt_f = s_hi - s_lo;
+    if (cnt_f <= 0) return;                                    // uniform
+    // A: arrival slot of every row in its line
+    for (int i = tid; i < cnt_f; i += L0F_NT) {
+        const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)(lo + i));
+        const int line = c.y * g.H + c.z;
+        const unsigned old = atomicAdd(&cw[line >> 1], (line & 1) ? 0x10000u : 1u);
+        slot_ws[lo + i] = (unsigned short)((line & 1) ? old >> 16 : old & 0xffffu);
+    }
+    __syncthreads();
+    // B: exclusive scan of the LH counters in place (42 consecutive lines = 21 words per thread)
+    {
+        constexpr int WPT = (L0F_MAXLINES / 2) / L0F_NT;      // 21
+        unsigned w[WPT];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            w[k] = cw[tid * WPT + k];
+            sum += (int)(w[k] & 0xffffu) + (int)(w[k] >> 16);
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) s_part[wave] = inc;
+        __syncthreads();
+        if (wave == 0) {
+            int v = lane < L0F_NT / 64 ? s_part[lane] : 0;
+#pragma unroll
+            for (int off = 1; off < L0F_NT / 64; off <<= 1) {
+                const int t = __shfl_up(v, off);
+                if (lane >= off) v += t;
+            }
+            if (lane < L0F_NT / 64) s_part[lane] = v;          // inclusive wave totals
+        }
+        __syncthreads();
+        int run = (wave > 0 ? s_part[wave - 1] : 0) + inc - sum;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const int c0 = (int)(w[k] & 0xffffu), c1 = (int)(w[k] >> 16);
+            cw[tid * WPT + k] = (unsigned)run | ((unsigned)(run + c0) << 16);
+            run += c0 + c1;
+        }
+        if (tid == L0F_NT - 1) cw[L0F_MAXLINES / 2] = (unsigned)run;   // base[MAXLINES] = the frame's row count
+    }
+    __syncthreads();
+    auto base_of = [&](int line) -> int { const unsigned v = cw[line >> 1]; return (int)((line & 1) ? v >> 16 : v & 0xffffu); };
+    // C: rows grouped by line (arrival order inside a line)
+    for (int i = tid; i < cnt_f; i += L0F_NT) {
+        const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)(lo + i));
+        const int line = c.y * g.H + c.z;
+        const int p = lo + base_of(line) + slot_ws[lo + i];
+        bx[p] = (unsigned short)c.w;
+        bl[p] = line;
+        bid[p] = lo + i;
+    }
+    __syncthreads();                                           // the bucket arrays are read back by other threads below
+    // D: rank inside each line from an x bit mask, 512 lines at a time
+    for (int L0 = 0; L0 < LH; L0 += L0F_CHUNK) {
+        const int L1 = L0 + L0F_CHUNK < LH ? L0 + L0F_CHUNK : LH;
+        const int p0 = base_of(L0), p1 = L1 < L0F_MAXLINES ? base_of(L1) : (int)cw[L0F_MAXLINES / 2];
+        if (p0 == p1) continue;                                // uniform: no row in these lines
+        for (int i = tid; i < L0F_CHUNK * 32; i += L0F_NT) bits[i] = 0u;
+        __syncthreads();
+        for (int p = p0 + tid; p < p1; p += L0F_NT) {
+            const unsigned x = bx[lo + p];
+            atomicOr(&bits[(bl[lo + p] - L0) * 32 + (x >> 5)], 1u << (x & 31u));
+        }
+        __syncthreads();
+        for (int p = p0 + tid; p < p1; p += L0F_NT) {
+            const unsigned x = bx[lo + p];
+            const int line = bl[lo + p];
+            const unsigned* m = &bits[(line - L0) * 32];
+            int rank = __popc(m[x >> 5] & ((1u << (x & 31u)) - 1u));
+            for (unsigned k = 0; k < (x >> 5); ++k) rank += __popc(m[k]);
+            const int pos = lo + base_of(line) + rank;
+            perm[pos] = bid[lo + p];
+            *reinterpret_cast<int4*>(coords_r + 4 * (int64_t)pos) = make_int4(b, line / g.H, line % g.H, (int)x);
+        }
+        __syncthreads();
+    }
+}
+
 static inline int64_t l0_lines(int B, int D, int H) { return (int64_t)B * D * H; }
 
 extern "C" int64_t al3d_sp_raster_perm_workspace_bytes(int n, int B, int D, int H)
 {
     const int64_t L = l0_lines(B, D, H);
-    return 2 * al3d_align(L * 4, 256) + al3d_scan_workspace_bytes(L) + al3d_align((int64_t)n * 4, 256) * 2 +
+    return 2 * al3d_align(L * 4, 256) + al3d_scan_workspace_bytes(L) + al3d_align((int64_t)n * 4, 256) * 3 +
            al3d_align((int64_t)n * 2, 256);
 }
 
-extern "C" int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H, int W, void* workspace, int* perm,
-                                   int* coords_raster, void* stream)
+extern "C" int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H, int W, int frame_rows_max,
+                                   void* workspace, int* perm, int* coords_raster, void* stream)
 {
     AL3D_REQUIRE(n >= 0 && B > 0 && D > 0 && H > 0 && W > 0 && W <= 2048, "al3d_sp_raster_perm: bad sizes (W <= 2048)");
     AL3D_REQUIRE(l0_lines(B, D, H) < (1ll << 31), "al3d_sp_raster_perm: too many (b, z, y) lines");
@@ -130,8 +248,17 @@ extern "C" int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H
     void* scan_ws = w; w += al3d_scan_workspace_bytes(L);
     int* slot = (int*)w; w += al3d_align((int64_t)n * 4, 256);
     int* bid = (int*)w; w += al3d_align((int64_t)n * 4, 256);
-    unsigned short* bx = (unsigned short*)w;
+    unsigned short* bx = (unsigned short*)w; w += al3d_align((int64_t)n * 2, 256);
+    int* bl = (int*)w;
     const L0Dims g{B, D, H, W};
+    if (frame_rows_max > 0 && frame_rows_max <= 65535 && D * H <= L0F_MAXLINES && W <= 1024) {
+        // frame-sorted input (coords[:, 0] ascending, at most frame_rows_max rows per frame): one workgroup per frame
+        unsigned short* slot16 = (unsigned short*)slot;
+        hipLaunchKernelGGL(l0_frame_sort_kernel, dim3((unsigned)B), dim3(L0F_NT), 0, s, coords, n, g, slot16, bx, bl, bid, perm,
+                           coords_raster);
+        AL3D_CHECK_LAUNCH("l0_frame_sort_kernel");
+        return AL3D_OK;
+    }
     if (hipMemsetAsync(cnt, 0, L * 4, s) != hipSuccess) return al3d_fail(AL3D_ELAUNCH, "al3d_sp_raster_perm: memset failed");
     const unsigned nb = (unsigned)al3d_cdiv(n, 256);
     hipLaunchKernelGGL(l0_line_count_kernel, dim3(nb), dim3(256), 0, s, coords, n, g, cnt, slot);

@@ -203,7 +203,7 @@ class FileSweepLoader:
         gs = self.voxelizer.grid_size
         return {
             "voxel_features": v["feat"], "coordinates": v["coords"], "num_points": v["num_points"],
-            "num_voxels": v["num_voxels"],
+            "num_voxels": v["num_voxels"], "voxel_cap": v["voxel_cap"],
             "shape": np.tile(np.asarray(gs, dtype=np.int64)[None], (st.B, 1)),
             "anchors": self.anchors,
             "metadata": [{"token": str(self.infos[i].get("token", f"frame{i:06d}")), "index": i} for i in st.ids],

@@ -207,6 +207,7 @@ def collate_device(batch_list):
         if batch_list[0].get(k) is not None:
             out[k] = torch.cat([ex[k] for ex in batch_list], dim=0)
     out["num_voxels"] = np.concatenate([np.asarray(ex["num_voxels"]) for ex in batch_list])
+    out["voxel_cap"] = int(out["num_voxels"].max()) if len(out["num_voxels"]) else 0   # frames are concatenated in order
     out["shape"] = np.stack([np.asarray(ex["shape"]) for ex in batch_list])
     out["metadata"] = [ex.get("metadata") for ex in batch_list]
     if "anchors" in batch_list[0]:

@@ -108,7 +108,7 @@ class DeviceSweepLoader:
             B = len(ids)
             yield {
                 "voxel_features": v["feat"], "coordinates": v["coords"], "num_points": v["num_points"],
-                "num_voxels": v["num_voxels"],
+                "num_voxels": v["num_voxels"], "voxel_cap": v["voxel_cap"],
                 "shape": np.tile(np.asarray(gs, dtype=np.int64)[None], (B, 1)),
                 "anchors": self.anchors,
                 "metadata": [{"token": self.pool.tokens[i], "index": i} for i in ids],

@@ -303,8 +303,10 @@ def pack_r16_f16x3(planes):
     return R16Packed(out, cout)
 
 
-def raster_perm(coords, batch, shape):
-    """coords [n,4] i32 (b,z,y,x) -> (perm [n] i32: raster position -> row, coords in raster order)."""
+def raster_perm(coords, batch, shape, frame_rows_max=0):
+    """coords [n,4] i32 (b,z,y,x) -> (perm [n] i32: raster position -> row, coords in raster order).
+    frame_rows_max > 0: the rows are frame-sorted with at most that many rows per frame (the voxelizer's output and its
+    voxel cap): the sort then runs in LDS, one workgroup per frame."""
     coords = _dev(coords, torch.int32, "coords")
     n = coords.shape[0]
     D_, H_, W_ = [int(v) for v in shape]
@@ -312,7 +314,8 @@ def raster_perm(coords, batch, shape):
     out = torch.empty_like(coords)
     ws = torch.empty(max(int(lib.load().al3d_sp_raster_perm_workspace_bytes(n, batch, D_, H_)), 1), dtype=torch.uint8,
                      device=coords.device)
-    lib.call("al3d_sp_raster_perm", _ptr(coords), n, batch, D_, H_, W_, _ptr(ws), _ptr(perm), _ptr(out), _stream())
+    lib.call("al3d_sp_raster_perm", _ptr(coords), n, batch, D_, H_, W_, int(frame_rows_max), _ptr(ws), _ptr(perm), _ptr(out),
+             _stream())
     return perm, out
 
 
@@ -558,7 +561,7 @@ class Voxelizer:
                  _ptr(num_voxels), _ptr(row_base), _stream())
         m = int(row_base[-1].item())            # one small D2H per batch
         return dict(feat=feat[:m], coords=coords[:m], num_points=num_points[:m],
-                    num_voxels=num_voxels, row_base=row_base,
+                    num_voxels=num_voxels, row_base=row_base, voxel_cap=self.max_voxels,
                     voxels=None if voxels is None else voxels[:m])
 
 

@@ -86,7 +86,7 @@ SIGNATURES = {
     "al3d_sp_conv_rng_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int,
                                        c_p, c_int, c_int, c_p]),
     "al3d_sp_raster_perm_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
-    "al3d_sp_raster_perm": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p]),
+    "al3d_sp_raster_perm": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p]),
     "al3d_sp_rows_gather_pad_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p, c_p]),
     "al3d_sp_tile_items_workspace_bytes": (c_i64, [c_int]),
     "al3d_sp_tile_items": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p]),

@@ -223,7 +223,7 @@ class _SparseEncoderBase(nn.Module):
     def _out_shape(shape, k, s, p):
         return [(shape[d] + 2 * p[d] - (k[d] - 1) - 1) // s[d] + 1 for d in range(3)]
 
-    def build_rulebook(self, coords, batch_size, spatial_shape):
+    def build_rulebook(self, coords, batch_size, spatial_shape, frame_rows_max=0):
         """All index work of one batch.  It depends on the voxel coordinates only -- level grids,
         output sites of the strided convs (one small D2H each), every layer's tap-major table -- so
         the sweep can run it for batch i+1 on a side stream while batch i is being convolved.
@@ -241,7 +241,8 @@ class _SparseEncoderBase(nn.Module):
             # the input level's rows renumbered in raster order (b, z, y, x): the order of a level's rows is free inside
             # the encoder (example["coordinates"] keeps the reference's first-appearance order), and raster order makes
             # the neighbour sets of consecutive rows contiguous index ranges (csrc/spconv_l0.hip)
-            perm, coords = D.raster_perm(coords, batch_size, shape)
+            # (frame_rows_max > 0: the caller promises frame-sorted rows with at most that many rows per frame)
+            perm, coords = D.raster_perm(coords, batch_size, shape, frame_rows_max)
         lv = self._level(shape, batch_size, dev)
         lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W, _ptr(lv.grid),
                  1, st)
@@ -407,14 +408,14 @@ class FPNSpMiddleResNetFHD(_SparseEncoderBase):
     def _stages(self):
         return [self.middle_conv0, self.middle_conv1, self.middle_conv2, self.middle_conv3]
 
-    def rulebook_for(self, coors, batch_size, input_shape):
-        return self.build_rulebook(coors, batch_size, np.array(input_shape[::-1]) + [1, 0, 0])
+    def rulebook_for(self, coors, batch_size, input_shape, frame_rows_max=0):
+        return self.build_rulebook(coors, batch_size, np.array(input_shape[::-1]) + [1, 0, 0], frame_rows_max)
 
-    def forward(self, voxel_features, coors, batch_size, input_shape, book=None):
+    def forward(self, voxel_features, coors, batch_size, input_shape, book=None, frame_rows_max=0):
         """-> (dense NHWC [B,128,128,256], middle list of 4 SparseTensor) -- the reference
         returns NCHW (scn.py:371-392); this build keeps activations channels-last."""
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
         if book is None:
-            book = self.build_rulebook(coors, batch_size, sparse_shape)
+            book = self.build_rulebook(coors, batch_size, sparse_shape, frame_rows_max)
         final, middle = self._run(voxel_features, coors, batch_size, sparse_shape, book=book)
         return self.dense_nhwc(final, out=book.pop("dense", None)), middle

@@ -72,7 +72,8 @@ class FPNVoxelNet(SingleStageDetector):
             input_features = data["mean_features"]
         else:
             input_features = self.reader(data["features"], data["num_voxels"])
-        x, middle = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+        x, middle = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"],
+                                  **self._cap_kw(data.get("voxel_cap", 0)))
         if self.with_neck:
             x = self.neck(x)
             middle.append(NHWCFeature(x, getattr(self.neck, "embedding", None)))
@@ -81,26 +82,35 @@ class FPNVoxelNet(SingleStageDetector):
     # The forward pass is exposed in two halves so that the sweep can run the sparse half of batch
     # i+1 (voxel features -> sparse encoder -> dense BEV; latency-bound gathers) on one HIP stream
     # while the dense half of batch i (neck + head + decode; matrix-core bound) runs on another.
+    def _cap_kw(self, cap):
+        """``voxel_cap`` of a device-voxelized example (frames concatenated in order, at most that many rows each) as the
+        sparse encoder's ``frame_rows_max`` promise, for encoders that take it."""
+        import inspect
+        if cap and "frame_rows_max" in inspect.signature(self.backbone.forward).parameters:
+            return {"frame_rows_max": int(cap)}
+        return {}
+
     def prepare(self, example):
         """Index work of a batch (sparse-conv rulebook); needs ``coordinates`` only, so the sweep runs
         it one batch ahead on a side stream.  Pass the result as ``book=`` to forward / sparse_stage."""
         if not hasattr(self.backbone, "rulebook_for"):
             return None
         return self.backbone.rulebook_for(example["coordinates"], len(example["num_voxels"]),
-                                          example["shape"][0])
+                                          example["shape"][0], **self._cap_kw(example.get("voxel_cap", 0)))
 
     def sparse_stage(self, example, book=None):
         num_voxels = example["num_voxels"]
         data = dict(features=example.get("voxels"), num_voxels=example.get("num_points"),
                     mean_features=example.get("voxel_features"), coors=example["coordinates"],
-                    batch_size=len(num_voxels), input_shape=example["shape"][0])
+                    batch_size=len(num_voxels), input_shape=example["shape"][0], voxel_cap=example.get("voxel_cap", 0))
         if data.get("mean_features") is not None:     # device voxelizer already reduced the points
             input_features = data["mean_features"]
         else:
             input_features = self.reader(data["features"], data["num_voxels"])
         if book is not None:
             return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"], book=book)
-        return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+        return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"],
+                             **self._cap_kw(data["voxel_cap"]))
 
     def dense_stage(self, example, x, middle, finetune=False, **kwargs):
         pair = False

@@ -333,7 +333,9 @@ int al3d_sp_conv_rng_f16x3(const float* fin, const int* nbr, int nbr_pitch, cons
  * level is free, so the encoder renumbers level 0 in raster order (b, z, y, x):
  *   al3d_sp_raster_perm: coords [n][4] (b, z, y, x; unique cells; W <= 2048) -> perm [n] (raster position ->
  *     original row) and coords_raster [n][4]; a counting sort over the (b, z, y) lines + a bit-mask rank inside each
- *     line.  workspace >= al3d_sp_raster_perm_workspace_bytes(n, B, D, H).
+ *     line.  workspace >= al3d_sp_raster_perm_workspace_bytes(n, B, D, H).  frame_rows_max > 0 promises frame-sorted
+ *     rows (coords[:, 0] ascending) with at most that many rows per frame: up to 65,535 rows, D H <= 43,008 lines and
+ *     W <= 1024 the whole sort then runs in LDS, one workgroup per frame; 0: no promise, the general path.
  *   al3d_sp_rows_gather_pad_f32: out[r] = rows[perm[r]] (perm NULL: identity) zero-padded from channels_in to
  *     channels_out (% 8 == 0) channels, as f32 rows or pair rows.
  * In raster order the neighbours of 32 consecutive output rows under the three kx taps of a (kz, ky) group lie in one
@@ -349,8 +351,8 @@ int al3d_sp_conv_rng_f16x3(const float* fin, const int* nbr, int nbr_pitch, cons
  *     f16x3 arithmetic in al3d_sp_conv_wave2_f16x3's summation order: BIT-IDENTICAL to it.  residual only at Cout 16;
  *     io as below; tiles_per_wave <= 0: default. */
 int64_t al3d_sp_raster_perm_workspace_bytes(int n, int B, int D, int H);
-int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H, int W, void* workspace, int* perm,
-                        int* coords_raster, void* stream);
+int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H, int W, int frame_rows_max, void* workspace,
+                        int* perm, int* coords_raster, void* stream);
 int al3d_sp_rows_gather_pad_f32(const float* rows, const int* perm, int64_t n, int channels_in, int channels_out,
                                 int to_pair, float* out, void* stream);
 int64_t al3d_sp_tile_items_workspace_bytes(int n_out);

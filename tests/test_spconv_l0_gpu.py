@@ -57,6 +57,43 @@ def test_raster_perm_equals_a_stable_sort(case):
     assert np.array_equal(cr.cpu().numpy(), coords[want])
 
 
+@pytest.mark.parametrize("case", ["frames", "one_frame_full_lines", "empty_frames", "cap_hit"])
+def test_raster_perm_frame_sorted_fast_path(case):
+    """Frame-sorted rows with a promised per-frame cap (the voxelizer's output): one workgroup per frame sorts in LDS
+    (16-bit packed line counters, LDS scan, bit-mask rank over chunks of 512 lines).  Same contract: == the stable sort.
+    Cases: several frames of different sizes; lines with hundreds of members crossing chunk borders; frames without a row
+    in between; a frame at the 65,535-row limit."""
+    from al3d import detector_ops as D
+    rng = np.random.default_rng(len(case) + 7)
+    shape = [41, 96, 1024]
+    if case == "frames":
+        counts = [5001, 1, 12000, 333, 0, 7000]
+    elif case == "one_frame_full_lines":
+        shape = [3, 700, 1024]                                          # 2,100 lines: several chunks, dense lines
+        counts = [60000]
+    elif case == "empty_frames":
+        counts = [0, 0, 4000, 0, 2500, 0]
+    else:
+        counts = [65535, 100]
+    rows = []
+    for b, c in enumerate(counts):
+        cells = rng.choice(shape[0] * shape[1] * shape[2], size=c, replace=False)
+        if case == "one_frame_full_lines":                                  # most rows in a few hundred completely filled lines
+            cells = np.concatenate([np.arange(58 * 1024) + 1024 * 600, rng.choice(1024 * 600, size=c - 58 * 1024, replace=False)])
+            cells = rng.permutation(cells)
+        x, y, z = cells % shape[2], (cells // shape[2]) % shape[1], cells // (shape[2] * shape[1])
+        rows.append(np.stack([np.full_like(x, b), z, y, x], 1))
+    coords = np.concatenate(rows).astype(np.int32)
+    batch = len(counts)
+    perm, cr = D.raster_perm(_t(coords), batch, shape, frame_rows_max=max(counts))
+    torch.cuda.synchronize()
+    want = np.argsort(_raster_key(coords, shape), kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), want.astype(np.int32))
+    assert np.array_equal(cr.cpu().numpy(), coords[want])
+    slow_perm, slow_cr = D.raster_perm(_t(coords), batch, shape)            # the general path gives the same answer
+    assert torch.equal(slow_perm, perm) and torch.equal(slow_cr, cr)
+
+
 def test_rows_gather_pad():
     """out[r] = rows[perm[r]] zero-padded (5 -> 16 channels), as f32 rows and as pair rows (== rows_convert of the f32 form);
     perm = None is the identity."""

@@ -47,7 +47,7 @@ for tag, l0, couts, rows in modes:
             times.clear(); names.clear()
             b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             b0.record()
-            book = enc.rulebook_for(ex["coordinates"], bs, ex["shape"][0])
+            book = enc.rulebook_for(ex["coordinates"], bs, ex["shape"][0], frame_rows_max=ex.get("voxel_cap", 0))
             b1.record()
             dense, _ = enc(ex["voxel_features"], ex["coordinates"], bs, ex["shape"][0], book=book)
             torch.cuda.synchronize()
