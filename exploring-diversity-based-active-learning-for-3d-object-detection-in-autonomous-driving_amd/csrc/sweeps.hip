@@ -123,7 +123,7 @@ __global__ void sweep_emit_batch_kernel(const float* __restrict__ raw, const int
                                         const unsigned char* __restrict__ has_xform,
                                         const double* __restrict__ time_lag, const unsigned char* __restrict__ is_key,
                                         const int* __restrict__ flags, const int* __restrict__ pos,
-                                        float* __restrict__ out)
+                                        float* __restrict__ out, int rule)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total || !flags[i]) return;
@@ -134,10 +134,20 @@ __global__ void sweep_emit_batch_kernel(const float* __restrict__ raw, const int
     if (!key && has_xform[f]) {
         const double* t = xform + 12 * f;
         const double xd = x, yd = y, zd = z;
-        const float nx = (float)(((t[0] * xd + t[1] * yd) + t[2] * zd) + t[3]);
-        const float ny = (float)(((t[4] * xd + t[5] * yd) + t[6] * zd) + t[7]);
-        const float nz = (float)(((t[8] * xd + t[9] * yd) + t[10] * zd) + t[11]);
-        x = nx; y = ny; z = nz;
+        if (rule == 0) {
+            const float nx = (float)(((t[0] * xd + t[1] * yd) + t[2] * zd) + t[3]);
+            const float ny = (float)(((t[4] * xd + t[5] * yd) + t[6] * zd) + t[7]);
+            const float nz = (float)(((t[8] * xd + t[9] * yd) + t[10] * zd) + t[11]);
+            x = nx; y = ny; z = nz;
+        } else {
+            // BEVFusion (bevfusion/mmdet3d/datasets/pipelines/loading.py:222-226): `p[:, :3] = p[:, :3] @ R.T` stores the
+            // float64 product back into the float32 array, then `p[:, :3] += t` adds the float64 translation to the
+            // ROUNDED value and rounds again
+            const float rx = (float)((t[0] * xd + t[1] * yd) + t[2] * zd);
+            const float ry = (float)((t[4] * xd + t[5] * yd) + t[6] * zd);
+            const float rz = (float)((t[8] * xd + t[9] * yd) + t[10] * zd);
+            x = (float)((double)rx + t[3]); y = (float)((double)ry + t[7]); z = (float)((double)rz + t[11]);
+        }
     }
     float* o = out + 5 * (int64_t)pos[i];
     o[0] = x; o[1] = y; o[2] = z; o[3] = w;
@@ -155,12 +165,32 @@ __global__ void sweep_frame_off_kernel(const int64_t* __restrict__ off, const in
     out_frame_off[b] = r < total ? (int64_t)pos[r] : end;
 }
 
+extern "C" int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                                                const double* xform, const unsigned char* has_xform,
+                                                const double* time_lag, const unsigned char* is_key,
+                                                const int* frame_first_file, int n_frames, float min_distance, int rule,
+                                                float* out, int64_t* out_frame_off, void* workspace, void* stream);
+
 extern "C" int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
                                            const double* xform, const unsigned char* has_xform,
                                            const double* time_lag, const unsigned char* is_key,
                                            const int* frame_first_file, int n_frames, float min_distance,
                                            float* out, int64_t* out_frame_off, void* workspace, void* stream)
 {
+    return al3d_merge_sweeps_batch_rule_f32(raw, file_off, nfiles, total_rows, xform, has_xform, time_lag, is_key,
+                                            frame_first_file, n_frames, min_distance, 0, out, out_frame_off, workspace, stream);
+}
+
+// rule 0: det3d's loader (one float64 4x4 product, rounded once); rule 1: BEVFusion's LoadPointsFromMultiSweeps (float64
+// rotation rounded to float32, then the float64 translation added and rounded again); is_key files: no remove_close, time 0
+// (BEVFusion's padded key-frame copies of an empty sweep list are ordinary files with has_xform 0 and time lag 0)
+extern "C" int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                                                const double* xform, const unsigned char* has_xform,
+                                                const double* time_lag, const unsigned char* is_key,
+                                                const int* frame_first_file, int n_frames, float min_distance, int rule,
+                                                float* out, int64_t* out_frame_off, void* workspace, void* stream)
+{
+    AL3D_REQUIRE(rule == 0 || rule == 1, "al3d_merge_sweeps_batch_rule_f32: rule 0 (det3d) or 1 (BEVFusion)");
     AL3D_REQUIRE(nfiles >= 1 && n_frames >= 1 && total_rows >= 0 && total_rows < (1LL << 31),
                  "al3d_merge_sweeps_batch_f32: bad sizes");
     AL3D_REQUIRE(out_frame_off, "al3d_merge_sweeps_batch_f32: null out_frame_off");
@@ -181,7 +211,7 @@ extern "C" int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file
     int rc = al3d_exclusive_scan_i32(flags, pos, total_rows, scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(sweep_emit_batch_kernel, dim3(blocks), dim3(256), 0, s, raw, file_off, nfiles, total_rows,
-                       xform, has_xform, time_lag, is_key, flags, pos, out);
+                       xform, has_xform, time_lag, is_key, flags, pos, out, rule);
     hipLaunchKernelGGL(sweep_frame_off_kernel, dim3((unsigned)al3d_cdiv(n_frames + 1, 256)), dim3(256), 0, s, file_off,
                        frame_first_file, n_frames, total_rows, flags, pos, out_frame_off);
     AL3D_CHECK_LAUNCH("merge_sweeps_batch");

@@ -168,11 +168,13 @@ __global__ void vox_assign_kernel(const int64_t* __restrict__ off, int B, VoxCfg
 
 // pass 5: bucket the point indices per voxel at the arrival positions pass 4's counter handed out (arrival
 // order is irrelevant: pass 6 sorts) -- no second round of atomics
-__global__ void vox_bucket_kernel(int64_t npts, const int* __restrict__ prow, const int* __restrict__ ppos,
-                                  const int* __restrict__ boff, int* __restrict__ bucket)
+__global__ void vox_bucket_kernel(const int64_t* __restrict__ off, int B, const int* __restrict__ prow,
+                                  const int* __restrict__ ppos, const int* __restrict__ boff, int* __restrict__ bucket)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npts) return;
+    // the point list ends at off[B]: `points` may hold more rows than that (a loader's compaction leaves an unused tail),
+    // and passes 1-4 never wrote the per-point arrays beyond it
+    if (i >= off[B]) return;
     const int row = prow[i];
     if (row < 0) return;
     bucket[boff[row] + ppos[i]] = (int)i;
@@ -270,11 +272,11 @@ __global__ void vox_gather_kernel(const float* __restrict__ pts, VoxCfg c, int r
 
 // pass 7: put the touched cells of the first-index grid back to EMPTY
 // one write per occupied cell: its leader restores it (every point of the cell used to)
-__global__ void vox_restore_kernel(int64_t npts, int64_t cells, const int* __restrict__ pframe,
+__global__ void vox_restore_kernel(const int64_t* __restrict__ off, int B, int64_t cells, const int* __restrict__ pframe,
                                    const int* __restrict__ pcell, const int* __restrict__ flag, int* __restrict__ first)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npts) return;
+    if (i >= off[B]) return;                                 // (as vox_bucket_kernel: rows past off[B] were never classified)
     if (flag[i]) first[(int64_t)pframe[i] * cells + pcell[i]] = VX_EMPTY;
 }
 
@@ -359,14 +361,14 @@ extern "C" int al3d_voxelize_mean_f32(const float* points, const int64_t* point_
                        pframe, pcell, lscan, row_base, prow, ppos, coords, cnt);
     rc = al3d_exclusive_scan_i32(cnt, boff, rows + 1, scan_ws, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_bucket_kernel, dim3(pb), dim3(256), 0, s, npts, prow, ppos, boff, bucket);
+    hipLaunchKernelGGL(vox_bucket_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, prow, ppos, boff, bucket);
     if (c.max_points == 10 && c.nfeat == 5)      // the nuScenes configuration: register-resident selection
         hipLaunchKernelGGL((vox_gather_fixed_kernel<10, 5>), dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s,
                            points, (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);
     else
         hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)al3d_cdiv(rows, 128)), dim3(128), 0, s, points, c,
                            (int)rows, boff, cnt, bucket, row_base, B, voxels, num_points, feat);
-    hipLaunchKernelGGL(vox_restore_kernel, dim3(pb), dim3(256), 0, s, npts, cells, pframe, pcell, flag, first);
+    hipLaunchKernelGGL(vox_restore_kernel, dim3(pb), dim3(256), 0, s, point_offsets, B, cells, pframe, pcell, flag, first);
     AL3D_CHECK_LAUNCH("voxelize");
     return AL3D_OK;
 }

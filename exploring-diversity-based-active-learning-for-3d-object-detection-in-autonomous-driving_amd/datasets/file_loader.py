@@ -120,24 +120,33 @@ class FileSweepLoader:
         p = str(p)
         return p if self.root is None or os.path.isabs(p) else os.path.join(self.root, p)
 
+    # transform rule of al3d_merge_sweeps_batch_rule_f32: 0 = det3d's loader (one float64 4 x 4 product, rounded once)
+    rule = 0
+
+    def _frame_files(self, info):
+        """One frame's files in merge order: (paths, 3x4 / 4x4 float64 transforms or None, time lags, key-frame flags).
+        det3d infos (nusc_common.py:410-419): ``lidar_path``, ``sweeps[i]{lidar_path, transform_matrix, time_lag}``."""
+        assert self.nsweeps - 1 <= len(info["sweeps"]), \
+            f"nsweeps {self.nsweeps} should not greater than list length {len(info['sweeps'])}."
+        paths, xforms, lags, keys = [self._path(info["lidar_path"])], [None], [0.0], [1]
+        for k in range(self.nsweeps - 1):
+            sw = info["sweeps"][k]
+            paths.append(self._path(sw["lidar_path"]))
+            xforms.append(sw.get("transform_matrix"))
+            lags.append(float(sw["time_lag"]))
+            keys.append(0)
+        return paths, xforms, lags, keys
+
     def _start(self, b):
         """Plan batch b, lay out its staging buffer, start the reads (returns immediately)."""
         ids = self.indices[b * self.batch_size:(b + 1) * self.batch_size]
         paths, xforms, lags, keys, first = [], [], [], [], [0]
         for i in ids:
-            info = self.infos[i]
-            assert self.nsweeps - 1 <= len(info["sweeps"]), \
-                f"nsweeps {self.nsweeps} should not greater than list length {len(info['sweeps'])}."
-            paths.append(self._path(info["lidar_path"]))
-            xforms.append(None)
-            lags.append(0.0)
-            keys.append(1)
-            for k in range(self.nsweeps - 1):
-                sw = info["sweeps"][k]
-                paths.append(self._path(sw["lidar_path"]))
-                xforms.append(sw.get("transform_matrix"))
-                lags.append(float(sw["time_lag"]))
-                keys.append(0)
+            p_, x_, l_, k_ = self._frame_files(self.infos[i])
+            paths += p_
+            xforms += x_
+            lags += l_
+            keys += k_
             first.append(len(paths))
         rows = self.reader.plan(paths)
         st = _Staged()
@@ -196,8 +205,8 @@ class FileSweepLoader:
         frame_off = torch.empty((st.B + 1,), dtype=torch.int64, device=dev)
         ws = torch.empty(lib.load().al3d_merge_sweeps_workspace_bytes(st.total), dtype=torch.uint8, device=dev)
         base = buf.data_ptr()
-        lib.call("al3d_merge_sweeps_batch_f32", base, base + st.o_off, st.nf, st.total, base + st.o_xf, base + st.o_has,
-                 base + st.o_tl, base + st.o_key, base + st.o_ff, st.B, self.min_distance, out.data_ptr(),
+        lib.call("al3d_merge_sweeps_batch_rule_f32", base, base + st.o_off, st.nf, st.total, base + st.o_xf, base + st.o_has,
+                 base + st.o_tl, base + st.o_key, base + st.o_ff, st.B, self.min_distance, int(self.rule), out.data_ptr(),
                  frame_off.data_ptr(), ws.data_ptr(), stream.cuda_stream)
         v = self.voxelizer(out, frame_off)
         gs = self.voxelizer.grid_size

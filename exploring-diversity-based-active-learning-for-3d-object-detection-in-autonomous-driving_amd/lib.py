@@ -152,6 +152,13 @@ SIGNATURES = {
     "al3d_reader_wait": (c_int, [c_p, c_int]),
     "al3d_merge_sweeps_batch_f32": (c_int, [c_p, c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_p, c_int, ctypes.c_float,
                                             c_p, c_p, c_p, c_p]),
+    "al3d_merge_sweeps_batch_rule_f32": (c_int, [c_p, c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_p, c_int, ctypes.c_float,
+                                                 c_int, c_p, c_p, c_p, c_p]),
+    "al3d_image_resample_ksize": (c_int, [c_int, c_int, c_int]),
+    "al3d_image_resample_coeffs": (c_int, [c_int, c_int, c_int, c_p, c_p]),
+    "al3d_image_aug_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "al3d_image_aug_normalize_u8": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p,
+                                            c_int, c_p, c_p, c_int, c_p, c_p, c_int, c_int, c_p, c_p, c_p, c_p]),
     "al3d_gap_parts_count": (c_int, [c_int, c_int, c_int]),
     "al3d_conv2d_nhwc_f16x3_gap": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 11 + [c_p, c_int, c_p]),
     "al3d_deconv2x2_nhwc_f16x3_gap": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p, c_int, c_p]),

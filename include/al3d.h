@@ -585,6 +585,38 @@ int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int n
                                 const unsigned char* is_key, const int* frame_first_file, int n_frames,
                                 float min_distance, float* out, int64_t* out_frame_off, void* workspace,
                                 void* stream);
+/* The same with the transform rule as a parameter: 0 = det3d's loader (above); 1 = BEVFusion's LoadPointsFromMultiSweeps
+ * (bevfusion/mmdet3d/datasets/pipelines/loading.py:84-237): `p[:, :3] = p[:, :3] @ R.T` rounds the float64 rotation to
+ * float32, `p[:, :3] += t` adds the float64 translation to the rounded value and rounds again (xform rows = [R | t]);
+ * time column = float32(ts - sweep_ts) (time_lag); key frame unfiltered with time 0; the key-frame copies the reference
+ * appends for an EMPTY sweep list (pad_empty_sweeps) are ordinary files with has_xform 0 and time lag 0. */
+int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                                     const double* xform, const unsigned char* has_xform, const double* time_lag,
+                                     const unsigned char* is_key, const int* frame_first_file, int n_frames,
+                                     float min_distance, int rule, float* out, int64_t* out_frame_off, void* workspace,
+                                     void* stream);
+
+/* Camera images of a BEVFusion sample (csrc/images.hip): the test branch of the reference's image pipeline --
+ * LoadMultiViewImageFromFiles (loading.py:19-83; decoding stays on the host), ImageAug3D (transforms_3d.py:26-122:
+ * img.resize(resize_dims) = PIL's BICUBIC convolution resize on 8-bit pixels, Pillow pinned at 8.4.0 by
+ * bevfusion/README.md:71; img.crop(crop); no flip, rotate(0)), ImageNormalize (transforms_3d.py:903-920: ToTensor +
+ * Normalize in float32).
+ *   al3d_image_resample_ksize / _coeffs (HOST functions): PIL's per-coordinate filter windows, bounds [out][2] = (first
+ *     source index, taps) and 22-bit fixed-point weights [out][ksize]; filter 2 = bilinear, 3 = bicubic.
+ *   al3d_image_aug_normalize_u8: imgs [nimg][H][W][3] u8 RGB (device) -> out [nimg][fH][fW][3] f32 channels-last =
+ *     ((resize to (rH, rW))[crop_y : crop_y + fH, crop_x : crop_x + fW] / 255 - mean) / std, and / or out_u8 = the 8-bit
+ *     crop (either may be NULL).  mean3 / std3 are HOST pointers.  row_first / row_count: the source rows the crop's
+ *     vertical windows cover (v_bounds[crop_y] .. v_bounds[crop_y + fH - 1] + taps); workspace >=
+ *     al3d_image_aug_workspace_bytes(nimg, row_count, fW).  Bit-identical to PIL's resize + crop and to the torch float32
+ *     expression. */
+int al3d_image_resample_ksize(int in_size, int out_size, int filter);
+int al3d_image_resample_coeffs(int in_size, int out_size, int filter, int* bounds, int* coeffs);
+int64_t al3d_image_aug_workspace_bytes(int nimg, int rows, int out_w);
+int al3d_image_aug_normalize_u8(const unsigned char* imgs, int nimg, int H, int W, int rH, int rW, int crop_x, int crop_y,
+                                int fH, int fW, const int* h_bounds, const int* h_coeffs, int h_ksize, const int* v_bounds,
+                                const int* v_coeffs, int v_ksize, const float* mean3, const float* std3, int row_first,
+                                int row_count, void* workspace, float* out, unsigned char* out_u8, void* stream);
+
 
 /* 3x3 / stride 1 / pad 1 as Winograd F(2x2, 3x3) in f16x3 arithmetic (det3d/models/necks/rpn.py:66-113: the eleven
  * stride-1 3x3 layers of the SECOND neck): 2.25 x fewer matrix-core products than the direct kernels above, the input

@@ -109,3 +109,24 @@ def test_hip_voxelizer_runs_of_identical_cells(oracle):
         assert np.array_equal(out["feat"][sl].view(np.int32), f.view(np.int32))
         row += m
     assert row == len(out["coords"]) and out["num_points"].max() == 10
+
+
+def test_points_tensor_longer_than_the_offsets():
+    """A loader's compaction may leave unused rows behind the last frame (``points`` longer than ``point_offsets[-1]``): the
+    rows past the end are not part of any frame -- same voxels as the truncated tensor, and the first-index grid is left
+    clean (round 4: two passes used to walk the whole tensor and read per-point arrays nobody had written)."""
+    import torch
+    from al3d.detector_ops import Voxelizer
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.uniform(-50, 50, (30000, 2)), rng.uniform(-4, 2, (30000, 1)), rng.uniform(0, 1, (30000, 2))], 1).astype(np.float32)
+    tail = rng.uniform(-50, 50, (7000, 5)).astype(np.float32)
+    vox = Voxelizer([-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.1, 0.1, 0.2], 10, 60000, max_batch=2, device="cuda:0")
+    off = torch.tensor([0, 12000, 30000], dtype=torch.int64, device="cuda:0")
+    a = vox(torch.from_numpy(pts).cuda(), off)
+    for _ in range(3):                                                   # repeated calls: the grid must come back clean
+        junk = torch.randint(-2**31, 2**31 - 1, (4_000_000,), dtype=torch.int64, device="cuda:0")   # dirty the allocator's blocks
+        del junk
+        b = vox(torch.from_numpy(np.concatenate([pts, tail])).cuda(), off)
+        torch.cuda.synchronize()
+        for k in ("feat", "coords", "num_points", "num_voxels"):
+            assert torch.equal(a[k], b[k]), k

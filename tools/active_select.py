@@ -9,7 +9,8 @@ Seeds (3407), the empty-buffer bootstrap, ``build_detector`` / ``build_selector`
 detector is only built when the selector sweeps (``--pred``) -- the reference builds it and calls
 ``.cuda()`` even for metadata-only selectors; the pool is staged in HBM
 (``--synthetic-scenes`` generates one, otherwise ``cfg.selector.infos_origin`` + ``cfg.data_root``
-are read with the reference's loading rules); under torch.distributed every rank sweeps a
+are read with the reference's loading rules: det3d infos for the CBGS / lidar-only models, mmdet3d-format infos with
+``cams`` for the BEVFusion camera+lidar detector); under torch.distributed every rank sweeps a
 contiguous shard and the embeddings are all-gathered.
 """
 import argparse
@@ -131,8 +132,17 @@ def main():
                                             image_size=tuple(cam.get("image_size", (256, 704))),
                                             num_cameras=int(cam.get("num_cameras", 6)))
         elif cfg.model.get("type") == "BEVFusion":
-            raise SystemExit("BEVFusion camera+lidar pools need decoded camera images: only --synthetic-scenes is wired "
-                             "(hand CameraLidarSweepLoader your own `images` / `calib` tensors from Python)")
+            # camera+lidar from an mmdet3d-format pool (configs[4]): key frame + sweeps through the native reader and the
+            # BEVFusion merge rule, six camera frames per sample decoded on host threads and resized / cropped / normalised
+            # on the device (the reference's LoadMultiViewImageFromFiles / LoadPointsFromMultiSweeps / ImageAug3D /
+            # ImageNormalize test pipeline)
+            from al3d.datasets import CameraLidarFileLoader
+            cam = cfg.get("camera", {})
+            loader = CameraLidarFileLoader([infos[i] for i in mine], cfg.voxel_generator, anchors, batch_size=args.batch,
+                                           device=dev, sweeps_num=int(cam.get("sweeps_num", 9)), root=cfg.data_root,
+                                           threads=int(os.environ.get("AL3D_READER_THREADS", "8")),
+                                           image_size=tuple(cam.get("image_size", (256, 704))),
+                                           resize_lim=tuple(cam.get("resize_test", (0.48, 0.48))))
         elif args.synthetic_scenes:
             pool = PoolFrames.from_synthetic(len(mine), dev, seed=1000 + rank)
             loader = DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=args.batch, device=dev)
