@@ -279,16 +279,16 @@ class GeneralizedLSSFPN(nn.Module):
         used = len(laterals) - 1
         for i in range(used - 1, -1, -1):
             lat, src = laterals[i].contiguous(), laterals[i + 1].contiguous()
-            if lat.is_cuda and lat.shape[-1] % 4 == 0 and src.shape[-1] % 4 == 0:
-                # upsample + concatenation as one kernel writing the channels-last concat map (al3d_lss_upsample_cat_f32)
-                x = torch.empty((*lat.shape[:3], lat.shape[-1] + src.shape[-1]), dtype=torch.float32, device=lat.device)
-                lib.call("al3d_lss_upsample_cat_f32", _ptr(_dev(lat, torch.float32, "lateral")), _ptr(_dev(src, torch.float32, "coarser level")),
-                         lat.shape[0], lat.shape[1], lat.shape[2], lat.shape[3], src.shape[1], src.shape[2], src.shape[3],
-                         _ptr(x), _stream())
-            else:
-                up = torch.nn.functional.interpolate(src.permute(0, 3, 1, 2), size=lat.shape[1:3], mode="bilinear",
-                                                     align_corners=True).permute(0, 2, 3, 1)
-                x = torch.cat([lat, up], dim=-1).contiguous()
+            # upsample + concatenation as one kernel writing the channels-last concat map (al3d_lss_upsample_cat_f32): the
+            # only backend -- a level whose channel count the kernel's float4 lanes cannot serve is an error, not a detour
+            # through library ops
+            if lat.shape[-1] % 4 or src.shape[-1] % 4:
+                raise lib.Al3dError(f"GeneralizedLSSFPN: level channel counts {lat.shape[-1]} / {src.shape[-1]} must be "
+                                    "multiples of 4 (al3d_lss_upsample_cat_f32)")
+            x = torch.empty((*lat.shape[:3], lat.shape[-1] + src.shape[-1]), dtype=torch.float32, device=lat.device)
+            lib.call("al3d_lss_upsample_cat_f32", _ptr(_dev(lat, torch.float32, "lateral")), _ptr(_dev(src, torch.float32, "coarser level")),
+                     lat.shape[0], lat.shape[1], lat.shape[2], lat.shape[3], src.shape[1], src.shape[2], src.shape[3],
+                     _ptr(x), _stream())
             laterals[i] = self.fpn_convs[i](self.lateral_convs[i](x))
         return tuple(laterals[i] for i in range(used))
 

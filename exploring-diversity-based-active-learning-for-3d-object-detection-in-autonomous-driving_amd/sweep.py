@@ -211,51 +211,55 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                 nms_head = None
             if nms_head is not None:
                 nms_head.defer_nms = True
-            while True:
-                if pending is not None:
-                  with torch.cuda.stream(main):
-                    example, ahead, ev = pending
-                    main.wait_event(ev)
-                    if mode == "ahead" and SIDE_AFTER_SPARSE and hasattr(detector, "dense_stage"):
-                        # the next batch's index work (random grid traffic) is released only once this batch's
-                        # sparse convolutions -- the gather-bound kernels it would slow down -- are through: it
-                        # then runs beside the matrix-core-bound neck, which does not notice it
-                        x, middle = detector.sparse_stage(example, book=ahead)
-                        sparse_done = torch.cuda.Event()
-                        sparse_done.record(main)
-                        side.wait_event(sparse_done)
-                        if nms_head is not None:        # the previous batch's decode + NMS: beside this batch's neck too
-                            nms_head.flush_deferred(sparse_done)
-                        preds, middle = detector.dense_stage(example, x, middle, estimate=True)
-                    elif mode == "ahead":
-                        preds, middle = detector(example, return_loss=False, estimate=True, book=ahead)
-                    else:
-                        x, middle = ahead
-                        preds, middle = detector.dense_stage(example, x, middle, estimate=True)
-                    finish(example, preds, middle)
-                    pending = None
-                    e = torch.cuda.Event()
-                    e.record(main)
-                    done.append(e)
-                # bound the run-ahead: the side stream is ~10x faster than the main one and would
-                # otherwise prepare (and keep alive) every remaining batch of the pool at once
-                while len(done) > 1:
-                    done.pop(0).synchronize()
-                with torch.cuda.stream(side):
-                    try:
-                        data_batch = next(it)
-                    except StopIteration:
-                        break
-                    example = example_to_device(data_batch, device, non_blocking=False)
-                    ahead = detector.prepare(example) if mode == "ahead" else detector.sparse_stage(example)
-                    for t in _tensors_of((example, ahead)):
-                        t.record_stream(main)   # produced on the side stream, consumed on the main one
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                pending = (example, ahead, ev)
-            if nms_head is not None:            # the last batch's launch; later predict() calls launch at once again
-                nms_head.defer_nms = False
-                nms_head.flush_deferred()
+            try:
+              while True:
+                  if pending is not None:
+                    with torch.cuda.stream(main):
+                      example, ahead, ev = pending
+                      main.wait_event(ev)
+                      if mode == "ahead" and SIDE_AFTER_SPARSE and hasattr(detector, "dense_stage"):
+                          # the next batch's index work (random grid traffic) is released only once this batch's
+                          # sparse convolutions -- the gather-bound kernels it would slow down -- are through: it
+                          # then runs beside the matrix-core-bound neck, which does not notice it
+                          x, middle = detector.sparse_stage(example, book=ahead)
+                          sparse_done = torch.cuda.Event()
+                          sparse_done.record(main)
+                          side.wait_event(sparse_done)
+                          if nms_head is not None:        # the previous batch's decode + NMS: beside this batch's neck too
+                              nms_head.flush_deferred(sparse_done)
+                          preds, middle = detector.dense_stage(example, x, middle, estimate=True)
+                      elif mode == "ahead":
+                          preds, middle = detector(example, return_loss=False, estimate=True, book=ahead)
+                      else:
+                          x, middle = ahead
+                          preds, middle = detector.dense_stage(example, x, middle, estimate=True)
+                      finish(example, preds, middle)
+                      pending = None
+                      e = torch.cuda.Event()
+                      e.record(main)
+                      done.append(e)
+                  # bound the run-ahead: the side stream is ~10x faster than the main one and would
+                  # otherwise prepare (and keep alive) every remaining batch of the pool at once
+                  while len(done) > 1:
+                      done.pop(0).synchronize()
+                  with torch.cuda.stream(side):
+                      try:
+                          data_batch = next(it)
+                      except StopIteration:
+                          break
+                      example = example_to_device(data_batch, device, non_blocking=False)
+                      ahead = detector.prepare(example) if mode == "ahead" else detector.sparse_stage(example)
+                      for t in _tensors_of((example, ahead)):
+                          t.record_stream(main)   # produced on the side stream, consumed on the main one
+                      ev = torch.cuda.Event()
+                      ev.record(side)
+                  pending = (example, ahead, ev)
+            finally:
+                # also on an exception inside the loop (loader error, range check, OOM): a head left deferring would hold
+                # every later predict()'s launch -- and its head output -- back for ever
+                if nms_head is not None:        # the last batch's launch; later predict() calls launch at once again
+                    nms_head.defer_nms = False
+                    nms_head.flush_deferred()
             main.wait_stream(side)
             if main is not caller:
                 caller.wait_stream(main)

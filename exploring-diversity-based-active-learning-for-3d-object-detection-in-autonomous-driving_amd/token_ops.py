@@ -120,7 +120,10 @@ def linear(a, packed, a_pair=False, act=None, residual=None, rowmap=None, out=No
         if residual is not None and rowmap is not None:
             out = residual                                   # scatter-add back into the residual stream, in place
         else:
-            out = torch.empty((M if out_rows is None else out_rows, packed.n), dtype=torch.float32, device=a.device)
+            # with a row map the kernel skips dropped rows (-1) and may leave rows of a larger ``out_rows`` untouched: those
+            # must read as zeros, not as whatever the allocator held
+            alloc = torch.zeros if rowmap is not None else torch.empty
+            out = alloc((M if out_rows is None else out_rows, packed.n), dtype=torch.float32, device=a.device)
     if residual is not None:
         residual = _dev(residual, torch.float32, "residual")
     lib.call("al3d_tok_linear_f16x3", _ptr(a), int(a_pair), _ptr(packed.image), _ptr(packed.scale), _ptr(packed.bias),
