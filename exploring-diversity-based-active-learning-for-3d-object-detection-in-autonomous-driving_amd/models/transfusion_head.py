@@ -20,7 +20,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import lib
 from .. import token_ops as T
+from ..selector_ops import _dev, _ptr, _stream
 from .bevfusion_camera import _ConvAffine
 from .registry import HEADS
 from .swin import _Packed
@@ -304,14 +306,11 @@ class TransFusionHead(nn.Module):
         key_rows = lidar_nhwc.reshape(B * H * W, -1)                          # token rows, h-major like the reference's .view
         dense_heatmap = dense_nhwc.permute(0, 3, 1, 2)                        # [B,num_classes,H,W]
         bev_pos = self._bev_pos_on(x.device)                                  # [H*W, 2] rows, shared by the samples
-        top_class, top_index, heatmap = self._proposals(dense_heatmap)
         P = self.num_proposals
-        flat_index = (top_index + torch.arange(B, device=x.device)[:, None] * (H * W)).reshape(-1)
+        # query initialisation as ONE device call (csrc/proposals.hip): local maxima, top-P, class / cell, the winners'
+        # masked scores, query positions and query features (token row + class-encoding column + bias)
+        top_class, top_index, qscore, query_feat, query_pos = self._proposals(dense_nhwc, key_rows, bev_pos)
         self.query_labels = top_class
-        # class encoding of a one-hot vector = one column of the Conv1d weight (+ bias)
-        ce = self.class_encoding
-        query_feat = key_rows[flat_index] + ce.weight[:, :, 0].t()[top_class.reshape(-1)] + ce.bias
-        query_pos = bev_pos[top_index.reshape(-1)]                            # [B*P, 2]
         ret_dicts = []
         for i in range(self.num_decoder_layers):
             query_feat = self.decoder[i](query_feat.contiguous(), key_rows, query_pos.contiguous(), bev_pos, B)
@@ -319,8 +318,7 @@ class TransFusionHead(nn.Module):
             res["center"] = res["center"] + query_pos.view(B, P, 2).permute(0, 2, 1)
             ret_dicts.append(res)
             query_pos = res["center"].detach().permute(0, 2, 1).reshape(B * P, 2)
-        ret_dicts[0]["query_heatmap_score"] = heatmap.gather(index=top_index[:, None, :].expand(-1, self.num_classes, -1),
-                                                             dim=-1)
+        ret_dicts[0]["query_heatmap_score"] = qscore                          # [B, num_classes, P]
         ret_dicts[0]["dense_heatmap"] = dense_heatmap
         if self.auxiliary is False:
             return [ret_dicts[-1]]
@@ -332,28 +330,31 @@ class TransFusionHead(nn.Module):
                 new_res[key] = ret_dicts[0][key]
         return [new_res]
 
-    def _proposals(self, dense_heatmap):
+    def _proposals(self, dense_nhwc, key_rows, bev_pos):
         """Query initialisation (transfusion.py:236-275): a cell proposes class c when its sigmoid score is the maximum
         of its k x k neighbourhood -- evaluated on the interior only: the k//2-wide frame never proposes -- except for
         the small-object classes (nuScenes pedestrian / traffic cone, Waymo pedestrian / cyclist), where every cell may;
-        the num_proposals best (class, cell) pairs over all classes win.  -> (class [B,P], cell [B,P], masked scores
-        [B,C,H*W])."""
-        score = dense_heatmap.detach().sigmoid()
-        B, C, H, W = score.shape
-        k = self.nms_kernel_size
-        r = k // 2
-        peak = torch.zeros_like(score, dtype=torch.bool)
-        if r > 0:
-            inner = score[:, :, r:H - r, r:W - r]
-            peak[:, :, r:H - r, r:W - r] = inner == F.max_pool2d(score, kernel_size=k, stride=1, padding=0)
-        else:
-            peak[:] = True
+        the num_proposals best (class, cell) pairs over all classes win (ties: the smaller flat index).
+        -> (class [B,P] i64, cell [B,P] i64, masked scores of the winning cells [B,C,P], query features [B*P, hidden],
+        query positions [B*P, 2]), all from ``al3d_tf_proposals_f32``."""
+        B, H, W, C = dense_nhwc.shape
+        P, dev = self.num_proposals, dense_nhwc.device
         free = {"nuScenes": (8, 9), "Waymo": (1, 2)}.get(self.test_cfg.get("dataset"), ())
-        for c in free:
-            peak[:, c] = True
-        masked = (score * peak).reshape(B, C, H * W)
-        order = masked.reshape(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]
-        return order // (H * W), order % (H * W), masked
+        mask = sum(1 << c for c in free if c < C)
+        ce = self.class_encoding
+        cols = ce.weight.detach()[:, :, 0].t().contiguous().float()
+        hidden = key_rows.shape[1]
+        top_class = torch.empty((B, P), dtype=torch.int64, device=dev)
+        top_cell = torch.empty((B, P), dtype=torch.int64, device=dev)
+        qscore = torch.empty((B, C, P), dtype=torch.float32, device=dev)
+        qfeat = torch.empty((B * P, hidden), dtype=torch.float32, device=dev)
+        qpos = torch.empty((B * P, 2), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(int(lib.load().al3d_tf_proposals_workspace_bytes(B, H, W, C)), 1), dtype=torch.uint8, device=dev)
+        lib.call("al3d_tf_proposals_f32", _ptr(_dev(dense_nhwc.detach(), torch.float32, "heat map")), B, H, W, C,
+                 int(self.nms_kernel_size), mask, P, _ptr(_dev(key_rows.detach(), torch.float32, "tokens")), hidden,
+                 _ptr(_dev(bev_pos, torch.float32, "bev_pos")), _ptr(cols), _ptr(ce.bias.detach().float().contiguous()), _ptr(ws),
+                 _ptr(top_class), _ptr(top_cell), _ptr(qscore), _ptr(qfeat), _ptr(qpos), _stream())
+        return top_class, top_cell, qscore, qfeat, qpos
 
     def predict(self, example, preds_dicts, test_cfg=None, **_unused):
         """The det3d head contract (``bbox_head.predict(example, preds, test_cfg)``, voxelnet.py:73-81) over

@@ -596,6 +596,19 @@ int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t* file_off, 
                                      float min_distance, int rule, float* out, int64_t* out_frame_off, void* workspace,
                                      void* stream);
 
+/* TransFusion query initialisation (csrc/proposals.hip; bevfusion/mmdet3d/models/heads/bbox/transfusion.py:236-275):
+ * heat_logits [B][H][W][C] channels-last (the heat-map head's output) -> the P best (class, cell) pairs among the k x k
+ * local maxima of sigmoid(heat) (interior cells only; classes of free_class_mask keep every cell), ties broken by the
+ * smaller flat index c * HW + cell (the reference's argsort leaves them unspecified), in descending score order:
+ * top_class / top_cell [B][P] int64, query_heatmap_score [B][C][P] (the masked scores of each winning cell),
+ * query_feat [B*P][hidden] = tokens[b * HW + cell] + class_cols[class] + class_bias (class_cols [C][hidden] = the
+ * class-encoding Conv1d's weight columns), query_pos [B*P][2] = bev_pos[cell].  P <= 256, C <= 32. */
+int64_t al3d_tf_proposals_workspace_bytes(int B, int H, int W, int C);
+int al3d_tf_proposals_f32(const float* heat_logits, int B, int H, int W, int C, int nms_kernel, unsigned free_class_mask,
+                          int P, const float* tokens, int hidden, const float* bev_pos, const float* class_cols,
+                          const float* class_bias, void* workspace, int64_t* top_class, int64_t* top_cell,
+                          float* query_heatmap_score, float* query_feat, float* query_pos, void* stream);
+
 /* Camera images of a BEVFusion sample (csrc/images.hip): the test branch of the reference's image pipeline --
  * LoadMultiViewImageFromFiles (loading.py:19-83; decoding stays on the host), ImageAug3D (transforms_3d.py:26-122:
  * img.resize(resize_dims) = PIL's BICUBIC convolution resize on 8-bit pixels, Pillow pinned at 8.4.0 by

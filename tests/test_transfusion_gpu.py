@@ -201,3 +201,72 @@ def test_mha16_kernel_matches_float64(B, Pq, Pk):
     got = T.mha16(q, k, v, B, Pq, Pk, heads, 0.25)
     e, e32 = float((got.double() - ref).abs().max()), float((ref32.double() - ref).abs().max())
     assert e <= 3.0 * e32 + 1e-6 and e <= 1e-5, (e, e32)
+
+
+@pytest.mark.parametrize("case", ["random", "ties", "k1", "waymo"])
+def test_proposal_kernel_against_the_reference_transcription(case):
+    """al3d_tf_proposals_f32 against transfusion.py:236-275 written with torch ops (sigmoid, max_pool2d on the interior, the
+    free classes, top-P of the masked scores): the same (class, cell) set in the same order wherever scores differ, ties
+    resolved towards the smaller flat index, masked scores / query positions / query features of the winners."""
+    import torch.nn.functional as F
+    from al3d import lib
+    from al3d.selector_ops import _ptr, _stream
+    g = torch.Generator().manual_seed(len(case))
+    B, H, W, C, P, hidden = 2, 23, 31, 10, 200, 16
+    logits = torch.randn(B, H, W, C, generator=g) * 2.0
+    k, free = 3, (8, 9)
+    if case == "ties":
+        logits = torch.round(logits * 2) / 2                          # many exactly equal scores, plateaus of equal maxima
+    elif case == "k1":
+        k = 1
+    elif case == "waymo":
+        C, free = 3, (1, 2)
+        logits = logits[..., :3].contiguous()
+    tokens = torch.randn(B * H * W, hidden, generator=g)
+    bev_pos = torch.rand(H * W, 2, generator=g) * 30
+    cols, bias = torch.randn(C, hidden, generator=g), torch.randn(hidden, generator=g)
+    dev = lambda t: t.to(DEV).contiguous()
+    out = dict(cls=torch.empty((B, P), dtype=torch.int64, device=DEV), cell=torch.empty((B, P), dtype=torch.int64, device=DEV),
+               score=torch.empty((B, C, P), device=DEV), feat=torch.empty((B * P, hidden), device=DEV),
+               pos=torch.empty((B * P, 2), device=DEV))
+    ws = torch.empty(int(lib.load().al3d_tf_proposals_workspace_bytes(B, H, W, C)), dtype=torch.uint8, device=DEV)
+    dl, dt, dp, dc, db = dev(logits), dev(tokens), dev(bev_pos), dev(cols), dev(bias)
+    lib.call("al3d_tf_proposals_f32", _ptr(dl), B, H, W, C, k, sum(1 << c for c in free), P, _ptr(dt), hidden, _ptr(dp), _ptr(dc),
+             _ptr(db), _ptr(ws), _ptr(out["cls"]), _ptr(out["cell"]), _ptr(out["score"]), _ptr(out["feat"]), _ptr(out["pos"]),
+             _stream())
+    torch.cuda.synchronize()
+    # the transcription (float32 on the device's own sigmoid values would differ in the last bit: compare via the kernel's
+    # masked scores where exactness matters, via torch's where a tolerance is stated)
+    score = logits.permute(0, 3, 1, 2).sigmoid()
+    r = k // 2
+    peak = torch.zeros_like(score, dtype=torch.bool)
+    if r > 0:
+        peak[:, :, r:H - r, r:W - r] = score[:, :, r:H - r, r:W - r] == F.max_pool2d(score, k, 1, 0)
+    else:
+        peak[:] = True
+    for c in free:
+        peak[:, c] = True
+    masked = (score * peak).reshape(B, C * H * W)
+    cls, cell, sc = out["cls"].cpu(), out["cell"].cpu(), out["score"].cpu()
+    flat = cls * (H * W) + cell
+    for b in range(B):
+        got = masked[b][flat[b]]
+        # (1) winners carry the P largest masked scores (as a multiset, to the sigmoid's last bits), in descending order
+        want = masked[b].sort(descending=True).values[:P]
+        assert torch.allclose(got, want, rtol=0, atol=2e-7), case
+        assert bool((got[:-1] >= got[1:] - 2e-7).all())
+        assert len(set(flat[b].tolist())) == P
+        # (2) equal scores: ascending flat index (checked on the kernel's own score values)
+        own = sc[b].reshape(C, P)[cls[b], torch.arange(P)]
+        eq = own[:-1] == own[1:]
+        assert bool((flat[b][:-1][eq] < flat[b][1:][eq]).all())
+        # (3) every proposal is a masked-in cell unless the pool of peaks ran out
+        assert bool(((got > 0) | (want <= 0)).all())
+        # (4) the C masked scores of each winning cell
+        ref_sc = masked[b].reshape(C, H * W)[:, cell[b]]
+        assert torch.allclose(sc[b], ref_sc, rtol=0, atol=2e-7)
+    # (5) query positions and features of the winners (exact: gathers and two float32 additions)
+    pos, feat = out["pos"].cpu().view(B, P, 2), out["feat"].cpu().view(B, P, hidden)
+    for b in range(B):
+        assert torch.equal(pos[b], bev_pos[cell[b]])
+        assert torch.equal(feat[b], tokens[b * H * W + cell[b]] + (cols[cls[b]] + bias))
