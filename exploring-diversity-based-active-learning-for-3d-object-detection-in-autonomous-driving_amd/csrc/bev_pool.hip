@@ -272,59 +272,121 @@ extern "C" int64_t al3d_bev_pool_workspace_bytes(int64_t n_points, int64_t n_cel
     return 3 * al3d_align(p * 4, 256) + 3 * al3d_align((c + 1) * 4, 256) + al3d_scan_workspace_bytes(c + 1);
 }
 
-static int bev_pool_run(const float* x, const float* depth, int lss, int Dd, int fHW, const float* geom, int64_t P,
-                        int C, int B, const float* lo, const float* dx, const int* nx, float* out, void* workspace,
-                        hipStream_t s, const char* name)
+struct BevPlan { int *cell, *list, *sorted, *count, *start, *fill; void* scan_ws; int64_t cb; };
+
+static BevPlan bev_plan_carve(void* workspace, int64_t P, int ncell)
 {
-    AL3D_REQUIRE(P >= 0 && P < (1LL << 31) && C >= 1 && B >= 1 && lo && dx && nx, "%s: bad arguments", name);
+    unsigned char* w = (unsigned char*)workspace;
+    const int64_t pb = al3d_align(P * 4, 256), cb = al3d_align(((int64_t)ncell + 1) * 4, 256);
+    BevPlan p;
+    p.cell = (int*)w;
+    p.list = (int*)(w + pb);
+    p.sorted = (int*)(w + 2 * pb);
+    p.count = (int*)(w + 3 * pb);
+    p.start = (int*)(w + 3 * pb + cb);
+    p.fill = (int*)(w + 3 * pb + 2 * cb);
+    p.scan_ws = w + 3 * pb + 3 * cb;
+    p.cb = cb;
+    return p;
+}
+
+static int bev_check_grid(int64_t P, int C, int B, const float* lo, const float* dx, const int* nx, const char* name, int* ncell)
+{
+    AL3D_REQUIRE(P >= 0 && P < (1LL << 31) && C >= 1 && B >= 1 && nx, "%s: bad arguments", name);
     AL3D_REQUIRE(nx[0] >= 1 && nx[1] >= 1 && nx[2] >= 1 && P % B == 0, "%s: bad grid / points not divisible by B", name);
     const int64_t ncell64 = (int64_t)B * nx[0] * nx[1] * nx[2];
     AL3D_REQUIRE(ncell64 < (1LL << 31) && ncell64 * C < (1LL << 40), "%s: grid too large", name);
-    AL3D_REQUIRE(out && workspace, "%s: null pointer", name);
-    const int ncell = (int)ncell64;
-    if (P == 0) {
-        if (hipMemsetAsync(out, 0, (size_t)ncell64 * C * 4, s) != hipSuccess) return al3d_fail(AL3D_ELAUNCH, "%s: memset failed", name);
-        return AL3D_OK;
-    }
-    AL3D_REQUIRE(x && geom && (!lss || depth), "%s: null pointer", name);
-    unsigned char* w = (unsigned char*)workspace;
-    const int64_t pb = al3d_align(P * 4, 256), cb = al3d_align(((int64_t)ncell + 1) * 4, 256);
-    int* cell = (int*)w;
-    int* list = (int*)(w + pb);
-    int* sorted = (int*)(w + 2 * pb);
-    int* count = (int*)(w + 3 * pb);
-    int* start = (int*)(w + 3 * pb + cb);
-    int* fill = (int*)(w + 3 * pb + 2 * cb);
-    void* scan_ws = w + 3 * pb + 3 * cb;
-    if (hipMemsetAsync(count, 0, (size_t)cb, s) != hipSuccess || hipMemsetAsync(fill, 0, (size_t)cb, s) != hipSuccess)
+    *ncell = (int)ncell64;
+    return AL3D_OK;
+}
+
+// the part that depends on the geometry only: cell of every point, members of every cell in ascending point order
+static int bev_pool_plan(const float* geom, int64_t P, int B, const float* lo, const float* dx, const int* nx, void* workspace,
+                         hipStream_t s, const char* name)
+{
+    int ncell;
+    int rc = bev_check_grid(P, 1, B, lo, dx, nx, name, &ncell);
+    if (rc) return rc;
+    AL3D_REQUIRE(geom && lo && dx && workspace && P > 0, "%s: null pointer / no point", name);
+    const BevPlan p = bev_plan_carve(workspace, P, ncell);
+    if (hipMemsetAsync(p.count, 0, (size_t)p.cb, s) != hipSuccess || hipMemsetAsync(p.fill, 0, (size_t)p.cb, s) != hipSuccess)
         return al3d_fail(AL3D_ELAUNCH, "%s: memset failed", name);
     BevGrid g;
     for (int k = 0; k < 3; ++k) { g.lo[k] = lo[k]; g.dx[k] = dx[k]; g.nx[k] = nx[k]; }
     g.B = B; g.per_batch = P / B;
     const unsigned pblocks = (unsigned)al3d_cdiv(P, 256);
-    hipLaunchKernelGGL(bev_cell_kernel, dim3(pblocks), dim3(256), 0, s, geom, P, g, cell, count);
-    int rc = al3d_exclusive_scan_i32(count, start, (int64_t)ncell + 1, scan_ws, s);
+    hipLaunchKernelGGL(bev_cell_kernel, dim3(pblocks), dim3(256), 0, s, geom, P, g, p.cell, p.count);
+    rc = al3d_exclusive_scan_i32(p.count, p.start, (int64_t)ncell + 1, p.scan_ws, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(bev_scatter_kernel, dim3(pblocks), dim3(256), 0, s, cell, P, start, fill, list);
+    hipLaunchKernelGGL(bev_scatter_kernel, dim3(pblocks), dim3(256), 0, s, p.cell, P, p.start, p.fill, p.list);
+    hipLaunchKernelGGL(bev_sort_long_kernel, dim3(1024), dim3(256), 0, s, p.count, p.start, p.list, p.sorted, ncell);
+    AL3D_CHECK_LAUNCH(name);
+    return AL3D_OK;
+}
+
+// the part that depends on the features: per cell the sum of its members' rows in ascending point order
+static int bev_pool_apply(const float* x, const float* depth, int lss, int Dd, int fHW, int64_t P, int C, int B, const int* nx,
+                          float* out, void* workspace, hipStream_t s, const char* name)
+{
+    int ncell;
+    int rc = bev_check_grid(P, C, B, nullptr, nullptr, nx, name, &ncell);
+    if (rc) return rc;
+    AL3D_REQUIRE(out && workspace && x && (!lss || depth) && P > 0, "%s: null pointer", name);
+    const BevPlan p = bev_plan_carve(workspace, P, ncell);
     const unsigned cblocks = (unsigned)al3d_cdiv(ncell, 4);
-    hipLaunchKernelGGL(bev_sort_long_kernel, dim3(1024), dim3(256), 0, s, count, start, list, sorted, ncell);
     if (C % 4 == 0 && C / 4 <= 64 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
         const int G = C / 4, CPW = 64 / G < BEV_CPW ? 64 / G : BEV_CPW;
         const unsigned vblocks = (unsigned)al3d_cdiv(ncell, 4 * CPW);
         if (lss)
-            hipLaunchKernelGGL(bev_sum_vec_kernel<1>, dim3(vblocks), dim3(256), 0, s, x, depth, C, G, CPW, Dd, fHW, count, start,
-                               list, sorted, ncell, out);
+            hipLaunchKernelGGL(bev_sum_vec_kernel<1>, dim3(vblocks), dim3(256), 0, s, x, depth, C, G, CPW, Dd, fHW, p.count, p.start,
+                               p.list, p.sorted, ncell, out);
         else
-            hipLaunchKernelGGL(bev_sum_vec_kernel<0>, dim3(vblocks), dim3(256), 0, s, x, depth, C, G, CPW, Dd, fHW, count, start,
-                               list, sorted, ncell, out);
+            hipLaunchKernelGGL(bev_sum_vec_kernel<0>, dim3(vblocks), dim3(256), 0, s, x, depth, C, G, CPW, Dd, fHW, p.count, p.start,
+                               p.list, p.sorted, ncell, out);
     } else if (lss)
-        hipLaunchKernelGGL(bev_sum_kernel<1>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, count, start, list,
-                           sorted, ncell, nx[2], out);
+        hipLaunchKernelGGL(bev_sum_kernel<1>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, p.count, p.start, p.list,
+                           p.sorted, ncell, nx[2], out);
     else
-        hipLaunchKernelGGL(bev_sum_kernel<0>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, count, start, list,
-                           sorted, ncell, nx[2], out);
+        hipLaunchKernelGGL(bev_sum_kernel<0>, dim3(cblocks), dim3(256), 0, s, x, depth, C, Dd, fHW, p.count, p.start, p.list,
+                           p.sorted, ncell, nx[2], out);
     AL3D_CHECK_LAUNCH(name);
     return AL3D_OK;
+}
+
+static int bev_pool_run(const float* x, const float* depth, int lss, int Dd, int fHW, const float* geom, int64_t P,
+                        int C, int B, const float* lo, const float* dx, const int* nx, float* out, void* workspace,
+                        hipStream_t s, const char* name)
+{
+    AL3D_REQUIRE(P >= 0 && P < (1LL << 31) && C >= 1 && B >= 1 && lo && dx && nx, "%s: bad arguments", name);
+    if (P == 0) {
+        int ncell;
+        int rc = bev_check_grid(P, C, B, lo, dx, nx, name, &ncell);
+        if (rc) return rc;
+        AL3D_REQUIRE(out, "%s: null pointer", name);
+        if (hipMemsetAsync(out, 0, (size_t)ncell * C * 4, s) != hipSuccess) return al3d_fail(AL3D_ELAUNCH, "%s: memset failed", name);
+        return AL3D_OK;
+    }
+    int rc = bev_pool_plan(geom, P, B, lo, dx, nx, workspace, s, name);
+    if (rc) return rc;
+    return bev_pool_apply(x, depth, lss, Dd, fHW, P, C, B, nx, out, workspace, s, name);
+}
+
+// The two halves as entry points: the plan (cell of every frustum point, members of every cell in ascending point order)
+// is a function of the geometry -- i.e. of the calibration matrices -- only; a sweep over a fixed rig builds it once and
+// applies it to every batch's (depth, context) maps.  `workspace` (al3d_bev_pool_workspace_bytes) holds the plan.
+extern "C" int al3d_bev_pool_plan(const float* geom, int64_t n_points, int B, const float* lo, const float* dx, const int* nx,
+                                  void* workspace, void* stream)
+{
+    return bev_pool_plan(geom, n_points, B, lo, dx, nx, workspace, (hipStream_t)stream, "al3d_bev_pool_plan");
+}
+
+extern "C" int al3d_bev_pool_lss_apply_f32(const float* depth, const float* ctx, int BN, int D, int fH, int fW, int C, int B,
+                                           const int* nx, const void* plan_workspace, float* out, void* stream)
+{
+    AL3D_REQUIRE(BN >= 1 && D >= 1 && fH >= 1 && fW >= 1 && B >= 1 && BN % B == 0, "al3d_bev_pool_lss_apply_f32: bad shape");
+    const int64_t P = (int64_t)BN * D * fH * fW;
+    return bev_pool_apply(ctx, depth, 1, D, fH * fW, P, C, B, nx, out, (void*)plan_workspace, (hipStream_t)stream,
+                          "al3d_bev_pool_lss_apply_f32");
 }
 
 extern "C" int al3d_bev_pool_f32(const float* x, const float* geom, int64_t n_points, int C, int B, const float* lo,

@@ -145,6 +145,8 @@ SIGNATURES = {
     "al3d_bev_pool_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
     "al3d_bev_pool_lss_f32": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p,
                                       c_p, c_p]),
+    "al3d_bev_pool_plan": (c_int, [c_p, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
+    "al3d_bev_pool_lss_apply_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p]),
     "al3d_reader_create": (c_int, [c_int, c_p]),
     "al3d_reader_destroy": (None, [c_p]),
     "al3d_reader_plan": (c_i64, [c_p, c_int, c_p]),

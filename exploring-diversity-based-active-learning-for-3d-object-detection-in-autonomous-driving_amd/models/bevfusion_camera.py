@@ -11,6 +11,7 @@ necks/generalized_lss.py:13-110 (``GeneralizedLSSFPN``), fusers/conv.py:11-25 (`
 the reference's [H=x, W=y]).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -158,6 +159,13 @@ class LSSViewTransform(nn.Module):
         """get_geometry with the per-point part on the device kernel (al3d_lss_geometry_f32): the 3x3 inverses and
         products per camera stay torch (B*N tiny matrices), the 2 M frustum points per sample do not."""
         B, N, _ = camera2lidar_trans.shape
+        return self._geometry_of_rows(self.geometry_rows(camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans,
+                                                         **kwargs), B, N)
+
+    def geometry_rows(self, camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs):
+        """The 44 floats per camera al3d_lss_geometry_f32 reads (inverse post-rotation, post-translation, camera2lidar x
+        inverse intrinsics, camera translation, the lidar augmentation): a function of the calibration matrices only."""
+        B, N, _ = camera2lidar_trans.shape
         dev = self.frustum.device
         f = lambda t, k: t.reshape(B * N, k).to(dev, torch.float32)
         zeros = torch.zeros((B * N, 9), dtype=torch.float32, device=dev)
@@ -171,6 +179,10 @@ class LSSViewTransform(nn.Module):
             torch.full((B * N, 1), 1.0 if has_rot else 0.0, dtype=torch.float32, device=dev),
             torch.full((B * N, 1), 1.0 if has_trans else 0.0, dtype=torch.float32, device=dev),
             zeros[:, :6]], dim=1).contiguous()
+        return rows
+
+    def _geometry_of_rows(self, rows, B, N):
+        dev = rows.device
         Dd, fH, fW, _ = self.frustum.shape
         geom = torch.empty((B, N, Dd, fH, fW, 3), dtype=torch.float32, device=dev)
         ws = torch.empty(lib.load().al3d_lss_geometry_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
@@ -178,11 +190,46 @@ class LSSViewTransform(nn.Module):
                  _ptr(ws), _stream())
         return geom
 
+    # The frustum geometry and the pooling plan (every frustum point's BEV cell, every cell's members in point order) are
+    # functions of the calibration matrices only.  A sweep over a fixed camera rig hands the same matrices with every batch:
+    # the last (rows -> plan) pair is kept and reused when the new rows have the same contents (one small comparison per
+    # batch).  AL3D_LSS_PLAN_CACHE=0 rebuilds every time.
+    PLAN_CACHE = os.environ.get("AL3D_LSS_PLAN_CACHE", "1") != "0"
+
+    def pool_lss(self, depth, ctx, rows, B, N):
+        """Lift-Splat pooling of (depth [BN,D,fH,fW], ctx [BN,fH,fW,C]) under the cameras ``rows`` [BN,44]
+        (geometry_rows): -> [B, nx0, nx1, nx2 * C]."""
+        dx, bx, nx = self.grid_numpy()
+        dxn = np.asarray(dx, dtype=np.float32)
+        lo = np.asarray(bx, dtype=np.float32) - dxn / np.float32(2.0)          # (bx - dx / 2.0) in float32
+        nxn = np.asarray(nx, dtype=np.int32)
+        depth, ctx = _dev(depth, torch.float32, "depth"), _dev(ctx, torch.float32, "ctx")
+        BN, Dd, fH, fW = depth.shape
+        C = ctx.shape[-1]
+        P = BN * Dd * fH * fW
+        f3, i3 = ctypes.c_float * 3, ctypes.c_int * 3
+        held = getattr(self, "_plan", None)
+        hit = (self.PLAN_CACHE and held is not None and held[0].shape == rows.shape and held[0].device == rows.device
+               and held[3] == (B, P) and bool(torch.equal(held[0], rows)))
+        if not hit:
+            geom = self._geometry_of_rows(rows, B, N)
+            ncell = B * int(nxn[0]) * int(nxn[1]) * int(nxn[2])
+            ws = torch.empty(lib.load().al3d_bev_pool_workspace_bytes(P, ncell), dtype=torch.uint8, device=depth.device)
+            lib.call("al3d_bev_pool_plan", _ptr(geom.reshape(-1, 3)), P, B, f3(*lo.tolist()), f3(*dxn.tolist()), i3(*nxn.tolist()),
+                     _ptr(ws), _stream())
+            held = (rows.clone(), ws, None, (B, P))
+            object.__setattr__(self, "_plan", held)
+            self.plan_builds = getattr(self, "plan_builds", 0) + 1
+        out = torch.empty((B, int(nxn[0]), int(nxn[1]), int(nxn[2]) * C), dtype=torch.float32, device=depth.device)
+        lib.call("al3d_bev_pool_lss_apply_f32", _ptr(depth), _ptr(ctx), BN, Dd, fH, fW, C, B, i3(*nxn.tolist()), _ptr(held[1]),
+                 _ptr(out), _stream())
+        return out
+
     def forward(self, depth, ctx, camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs):
         B, N, Dd, fH, fW = depth.shape
-        geom = self.geometry_device(camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs)
-        x = bev_pool(ctx.reshape(B * N, fH, fW, self.C).contiguous(), geom, B, *self.grid_numpy(),
-                     depth=depth.reshape(B * N, Dd, fH, fW).contiguous())
+        rows = self.geometry_rows(camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs)
+        x = self.pool_lss(depth.reshape(B * N, Dd, fH, fW).contiguous(), ctx.reshape(B * N, fH, fW, self.C).contiguous(), rows,
+                          B, N)
         for layer in self._ds:
             x = layer(x)
         return x
@@ -392,10 +439,10 @@ class DepthLSSTransform(LSSViewTransform):
         B, N, fH, fW, _ = img.shape
         d = self.depth_image(points, lidar2image, img_aug_matrix, lidar_aug_matrix)
         depth, ctx = self.get_cam_feats(img, d)
-        geom = self.geometry_device(camera2lidar[..., :3, :3], camera2lidar[..., :3, 3], cam_intrinsic[..., :3, :3],
-                                    img_aug_matrix[..., :3, :3], img_aug_matrix[..., :3, 3],
-                                    extra_rots=lidar_aug_matrix[..., :3, :3], extra_trans=lidar_aug_matrix[..., :3, 3])
-        x = bev_pool(ctx, geom, B, *self.grid_numpy(), depth=depth)
+        rows = self.geometry_rows(camera2lidar[..., :3, :3], camera2lidar[..., :3, 3], cam_intrinsic[..., :3, :3],
+                                  img_aug_matrix[..., :3, :3], img_aug_matrix[..., :3, 3],
+                                  extra_rots=lidar_aug_matrix[..., :3, :3], extra_trans=lidar_aug_matrix[..., :3, 3])
+        x = self.pool_lss(depth, ctx, rows, B, N)
         for layer in self._ds:
             x = layer(x)
         return x

@@ -560,6 +560,15 @@ int al3d_bev_pool_f32(const float* x, const float* geom, int64_t n_points, int C
 int al3d_bev_pool_lss_f32(const float* depth, const float* ctx, const float* geom, int BN, int D, int fH, int fW,
                           int C, int B, const float* lo, const float* dx, const int* nx, float* out,
                           void* workspace, void* stream);
+/* The same pooling in two halves: the plan (every frustum point's cell, every cell's members in ascending point order)
+ * depends on the geometry only, i.e. on the calibration matrices; a sweep over a fixed camera rig builds it once
+ * (al3d_bev_pool_plan, into a workspace of al3d_bev_pool_workspace_bytes) and applies it to every batch's (depth,
+ * context) maps (al3d_bev_pool_lss_apply_f32).  plan + apply == al3d_bev_pool_lss_f32 bit for bit. */
+int al3d_bev_pool_plan(const float* geom, int64_t n_points, int B, const float* lo, const float* dx, const int* nx,
+                       void* workspace, void* stream);
+int al3d_bev_pool_lss_apply_f32(const float* depth, const float* ctx, int BN, int D, int fH, int fW, int C, int B,
+                                const int* nx, const void* plan_workspace, float* out, void* stream);
+
 
 /* ---------------------------------------------------------------- streaming file loader (a1 / f2)
  * Host reader pool (csrc/reader.cpp, pthreads): replaces the reference's DataLoader worker processes

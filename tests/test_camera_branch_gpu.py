@@ -208,3 +208,41 @@ def test_upsample_cat_kernel_matches_torch(shape):
     # only the blend's rounding remains; against exact positions the position's rounding (1 ulp of ~16) times a tap difference
     assert float((out[..., C1:] - up32).abs().max()) <= 2e-6 * scale
     assert float((out[..., C1:].double() - up64).abs().max()) <= 2e-5 * scale
+
+
+def test_pooling_plan_is_cached_per_calibration_and_equals_the_one_shot_call():
+    """The Lift-Splat plan (frustum geometry, every point's BEV cell, every cell's members in point order) depends on the
+    calibration matrices only: plan + apply == the one-shot al3d_bev_pool_lss_f32 bit for bit; a second batch under the SAME
+    rig reuses the plan (no new build) and still gives the one-shot result; changed matrices rebuild it."""
+    from al3d.models.bevfusion_camera import DepthLSSTransform, bev_pool
+    image_size, feature_size = (64, 176), (8, 22)
+    B, N, C = 2, 6, 16
+    vt = _seed_(DepthLSSTransform(32, C, image_size, feature_size, [-54.0, 54.0, 0.6], [-54.0, 54.0, 0.6], [-10.0, 10.0, 20.0],
+                                  [1.0, 60.0, 1.0], downsample=2), 5).to(DEV)
+    K, cam2lidar, _, img_aug, lidar_aug, _ = _camera_setup(B, N, 4, image_size)
+    g = torch.Generator().manual_seed(8)
+
+    def maps():
+        depth = torch.rand(B * N, vt.D, *feature_size, generator=g).softmax(1).to(DEV)
+        ctx = torch.randn(B * N, *feature_size, C, generator=g).to(DEV)
+        return depth, ctx
+
+    def rows(c2l):
+        return vt.geometry_rows(c2l[..., :3, :3].to(DEV), c2l[..., :3, 3].to(DEV), K[..., :3, :3].to(DEV),
+                                img_aug[..., :3, :3].to(DEV), img_aug[..., :3, 3].to(DEV),
+                                extra_rots=lidar_aug[..., :3, :3].to(DEV), extra_trans=lidar_aug[..., :3, 3].to(DEV))
+
+    def one_shot(depth, ctx, r):
+        geom = vt._geometry_of_rows(r, B, N)
+        return bev_pool(ctx, geom, B, *vt.grid_numpy(), depth=depth)
+    vt.plan_builds = 0
+    r1 = rows(cam2lidar)
+    d1, c1 = maps()
+    assert torch.equal(vt.pool_lss(d1, c1, r1, B, N), one_shot(d1, c1, r1)) and vt.plan_builds == 1
+    d2, c2 = maps()
+    assert torch.equal(vt.pool_lss(d2, c2, rows(cam2lidar), B, N), one_shot(d2, c2, r1)) and vt.plan_builds == 1   # same rig: reused
+    moved = cam2lidar.clone()
+    moved[..., 0, 3] += 0.25
+    r3 = rows(moved)
+    out3 = vt.pool_lss(d2, c2, r3, B, N)
+    assert vt.plan_builds == 2 and torch.equal(out3, one_shot(d2, c2, r3)) and not torch.equal(out3, one_shot(d2, c2, r1))
