@@ -441,6 +441,11 @@ def cpu_baseline(cfg, model_cpu_state, infos, feats, sample_frames=2):
 def main():
     args = parse()
     global BUDGET
+    if os.environ.get("AL3D_STACKDUMP_AFTER"):
+        # diagnosis aid for runs under a profiler (a counter pass of round 3 hung under the two-stream pipeline and left no
+        # trace of where): every N seconds the Python stacks of all threads go to stderr, so a stuck pass shows its wait
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["AL3D_STACKDUMP_AFTER"]), repeat=True, file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.scenes is None:
         args.scenes = SCENES_PER_RANK if world == 1 else SCENES_PER_RANK_MULTI

@@ -1,0 +1,44 @@
+# Round-4 profile summaries on a GPU box (gpurun): one process per leg, collected at the round's final kernels.
+#   PART=stats  kernel stats of the default (pipelined) and the serial bench, of the camera+lidar / head / lidar-only sweeps
+#   PART=pmc    HBM traffic counters of the headline bench WITH the two-stream pipeline on (the round-3 attempt hung in this
+#               pass and was collected serial): a stack-dump watchdog and the pass's stderr are kept either way
+#   PART=sq     SQ counters of the level-0 kernels
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+PART=${PART:-stats}
+HEAD="--steps 2 --warmup 1 --no-cpu-baseline --no-extra-math --no-from-files --no-bevfusion"
+if [ "$PART" = stats ]; then
+  rm -rf /tmp/p_*
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/p_def -o d -- python3 $R/bench.py $HEAD > $O/r04_bench_default_line.json 2> $O/r04_prof_def.err || exit 1
+  python3 $R/tools/rocpd_summary.py stats $(find /tmp/p_def -name "*.db" | head -1) $O/r04_bench_default_kernel_stats.csv
+  AL3D_PIPELINE=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/p_ser -o s -- python3 $R/bench.py $HEAD > $O/r04_bench_serial_line.json 2> $O/r04_prof_ser.err || exit 1
+  python3 $R/tools/rocpd_summary.py stats $(find /tmp/p_ser -name "*.db" | head -1) $O/r04_bench_serial_kernel_stats.csv
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cl -o c -- python3 $R/tools/bench_bevfusion_camera_lidar.py 16 3 > $O/r04_bevfusion_camera_lidar.log 2> $O/r04_prof_cl.err || exit 1
+  python3 $R/tools/rocpd_summary.py stats $(find /tmp/p_cl -name "*.db" | head -1) $O/r04_bevfusion_camera_lidar_kernel_stats.csv
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/p_clh -o c -- python3 $R/tools/bench_bevfusion_camera_lidar.py 8 3 1 > $O/r04_bevfusion_camera_lidar_head.log 2> $O/r04_prof_clh.err || exit 1
+  python3 $R/tools/rocpd_summary.py stats $(find /tmp/p_clh -name "*.db" | head -1) $O/r04_bevfusion_camera_lidar_head_kernel_stats.csv
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/p_li -o l -- python3 $R/tools/bench_bevfusion_lidar.py 96 32 > $O/r04_bevfusion_lidar.log 2> $O/r04_prof_li.err || exit 1
+  python3 $R/tools/rocpd_summary.py stats $(find /tmp/p_li -name "*.db" | head -1) $O/r04_bevfusion_lidar_kernel_stats.csv
+fi
+if [ "$PART" = pmc ]; then
+  rm -rf /tmp/p_fetch /tmp/p_write
+  ARGS="--scenes 16 --steps 1 --warmup 0 --no-cpu-baseline --no-extra-math --no-from-files --no-verify --no-bevfusion"
+  export AL3D_STACKDUMP_AFTER=45
+  echo "fetch pass (pipeline ${AL3D_PIPELINE:-ahead}) start $(date +%T)" >> $O/r04_pmc_progress.log
+  timeout -k 10 170 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch -o f -- python3 $R/bench.py $ARGS > $O/r04_pmc_fetch_line.json 2> $O/r04_prof_fetch.err
+  rc=$?
+  echo "fetch pass rc $rc $(date +%T)" >> $O/r04_pmc_progress.log
+  [ $rc -eq 0 ] || exit $rc
+  timeout -k 10 170 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write -o w -- python3 $R/bench.py $ARGS > $O/r04_pmc_write_line.json 2> $O/r04_prof_write.err
+  rc=$?
+  echo "write pass rc $rc $(date +%T)" >> $O/r04_pmc_progress.log
+  [ $rc -eq 0 ] || exit $rc
+  python3 $R/tools/rocpd_summary.py hbm $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) $O/r04_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, AL3D_PIPELINE=${AL3D_PIPELINE:-ahead} bench.py $ARGS (640 frames = 5 batches of 128, AL3D_MATH=f16x3)" $O/r04_pmc_fetch_line.json
+fi
+if [ "$PART" = sq ]; then
+  BENCH_L0_MODES=off,raster16p bash $R/tools/pmc_sq_l0.sh
+  cp $O/pmc_l0.txt $O/r04_pmc_sq_l0.txt
+fi
+ls -la $O/r04_* | tail -30
