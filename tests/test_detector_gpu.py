@@ -592,7 +592,7 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
         # ("wave2"), or per channel pair (the default) -- one arithmetic each, same bits
         # (round 4: the default also renumbers the level-0 rows in raster order and runs their layers as item streams,
         # csrc/spconv_l0.hip; "glds" / "wave2" keep the voxelizer's row order.  Same bits as long as the level-0 rows travel
-        # as f32 rows in all of them; as pair rows -- the default -- the embedding moves by the pair format's rounding)
+        # as f32 rows -- the default -- in all of them; as pair rows the embedding moves by the pair format's rounding)
         saved_l0 = D.L0_ROWS
         try:
             D.L0_ROWS = "f32"
@@ -601,11 +601,15 @@ def test_full_size_frames_kernel_structures_and_pipeline_agree():
                 D.SPCONV = mode
                 assert torch.equal(run(4), ref_f32), mode
             D.SPCONV = saved[0]
+            if D.MATH == "f16x3" and D.sparse_raster():
+                D.L0_ROWS = "pair"
+                ref_pair = run(4)
+                assert float((ref_f32 - ref_pair).abs().max()) <= 2e-5 * float(ref_f32.abs().max())
+                assert not torch.equal(ref_f32, ref_pair)   # the knob does something
         finally:
             D.L0_ROWS = saved_l0
-        if D.MATH == "f16x3" and D.sparse_raster() and D.L0_ROWS == "pair":
-            assert float((ref_f32 - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
-            assert not torch.equal(ref_f32, ref)            # the knob does something
+        if saved_l0 == "f32":
+            assert torch.equal(ref, ref_f32)                # the default IS the bit-compatible form
         # f16x3 dense structures: LDS-staged kernels everywhere / round 1's streamed-weight policy, against the
         # default (3x3 streamed fragments + LDS-DMA kernel for the other geometries, fused GAP in all of them)
         for mode in ("lds", "stream"):

@@ -268,7 +268,7 @@ def test_encoder_raster_path_equals_appearance_order_path():
     """The whole middle encoder with its level-0 rows renumbered in raster order gives, cell for cell, the bits of the
     encoder run in the voxelizer's first-appearance order (AL3D_L0=off: round 3's kernels), with the item-stream kernel
     on the 16 -> 16 layers only and on the strided 16 -> 32 layer too -- when the level-0 rows stay f32 rows
-    (AL3D_L0_ROWS=f32); as pair rows (the default) the outputs agree to the pair format's rounding."""
+    (AL3D_L0_ROWS=f32, the default); as pair rows the outputs agree to the pair format's rounding."""
     from al3d import detector_ops as D, synthetic
     from al3d.models.backbones import FPNSpMiddleResNetFHD
     if D.MATH != "f16x3":
@@ -300,7 +300,7 @@ def test_encoder_raster_path_equals_appearance_order_path():
         assert torch.equal(dense.view(torch.int32), ref_dense.view(torch.int32)), tag
         for (f, i, s), (rf, ri, rs) in zip(mid, ref_mid):
             assert s == rs and torch.equal(i, ri) and torch.equal(f.view(torch.int32), rf.view(torch.int32)), tag
-    # level-0 rows as pair rows between the item-stream layers (the default): the products are unchanged, the stored
+    # level-0 rows as pair rows between the item-stream layers (AL3D_L0_ROWS=pair): the products are unchanged, the stored
     # activations carry 22-23 significant bits (what the residual adds and the next layer's split see): same outputs to
     # ~1e-6 of the scale, not the same bits
     for tag in ("pair16", "pair16+32"):
