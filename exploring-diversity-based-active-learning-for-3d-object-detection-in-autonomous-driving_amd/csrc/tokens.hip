@@ -1123,3 +1123,447 @@ extern "C" int al3d_tok_mha16_f32(const float* q, int ldq, const float* k, int l
     AL3D_CHECK_LAUNCH("tok_mha16_combine_kernel");
     return AL3D_OK;
 }
+
+// sum over the 16 lanes of a DPP row, every lane gets it: rotations by 8, 4, 2, 1 inside the row.  After the step by 8
+// lanes i and i ^ 8 hold equal values, so the lane a rotation reaches holds what lane i ^ step holds: the additions are
+// those of the __shfl_xor butterfly 8, 4, 2, 1 (tok_layernorm_kernel<16>), bit for bit, without the LDS crossbar.
+__device__ __forceinline__ float tk_row16_sum(float v)
+{
+#define TK_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+    v += TK_ROR(8);
+    v += TK_ROR(4);
+    v += TK_ROR(2);
+    v += TK_ROR(1);
+#undef TK_ROR
+    return v;
+}
+
+// ------------------------------------------------------------------ fused attention half of a Swin block
+// x += proj(W-MSA(LN1(x))) as ONE kernel (C = 96 / 192, the two stages whose separate LN1 / qkv / attention / proj
+// launches are bound by the 44 C bytes per token they move; this kernel reads the window's rows once and writes them once:
+// 8 C).  One workgroup per 7 x 7 window, one wave per head:
+//   1. all waves: LayerNorm of the window's 49 rows, gathered arithmetically (cyclic shift + window partition + padding
+//      from the window's position: no row map; the stand-alone kernel's arithmetic, 16 lanes per row, all rows of a lane
+//      group requested before the first is reduced) -> pair rows (xh, xl') in LDS, padding and rows 49 .. 63 zero;
+//   2. wave h: K^T and Q^T tiles of its head as  W^T xn^T  (weights = A operand; tokens across the lanes, head channels
+//      down the accumulator registers) and V as  xn W  (head channel = lane, tokens down the registers).  In these
+//      orientations every accumulator IS the next product's operand after bias + split: K (A) and Q^T (B) of
+//      S^T = K Q^T share the register order of the head channels; V^T (A) of O^T = V^T P^T has the keys in the order
+//      P^T's rows come out of the softmax.  q, k, v never exist in memory;
+//   3. softmax down the registers with the relative position bias and the shifted-window mask exactly as
+//      tok_window_attention_kernel; O^T -> pair rows in LDS (natural channel order);
+//   4. wave w: output channels 32 w .. 32 w + 31 of  Wp^T O^T  for both token tiles, + bias + residual, written back to
+//      the rows the window came from.
+// The weights never touch LDS: each wave streams its own fragments (image per wave: parts k | v | q | proj, each
+// [C/16][2 planes][64 lanes][8], MFMA lane order) from L2 into a register ring of AB_D steps, one whole part ahead of
+// their use -- the first part is requested before the LayerNorm's rows.
+// f16x3 arithmetic as everywhere: weights x activations = three products into one accumulator, activations x activations
+// = main + 2^-11 correction accumulators.
+struct TokAttnBlockParams {
+    float* x;                // [B * H * W][C] residual stream, updated in place
+    const _Float16* image;
+    const float* gamma;      // LN1 [C]
+    const float* beta;
+    const float* bias_qkv;   // [3 C]: q | k | v
+    const float* bias_proj;  // [C]
+    const float* table;      // [169][heads]
+    float eps, scale_qkv, scale_proj, scale;
+    int B, H, W, nwy, nwx, shift;
+};
+
+#define AB_D 6               // ring depth in channel steps (2 fragments of 16 bytes per lane each)
+
+template <int C>
+__global__ __launch_bounds__(C * 2, 2) void tok_attn_block_f16x3_kernel(TokAttnBlockParams p)
+{
+    constexpr int NH = C / 32, KC = C / 16, NTHR = NH * 64, PITCH = C * 4 + 16, NG = C / 8;
+    constexpr int RPP = NTHR / 16, NR = (TK_NT + RPP - 1) / RPP, NT = (NG + 15) / 16;
+    constexpr int NSTEP = 4 * KC;
+    static_assert(KC % AB_D == 0, "the ring holds a whole number of steps per part");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ab_smem[];
+    unsigned char* xn = ab_smem;                          // 64 pair rows (pitch + 16 B: conflict-free fragment reads)
+    unsigned char* ob = ab_smem + 64 * PITCH;             // 64 pair rows of attention output
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* tbl = reinterpret_cast<float*>(ab_smem + 128 * PITCH) + wave * 176;
+    // this wave's bias rows k | q | proj | v (32 each): staged once, so that no global load sits between the weight stream's
+    // requests and their use (vmcnt retires in order: a bias load issued after a refill would wait for it)
+    float* bsm = reinterpret_cast<float*>(ab_smem + 128 * PITCH + NH * 176 * 4) + wave * 128;
+    const int win = blockIdx.x;
+    const int wi = win % (p.nwy * p.nwx), b = win / (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
+    // token row of window position `row` (ty, tx), or -1 for padding: shifted[hp] = padded[(hp + shift) % Hp]
+    auto token_of = [&](int row) __attribute__((always_inline)) -> int {
+        const int ty = row / TK_WS, tx = row - ty * TK_WS;
+        int hs = wy * TK_WS + ty + p.shift, ws = wx * TK_WS + tx + p.shift;
+        hs -= hs >= p.nwy * TK_WS ? p.nwy * TK_WS : 0;
+        ws -= ws >= p.nwx * TK_WS ? p.nwx * TK_WS : 0;
+        return row < TK_NT && hs < p.H && ws < p.W ? (b * p.H + hs) * p.W + ws : -1;
+    };
+
+    // ---- the weight stream: step g = (part, channel step); fragments of step g live in ring slot g % AB_D
+    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.image) + (size_t)wave * (NSTEP * 2048) + lane * 16;
+    f16x8 rwh[AB_D], rwl[AB_D];
+    auto issue = [&](int g) __attribute__((always_inline)) {
+        if (g < NSTEP) {
+            rwh[g % AB_D] = *reinterpret_cast<const f16x8*>(wimg + g * 2048);
+            rwl[g % AB_D] = *reinterpret_cast<const f16x8*>(wimg + g * 2048 + 1024);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < AB_D; ++g) issue(g);
+
+    for (int t = lane; t < 169; t += 64) tbl[t] = p.table[t * NH + wave];
+    {
+        const int part = lane >> 5;                        // lanes 0-31: k, proj; 32-63: q, v
+        bsm[lane] = p.bias_qkv[(part == 0 ? C : 0) + 32 * wave + fr];
+        bsm[64 + lane] = part == 0 ? p.bias_proj[32 * wave + fr] : p.bias_qkv[2 * C + 32 * wave + fr];
+    }
+    // shifted-window regions of the window's 7 rows / 7 columns, two bits each (uniform): tokens attend inside a region
+    int rycode = 0, rxcode = 0;
+    if (p.shift > 0)
+        for (int t = 0; t < TK_WS; ++t) {
+            rycode |= tk_region1(wy * TK_WS + t, p.nwy * TK_WS, p.shift) << (2 * t);
+            rxcode |= tk_region1(wx * TK_WS + t, p.nwx * TK_WS, p.shift) << (2 * t);
+        }
+    // ---- 1. LayerNorm (tok_layernorm_kernel<16>'s arithmetic: same sums, same shuffles)
+    {
+        const int sub = tid & 15, grp = tid >> 4;
+        float v[NR][NT][8];
+        int src[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = grp + i * RPP;
+            src[i] = token_of(row);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int g = sub + 16 * t;
+                // unconditional (clamped) loads, zeroed afterwards: a load inside a branch would be waited for inside it,
+                // one memory round trip per row instead of one for all
+                const bool ok = src[i] >= 0 && g < NG;
+                const float* s = p.x + (int64_t)(ok ? src[i] : 0) * C + 8 * (ok ? g : 0);
+                const float4 a = *reinterpret_cast<const float4*>(s), b4 = *reinterpret_cast<const float4*>(s + 4);
+                v[i][t][0] = ok ? a.x : 0.f; v[i][t][1] = ok ? a.y : 0.f; v[i][t][2] = ok ? a.z : 0.f; v[i][t][3] = ok ? a.w : 0.f;
+                v[i][t][4] = ok ? b4.x : 0.f; v[i][t][5] = ok ? b4.y : 0.f; v[i][t][6] = ok ? b4.z : 0.f; v[i][t][7] = ok ? b4.w : 0.f;
+            }
+        }
+        for (int i = tid; i < (64 - TK_NT) * PITCH / 16; i += NTHR)          // rows 49 .. 63: keys with zero weight, finite values
+            *reinterpret_cast<uint4*>(xn + TK_NT * PITCH + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+        float ga[NT][8], be[NT][8];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int g = sub + 16 * t < NG ? sub + 16 * t : 0;
+            const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + 8 * g), g1 = *reinterpret_cast<const float4*>(p.gamma + 8 * g + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.beta + 8 * g), b1 = *reinterpret_cast<const float4*>(p.beta + 8 * g + 4);
+            ga[t][0] = g0.x; ga[t][1] = g0.y; ga[t][2] = g0.z; ga[t][3] = g0.w; ga[t][4] = g1.x; ga[t][5] = g1.y; ga[t][6] = g1.z; ga[t][7] = g1.w;
+            be[t][0] = b0.x; be[t][1] = b0.y; be[t][2] = b0.z; be[t][3] = b0.w; be[t][4] = b1.x; be[t][5] = b1.y; be[t][6] = b1.z; be[t][7] = b1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = grp + i * RPP;
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += v[i][t][e];
+            sum = tk_row16_sum(sum);
+            const float mean = sum / (float)C;
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (sub + 16 * t >= NG) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[i][t][e] - mean; sq += d * d; }
+            }
+            sq = tk_row16_sum(sq);
+            const float rstd = 1.0f / sqrtf(sq / (float)C + p.eps);
+            if (row >= TK_NT) continue;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int g = sub + 16 * t;
+                if (g >= NG) continue;
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = src[i] < 0 ? 0.f : ((v[i][t][e] - mean) * rstd) * ga[t][e] + be[t][e];
+                uint4 hi, lo;
+                sp_split8(y, hi, lo);
+                *reinterpret_cast<uint4*>(xn + row * PITCH + g * 32) = hi;
+                *reinterpret_cast<uint4*>(xn + row * PITCH + g * 32 + 16) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. this head's K, V, Q (both token tiles each)
+    auto xfrag = [&](const unsigned char* buf, int t, int kc, f16x8& xh, f16x8& xl) __attribute__((always_inline)) {
+        const unsigned char* s = buf + (32 * t + fr) * PITCH + (2 * kc + fh) * 32;
+        xh = *reinterpret_cast<const f16x8*>(s);
+        xl = *reinterpret_cast<const f16x8*>(s + 16);
+    };
+    // weights x activations over the C / 16 channel steps of stream part `part`; WA: the weights are the A operand
+    // (transposed product).  The step's ring slot is refilled with the fragments AB_D steps later.
+    auto gemm2 = [&](int part, const unsigned char* buf, bool WA, bool refill, f32x16& a0, f32x16& a1) __attribute__((always_inline)) {
+        f16x8 fx[2][4];                                     // [parity of the step][tile 0 h, l, tile 1 h, l]: read one step ahead
+        xfrag(buf, 0, 0, fx[0][0], fx[0][1]);
+        xfrag(buf, 1, 0, fx[0][2], fx[0][3]);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int g = part * KC + kc;
+            const f16x8 wh = rwh[g % AB_D], wl = rwl[g % AB_D];
+            const f16x8 wd = tk_lift_down(wh);
+            if (kc + 1 < KC) {
+                xfrag(buf, 0, kc + 1, fx[(kc + 1) & 1][0], fx[(kc + 1) & 1][1]);
+                xfrag(buf, 1, kc + 1, fx[(kc + 1) & 1][2], fx[(kc + 1) & 1][3]);
+            }
+            const f16x8 xh0 = fx[kc & 1][0], xl0 = fx[kc & 1][1], xh1 = fx[kc & 1][2], xl1 = fx[kc & 1][3];
+            if (WA) {
+                a0 = TK_MFMA(wd, xl0, a0); a1 = TK_MFMA(wd, xl1, a1);
+                a0 = TK_MFMA(wl, xh0, a0); a1 = TK_MFMA(wl, xh1, a1);
+                a0 = TK_MFMA(wh, xh0, a0); a1 = TK_MFMA(wh, xh1, a1);
+            } else {
+                a0 = TK_MFMA(xl0, wd, a0); a1 = TK_MFMA(xl1, wd, a1);
+                a0 = TK_MFMA(xh0, wl, a0); a1 = TK_MFMA(xh1, wl, a1);
+                a0 = TK_MFMA(xh0, wh, a0); a1 = TK_MFMA(xh1, wh, a1);
+            }
+            if (refill || g + AB_D < (part + 1) * KC) issue(g + AB_D);     // !refill: the next part is requested later
+            __builtin_amdgcn_sched_barrier(0);             // the request stays HERE (hipcc otherwise sinks it to its use)
+        }
+    };
+    auto zero16 = [](f32x16& a) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+    };
+    // bias of the accumulator's 16 rows: head channel (r & 3) + 8 (r >> 2) + 4 fh
+    auto bias16 = [&](const float* bsrc, float (&o)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bsrc + 8 * g + 4 * fh);
+            o[4 * g] = b4.x; o[4 * g + 1] = b4.y; o[4 * g + 2] = b4.z; o[4 * g + 3] = b4.w;
+        }
+    };
+
+    f16x8 kh[2][2], kl[2][2], vh[2][2], vl[2][2], qh[2][2], ql[2][2];
+    {
+        f32x16 a0, a1;
+        zero16(a0); zero16(a1);
+        gemm2(0, xn, true, true, a0, a1);
+        float bk[16];
+        bias16(bsm, bk);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v0[e] = a0[8 * s + e] * p.scale_qkv + bk[8 * s + e];
+                v1[e] = a1[8 * s + e] * p.scale_qkv + bk[8 * s + e];
+            }
+            tk_split8(v0, kh[0][s], kl[0][s]);
+            tk_split8(v1, kh[1][s], kl[1][s]);
+        }
+    }
+    {
+        f32x16 a0, a1;
+        zero16(a0); zero16(a1);
+        gemm2(1, xn, false, true, a0, a1);
+        const float bv = bsm[96 + fr];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v0[e] = a0[8 * s + e] * p.scale_qkv + bv;
+                v1[e] = a1[8 * s + e] * p.scale_qkv + bv;
+            }
+            tk_split8(v0, vh[0][s], vl[0][s]);
+            tk_split8(v1, vh[1][s], vl[1][s]);
+        }
+    }
+    {
+        f32x16 a0, a1;
+        zero16(a0); zero16(a1);
+        gemm2(2, xn, true, false, a0, a1);
+        float bq[16];
+        bias16(bsm + 32, bq);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v0[e] = (a0[8 * s + e] * p.scale_qkv + bq[8 * s + e]) * p.scale;
+                v1[e] = (a1[8 * s + e] * p.scale_qkv + bq[8 * s + e]) * p.scale;
+            }
+            tk_split8(v0, qh[0][s], ql[0][s]);
+            tk_split8(v1, qh[1][s], ql[1][s]);
+        }
+    }
+    // ---- 3. per query tile: S^T, softmax, O^T
+    const bool masked = p.shift > 0;
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {                            // a real loop: a tile's logits and outputs are live in one iteration only
+        const int query = 32 * j + fr;
+        f16x8 qhj[2], qlj[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qhj[s] = j ? qh[1][s] : qh[0][s]; qlj[s] = j ? ql[1][s] : ql[0][s]; }
+        f32x16 sm[2], sc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { zero16(sm[i]); zero16(sc[i]); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sc[i] = TK_MFMA(kl[i][s], qhj[s], sc[i]);
+                sc[i] = TK_MFMA(kh[i][s], qlj[s], sc[i]);
+                sm[i] = TK_MFMA(kh[i][s], qhj[s], sm[i]);
+            }
+        const int qq = query < TK_NT ? query : TK_NT - 1;
+        const int qy = (qq * 37) >> 8, qx = qq - TK_WS * qy;
+        const int qcode = qq + 6 * qy + 84;                          // 13 y + x + 84
+        // bit k of `same`: key k lies in this query's region (all ones without a shift).  No LDS, no branch per element:
+        // the per-element form (a region lookup behind `if (masked)`) made hipcc serialise 64 LDS round trips per tile
+        unsigned long long same = ~0ull;
+        if (masked) {
+            const int myry = (rycode >> (2 * qy)) & 3, myrx = (rxcode >> (2 * qx)) & 3;
+            unsigned colmask = 0u;
+            same = 0ull;
+#pragma unroll
+            for (int t = 0; t < TK_WS; ++t) colmask |= (unsigned)(((rxcode >> (2 * t)) & 3) == myrx) << t;
+#pragma unroll
+            for (int t = 0; t < TK_WS; ++t)
+                if (((rycode >> (2 * t)) & 3) == myry) same |= (unsigned long long)colmask << (TK_WS * t);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float tb[16];                                            // the tile's 16 bias lookups first, then their uses
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int kk = key < TK_NT ? key : TK_NT - 1;
+                tb[r] = tbl[qcode - (kk + 6 * ((kk * 37) >> 8))];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float v = sm[i][r] + sc[i][r] * 0.00048828125f;
+                v += tb[r];
+                v += ((same >> key) & 1ull) ? 0.0f : -100.0f;
+                v = key < TK_NT ? v : -INFINITY;
+                sm[i][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = sm[i][r] - mx;
+                const float t = __builtin_fmaf(d, 1.44269502162933349609f, d * 1.92596299112661746e-8f);
+                const float e = __builtin_amdgcn_exp2f(t);
+                sm[i][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        f32x16 om, oc;
+        zero16(om); zero16(oc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = sm[i][8 * s + e];
+                f16x8 ph, pl;
+                tk_split8(pv, ph, pl);
+                oc = TK_MFMA(vl[i][s], ph, oc);
+                oc = TK_MFMA(vh[i][s], pl, oc);
+                om = TK_MFMA(vh[i][s], ph, om);
+            }
+        // rows of O^T are head channels (r & 3) + 8 (r >> 2) + 4 fh: a register quad = four consecutive channels
+        unsigned char* orow = ob + query * PITCH + (4 * wave) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            _Float16 hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tk_split((om[4 * g + e] + oc[4 * g + e] * 0.00048828125f) * inv, hh[e], ll[e]);
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 vh4 = {hh[0], hh[1], hh[2], hh[3]}, vl4 = {ll[0], ll[1], ll[2], ll[3]};
+            *reinterpret_cast<uint2*>(orow + g * 32 + 8 * fh) = __builtin_bit_cast(uint2, vh4);
+            *reinterpret_cast<uint2*>(orow + g * 32 + 16 + 8 * fh) = __builtin_bit_cast(uint2, vl4);
+        }
+    }
+    // the projection's fragments (not held across the attention: registers) and the residual pieces this lane will add to:
+    // requested before the barrier
+#pragma unroll
+    for (int g = 3 * KC; g < 3 * KC + AB_D; ++g) issue(g);
+    int dst[2];
+    float4 rs[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        dst[t] = token_of(32 * t + fr);
+        const float* xr = p.x + (int64_t)(dst[t] < 0 ? 0 : dst[t]) * C + 32 * wave + 4 * fh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rs[t][g] = *reinterpret_cast<const float4*>(xr + 8 * g);
+    }
+    __syncthreads();
+
+    // ---- 4. output channels 32 wave .. + 31 of the projection, both token tiles; + bias + residual
+    {
+        f32x16 a0, a1;
+        zero16(a0); zero16(a1);
+        gemm2(3, ob, true, false, a0, a1);
+        float bp[16];
+        bias16(bsm + 64, bp);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (dst[t] < 0) continue;
+            float* xr = p.x + (int64_t)dst[t] * C + 32 * wave + 4 * fh;
+            const f32x16& a = t == 0 ? a0 : a1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 r4 = rs[t][g];
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = a[4 * g + e] * p.scale_proj + bp[4 * g + e];
+                r4.x += y[0]; r4.y += y[1]; r4.z += y[2]; r4.w += y[3];
+                *reinterpret_cast<float4*>(xr + 8 * g) = r4;
+            }
+        }
+    }
+}
+
+extern "C" int64_t al3d_tok_attn_block_image_bytes(int C) { return (int64_t)(C / 32) * 4 * (C / 16) * 2048; }
+
+extern "C" int al3d_tok_attn_block_f16x3(float* x, int B, int H, int W, int C, int shift, const float* gamma, const float* beta,
+                                         float eps, const void* image, float scale_qkv, const float* bias_qkv,
+                                         float scale_proj, const float* bias_proj, const float* table, float attn_scale,
+                                         void* stream)
+{
+    AL3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (int64_t)B * H * W < ((int64_t)1 << 31), "al3d_tok_attn_block_f16x3: bad map size");
+    if (B == 0) return AL3D_OK;
+    AL3D_REQUIRE(x && gamma && beta && image && bias_qkv && bias_proj && table, "al3d_tok_attn_block_f16x3: null pointer");
+    AL3D_REQUIRE(C == 96 || C == 192, "al3d_tok_attn_block_f16x3: built for C = 96 and 192 (the bandwidth-bound stages), got %d", C);
+    AL3D_REQUIRE(shift >= 0 && shift < TK_WS, "al3d_tok_attn_block_f16x3: shift=%d outside [0, 7)", shift);
+    AL3D_REQUIRE((((uintptr_t)x | (uintptr_t)image | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bias_qkv | (uintptr_t)bias_proj) & 15) == 0,
+                 "al3d_tok_attn_block_f16x3: x / image / gamma / beta / biases must be 16-byte aligned");
+    const int nwy = (H + TK_WS - 1) / TK_WS, nwx = (W + TK_WS - 1) / TK_WS;
+    AL3D_REQUIRE((int64_t)B * nwy * nwx < ((int64_t)1 << 31), "al3d_tok_attn_block_f16x3: too many windows");
+    TokAttnBlockParams p{x, (const _Float16*)image, gamma, beta, bias_qkv, bias_proj, table, eps, scale_qkv, scale_proj,
+                         attn_scale, B, H, W, nwy, nwx, shift};
+    const int NH = C / 32;
+    const size_t lds = (size_t)128 * (C * 4 + 16) + (size_t)NH * (176 + 128) * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)tok_attn_block_f16x3_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tok_attn_block_f16x3_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return al3d_fail(AL3D_ELAUNCH, "al3d_tok_attn_block_f16x3: cannot raise the dynamic LDS limit");
+        attr = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nwin = (unsigned)(B * nwy * nwx);
+    if (C == 96) hipLaunchKernelGGL(tok_attn_block_f16x3_kernel<96>, dim3(nwin), dim3(192), lds, s, p);
+    else hipLaunchKernelGGL(tok_attn_block_f16x3_kernel<192>, dim3(nwin), dim3(384), lds, s, p);
+    AL3D_CHECK_LAUNCH("tok_attn_block_f16x3_kernel");
+    return AL3D_OK;
+}

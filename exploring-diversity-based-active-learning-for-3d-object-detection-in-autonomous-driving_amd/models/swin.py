@@ -82,6 +82,14 @@ class WindowMSA(nn.Module):
             T.PackedLinear(self.qkv.weight, self.qkv.bias), T.PackedLinear(self.proj.weight, self.proj.bias),
             self.relative_position_bias_table.detach().float().contiguous()))
 
+    def packed_fused(self, device, norm):
+        """LN1 + qkv + attention + proj in the fused kernel's format (``al3d_tok_attn_block_f16x3``; embed dim 96 / 192)."""
+        if getattr(self, "_pkf", None) is None:
+            object.__setattr__(self, "_pkf", _Packed())
+        return self._pkf.get(device, (self, self.qkv, self.proj, norm), lambda: T.PackedAttnBlock(
+            norm.weight.to(device), norm.bias.to(device), norm.eps, self.qkv.weight.to(device), self.qkv.bias,
+            self.proj.weight.to(device), self.proj.bias, self.relative_position_bias_table.to(device)))
+
 
 class ShiftWindowMSA(nn.Module):
     def __init__(self, embed_dims, num_heads, window_size, shift_size=0, qkv_bias=True, qk_scale=None):
@@ -93,6 +101,10 @@ class ShiftWindowMSA(nn.Module):
         self.w_msa = WindowMSA(embed_dims, num_heads, (window_size, window_size), qkv_bias, qk_scale)
 
 
+# AL3D_SWIN_ATTN=split: LN1 / qkv / attention / proj as four launches everywhere (default "fused": one kernel at the
+# embed dims it is built for -- stages 0-1, whose four launches are bound by the activation bytes they move)
+FUSED_ATTN = _os.environ.get("AL3D_SWIN_ATTN", "fused") != "split"
+FUSED_ATTN_DIMS = tuple(int(v) for v in _os.environ.get("AL3D_SWIN_ATTN_DIMS", "96,192").split(",") if v)
 # AL3D_SWIN_MLP=split: LN2 / fc1 / fc2 as three launches everywhere (default "fused": one kernel where it is faster)
 FUSED_MLP = _os.environ.get("AL3D_SWIN_MLP", "fused") != "split"
 # (embed dim 96 only: at 192 the kernel needs 255 registers and a 96 KB ring and measured slower than the three launches)
@@ -133,13 +145,17 @@ class SwinBlock(nn.Module):
     def forward(self, x, geom):
         """x [B * H * W, C] f32 token rows, updated IN PLACE; geom = _Geometry of the stage."""
         msa = self.attn.w_msa
-        rowmap, (nwy, nwx) = geom.window_map(self.attn.shift_size)
-        qkv_w, proj_w, table = msa.packed(x.device)
         n1, n2 = self.norm1, self.norm2
-        xw = T.layernorm(x, n1.weight, n1.bias, n1.eps, rowmap=rowmap, zero_out=True, pair=True)
-        qkv = T.linear(xw, qkv_w, a_pair=True)
-        ao = T.window_attention(qkv, table, msa.num_heads, nwy, nwx, self.attn.shift_size, msa.scale, pair=True)
-        T.linear(ao, proj_w, a_pair=True, residual=x, rowmap=rowmap, out=x)
+        if FUSED_ATTN and x.shape[-1] in FUSED_ATTN_DIMS:
+            # LN1 + qkv + attention + proj + residual as one kernel: q, k, v and the attention output stay on the CU
+            T.attn_block(x, geom.B, geom.H, geom.W, msa.packed_fused(x.device, n1), self.attn.shift_size, msa.scale)
+        else:
+            rowmap, (nwy, nwx) = geom.window_map(self.attn.shift_size)
+            qkv_w, proj_w, table = msa.packed(x.device)
+            xw = T.layernorm(x, n1.weight, n1.bias, n1.eps, rowmap=rowmap, zero_out=True, pair=True)
+            qkv = T.linear(xw, qkv_w, a_pair=True)
+            ao = T.window_attention(qkv, table, msa.num_heads, nwy, nwx, self.attn.shift_size, msa.scale, pair=True)
+            T.linear(ao, proj_w, a_pair=True, residual=x, rowmap=rowmap, out=x)
         if FUSED_MLP and x.shape[-1] in FUSED_MLP_DIMS:
             # stage 0: LN2 + fc1 + GELU + fc2 + residual as one kernel (the hidden activation stays in registers)
             T.mlp(x, self.ffn.packed_fused(x.device, n2))

@@ -67,6 +67,51 @@ class PackedMlp:
         self.bias1, self.bias2 = f(fc1_bias, hidden), f(fc2_bias, C)
 
 
+class PackedAttnBlock:
+    """LN1 + qkv + proj of a Swin block in the fused attention kernel's format (``al3d_tok_attn_block_f16x3``): per head
+    the MFMA fragments of its k, v, q rows of ``qkv.weight`` and of rows 32 h .. 32 h + 31 of ``proj.weight`` in lane
+    order, (wh, wl) planes, one power-of-two scale per matrix; LayerNorm parameters, biases and the relative position
+    bias table as f32 tensors."""
+
+    def __init__(self, norm_weight, norm_bias, eps, qkv_weight, qkv_bias, proj_weight, proj_bias, table):
+        wq = qkv_weight.detach().float().contiguous()            # [3C, C]: q | k | v rows
+        wp = proj_weight.detach().float().contiguous()           # [C, C]
+        C = wp.shape[0]
+        if C not in (96, 192) or tuple(wq.shape) != (3 * C, C) or tuple(wp.shape) != (C, C):
+            raise lib.Al3dError(f"PackedAttnBlock: C={C} (the fused kernel is built for 96 / 192), qkv {tuple(wq.shape)}")
+        H, KC = C // 32, C // 16
+        pq, sq = split_f16x3(wq.view(3 * C, 1, C))
+        pp, sp = split_f16x3(wp.view(C, 1, C))
+        # [plane, which, h, fr, kc, fh, e] -> [h, which (k, v, q), kc, plane, fh, fr, e]   (lane = fh * 32 + fr)
+        a = pq.view(2, 3, H, 32, KC, 2, 8)[:, [1, 2, 0]].permute(2, 1, 4, 0, 5, 3, 6)
+        b = pp.view(2, 1, H, 32, KC, 2, 8).permute(2, 1, 4, 0, 5, 3, 6)
+        self.image = torch.cat([a, b], dim=1).contiguous()
+        assert self.image.numel() * 2 == lib.load().al3d_tok_attn_block_image_bytes(C)
+        self.C, self.heads, self.eps = C, H, float(eps)
+        self.scale_qkv, self.scale_proj = float(sq[0]), float(sp[0])
+        dev = self.image.device
+        f = lambda v, n: (torch.zeros(n) if v is None else v.detach().float()).to(dev).contiguous()
+        self.gamma, self.beta = f(norm_weight, C), f(norm_bias, C)
+        self.bias_qkv, self.bias_proj = f(qkv_bias, 3 * C), f(proj_bias, C)
+        self.table = table.detach().float().to(dev).contiguous()
+        if tuple(self.table.shape) != (169, H):
+            raise lib.Al3dError(f"PackedAttnBlock: relative position bias table {tuple(self.table.shape)}, expected (169, {H})")
+
+
+def attn_block(x, B, H, W, packed, shift, scale):
+    """``x += proj(shifted_window_attention(LN(x)))`` in place on the f32 token rows ``[B * H * W, C]`` of ``B`` maps
+    (7 x 7 windows, cyclic shift ``shift``, padding to multiples of 7 after the norm; one launch)."""
+    x = _dev(x, torch.float32, "x")
+    if x.dim() != 2 or x.shape[-1] != packed.C:
+        raise lib.Al3dError(f"attn_block: x {tuple(x.shape)}, the weights have {packed.C} channels")
+    if x.shape[0] != B * H * W:
+        raise lib.Al3dError(f"attn_block: x has {x.shape[0]} rows, {B} maps of {H} x {W} need {B * H * W}")
+    lib.call("al3d_tok_attn_block_f16x3", _ptr(x), B, H, W, packed.C, int(shift), _ptr(packed.gamma), _ptr(packed.beta),
+             packed.eps, _ptr(packed.image), packed.scale_qkv, _ptr(packed.bias_qkv), packed.scale_proj,
+             _ptr(packed.bias_proj), _ptr(packed.table), float(scale), _stream())
+    return x
+
+
 def mlp(x, packed):
     """``x += fc2(gelu(fc1(LN(x))))`` in place on f32 token rows ``[T, 96]`` (one launch)."""
     x = _dev(x, torch.float32, "x")

@@ -673,7 +673,16 @@ int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const fl
  *   image (al3d_tok_mlp_image_bytes): per 32 hidden units t the MFMA A-operand fragments [64 lanes][8 halves] of
  *   fc1.weight[32t + lane%32][16kc + 8(lane/32) + e], kc < C/16, planes (wh, wl) of al3d_split_f16x3, then of
  *   fc2.weight[32u + lane%32][32t + 16q + 8(e/4) + 4(lane/32) + e%4], u < C/32, q < 2, planes (wh, wl);
- *   scale1 / scale2 = 2^-s of the two splits; bias1 [hidden], bias2 [C]; hidden % 32 == 0. */
+ *   scale1 / scale2 = 2^-s of the two splits; bias1 [hidden], bias2 [C]; hidden % 32 == 0.
+ * al3d_tok_attn_block_f16x3: the attention half of a block as one kernel, x += proj(W-MSA(LN(x))) in place on the B maps of
+ *   H x W token rows x [B*H*W][C], for C = 96 / 192 (stages 0-1: their LN1 / qkv / attention / proj launches are
+ *   bandwidth-bound; q, k, v and the attention output never exist in memory).  The cyclic shift by `shift`, the padding to
+ *   multiples of 7 (after the norm: a padded position is a zero row, a key like any other, never written back) and the
+ *   window partition are evaluated from the window's position; one workgroup per window, one wave per 32-channel head.
+ *   image (al3d_tok_attn_block_image_bytes): per head h the MFMA fragments [C/16][2 planes][64 lanes][8] of qkv.weight
+ *   rows C + 32h + lane%32 (k), 2C + 32h + lane%32 (v), 32h + lane%32 (q) and of proj.weight rows 32h + lane%32,
+ *   element = column 16kc + 8(lane/32) + e, planes (wh, wl) of al3d_split_f16x3 (one split per matrix: scale_qkv,
+ *   scale_proj = 2^-s); bias_qkv [3C], bias_proj [C]; table / shift / attn_scale as al3d_tok_window_attention_f32. */
 /* img [B][H][W][3] f32 -> patch rows [B*ceil(H/4)*ceil(W/4)][48], k = (ky*4 + kx)*3 + c, zeros beyond the image: the A
  * matrix of the 4x4 / stride-4 patch embedding (mmdet PatchEmbed: Conv2d(3, 96, 4, 4)) as a token GEMM with K = 48. */
 int al3d_tok_patch_rows_f32(const float* img, int B, int H, int W, int out_pair, float* out, void* stream);
@@ -682,6 +691,10 @@ int al3d_tok_layernorm_f32(const float* x, const int* rowmap, int64_t rows_out, 
 int64_t al3d_tok_mlp_image_bytes(int C, int hidden);
 int al3d_tok_mlp_f16x3(float* x, int64_t T, int C, int hidden, const float* gamma, const float* beta, float eps,
                        const void* image, float scale1, const float* bias1, float scale2, const float* bias2, void* stream);
+int64_t al3d_tok_attn_block_image_bytes(int C);
+int al3d_tok_attn_block_f16x3(float* x, int B, int H, int W, int C, int shift, const float* gamma, const float* beta,
+                              float eps, const void* image, float scale_qkv, const float* bias_qkv, float scale_proj,
+                              const float* bias_proj, const float* table, float attn_scale, void* stream);
 int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt_image, const float* scale, const float* bias,
                           int64_t M, int K, int N, int act, const float* residual, int ldr, const int* rowmap,
                           float* out, int ldc, int out_pair, void* stream);

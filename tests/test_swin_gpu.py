@@ -13,6 +13,8 @@ What is checked, kernel by kernel, through the C ABI:
     output levels / strides / channels for the BEVFusion configuration, and the camera branch Swin-T ->
     GeneralizedLSSFPN -> DepthLSSTransform end to end."""
 import numpy as np
+import copy
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -470,3 +472,96 @@ def test_fused_mlp_edge_cases():
         Tk.PackedMlp(mk(192), mk(192), 1e-5, mk(768, 192), mk(768), mk(192, 768), mk(192))      # built for C = 96
     with pytest.raises(lib.Al3dError):
         Tk.mlp(mk(8, 192), pk)
+
+
+def _attn_half_float64(x, hw, blk):
+    """x + W-MSA(LN1(x)) in float64 through the restatement's own pieces (pad after the norm, cyclic shift, 7 x 7
+    partition, region mask, relative position bias); the functions cast the module's parameters to x's dtype."""
+    import swin_torch as R
+    xd = x.double()
+    return xd + R.shift_window_msa(blk.attn, R._ln(blk.norm1, xd), hw)
+
+
+@pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 23, 96, 3, 3), (2, 14, 21, 96, 3, 0), (2, 9, 16, 192, 6, 3),
+                                                 (1, 7, 7, 192, 6, 0), (3, 20, 11, 96, 3, 3)])
+def test_fused_attention_half_matches_float64_and_the_split_path(B, H, W, C, heads, shift):
+    """``al3d_tok_attn_block_f16x3`` (LN1 + qkv + 7 x 7 window attention + proj + residual as one kernel: one workgroup per
+    window, one wave per head, q / k / v / attention output never in memory) against the same half block in float64 and
+    against the four-launch path (LayerNorm kernel, token GEMM, attention kernel, token GEMM with the scatter): not further
+    from float64 than 3x the four launches, within 1e-5 of the output scale; maps that need padding, shifted and
+    unshifted windows, both embed dims the kernel is built for."""
+    from al3d import token_ops as Tk
+    from al3d.models import swin as S
+    from al3d.synthetic import seed_modules_
+    blk = seed_modules_(S.SwinBlock(C, heads, 4 * C, 7, shift > 0), 23 + C + shift).to(DEV)
+    with torch.no_grad():                                  # LayerNorm parameters and biases away from their 1 / 0 defaults
+        g = torch.Generator().manual_seed(3)
+        blk.norm1.weight.copy_(torch.randn(C, generator=g) * 0.2 + 1.0)
+        blk.norm1.bias.copy_(torch.randn(C, generator=g) * 0.1)
+        blk.attn.w_msa.relative_position_bias_table.copy_(torch.randn(169, heads, generator=g) * 0.5)
+    msa, n1 = blk.attn.w_msa, blk.norm1
+    x = (torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(B + H)) * 1.3 + 0.2).to(DEV)
+    geom = S._Geometry.of(B, H, W, 7, torch.device(DEV))
+    rowmap, (nwy, nwx) = geom.window_map(blk.attn.shift_size)
+    with torch.no_grad():
+        ref = _attn_half_float64(x.view(B, H * W, C).cpu(), (H, W), copy.deepcopy(blk).cpu()).view(-1, C)
+        fused = Tk.attn_block(x.clone(), B, H, W, msa.packed_fused(x.device, n1), blk.attn.shift_size, msa.scale)
+        qkv_w, proj_w, table = msa.packed(x.device)
+        xs = x.clone()
+        xw = Tk.layernorm(xs, n1.weight, n1.bias, n1.eps, rowmap=rowmap, zero_out=True, pair=True)
+        ao = Tk.window_attention(Tk.linear(xw, qkv_w, a_pair=True), table, heads, nwy, nwx, blk.attn.shift_size, msa.scale, pair=True)
+        split = Tk.linear(ao, proj_w, a_pair=True, residual=xs, rowmap=rowmap, out=xs)
+    scale = float(ref.abs().max())
+    e_fused = float((fused.cpu().double() - ref).abs().max())
+    e_split = float((split.cpu().double() - ref).abs().max())
+    print("fused", e_fused / scale, "split", e_split / scale, "fused - split", float((fused - split).abs().max()) / scale)
+    assert e_fused <= 3.0 * e_split + 1e-7 * scale, (e_fused, e_split, scale)
+    assert e_fused <= 1e-5 * scale, (e_fused, scale)
+    assert float((fused - split).abs().max()) <= 4e-6 * scale
+
+
+def test_swin_block_fused_and_split_attention_agree():
+    """Whole blocks (both embed dims) with the fused attention half (default) against AL3D_SWIN_ATTN=split semantics."""
+    from al3d.models import swin as S
+    from al3d.synthetic import seed_modules_
+    for C, heads in ((96, 3), (192, 6)):
+        blk = seed_modules_(S.SwinBlock(C, heads, 4 * C, 7, shift=True), 5).to(DEV)
+        B, H, W = 2, 14, 21
+        x = torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(1)).to(DEV)
+        geom = S._Geometry.of(B, H, W, 7, torch.device(DEV))
+        saved = S.FUSED_ATTN
+        try:
+            with torch.no_grad():
+                S.FUSED_ATTN = True
+                a = blk(x.clone(), geom)
+                S.FUSED_ATTN = False
+                b = blk(x.clone(), geom)
+        finally:
+            S.FUSED_ATTN = saved
+        assert float((a - b).abs().max()) <= 4e-6 * float(b.abs().max())
+
+
+def test_fused_attention_half_edge_cases():
+    """No window at all; a non-finite token poisons its own window only (windows are independent workgroups); loud
+    failures for an embed dim the kernel is not built for and for a row count that does not match the maps."""
+    from al3d import lib, token_ops as Tk
+    from al3d.models import swin as S
+    from al3d.synthetic import seed_modules_
+    C, heads, B, H, W = 96, 3, 1, 14, 14
+    blk = seed_modules_(S.SwinBlock(C, heads, 4 * C, 7, False), 2).to(DEV)
+    pk = blk.attn.w_msa.packed_fused(torch.device(DEV), blk.norm1)
+    assert Tk.attn_block(torch.empty(0, C, device=DEV), 0, H, W, pk, 0, 32 ** -0.5).shape == (0, C)
+    x = torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(4)).to(DEV)
+    clean = Tk.attn_block(x.clone(), B, H, W, pk, 0, 32 ** -0.5)
+    bad = x.clone()
+    bad[3 * W + 2, 11] = float("nan")                       # token (3, 2): window (0, 0)
+    out = Tk.attn_block(bad, B, H, W, pk, 0, 32 ** -0.5)
+    win00 = torch.zeros(H, W, dtype=torch.bool)
+    win00[:7, :7] = True
+    win00 = win00.view(-1).to(DEV)
+    assert bool(torch.isnan(out[win00]).all()) and torch.equal(out[~win00], clean[~win00])
+    with pytest.raises(lib.Al3dError):
+        seed = seed_modules_(S.SwinBlock(384, 12, 1536, 7, False), 2).to(DEV)
+        seed.attn.w_msa.packed_fused(torch.device(DEV), seed.norm1)
+    with pytest.raises(lib.Al3dError):
+        Tk.attn_block(x.clone(), B, H, W + 1, pk, 0, 32 ** -0.5)

@@ -12,7 +12,7 @@ c=sqlite3.connect("$DB")
 rows=c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name").fetchall()
 acc={}
 for k,cn,n,s in rows:
-    if "tok_mlp" in k or "tok_linear_f16x3_kernel<3>" in k or "tok_window" in k:
+    if "tok_mlp" in k or "tok_attn_block" in k or "tok_window" in k:
         acc.setdefault(k[:45],{})[cn]=s/n
 for k,v in acc.items():
     w=v.get("SQ_WAVE_CYCLES",1)
