@@ -1124,41 +1124,31 @@ extern "C" int al3d_tok_mha16_f32(const float* q, int ldq, const float* k, int l
     return AL3D_OK;
 }
 
-// sum over the 16 lanes of a DPP row, every lane gets it: rotations by 8, 4, 2, 1 inside the row.  After the step by 8
-// lanes i and i ^ 8 hold equal values, so the lane a rotation reaches holds what lane i ^ step holds: the additions are
-// those of the __shfl_xor butterfly 8, 4, 2, 1 (tok_layernorm_kernel<16>), bit for bit, without the LDS crossbar.
-__device__ __forceinline__ float tk_row16_sum(float v)
-{
-#define TK_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
-    v += TK_ROR(8);
-    v += TK_ROR(4);
-    v += TK_ROR(2);
-    v += TK_ROR(1);
-#undef TK_ROR
-    return v;
-}
-
 // ------------------------------------------------------------------ fused attention half of a Swin block
 // x += proj(W-MSA(LN1(x))) as ONE kernel (C = 96 / 192, the two stages whose separate LN1 / qkv / attention / proj
 // launches are bound by the 44 C bytes per token they move; this kernel reads the window's rows once and writes them once:
-// 8 C).  One workgroup per 7 x 7 window, one wave per head:
+// 8 C).  Per 7 x 7 window, two waves per head:
 //   1. all waves: LayerNorm of the window's 49 rows, gathered arithmetically (cyclic shift + window partition + padding
-//      from the window's position: no row map; the stand-alone kernel's arithmetic, 16 lanes per row, all rows of a lane
-//      group requested before the first is reduced) -> pair rows (xh, xl') in LDS, padding and rows 49 .. 63 zero;
-//   2. wave h: K^T and Q^T tiles of its head as  W^T xn^T  (weights = A operand; tokens across the lanes, head channels
-//      down the accumulator registers) and V as  xn W  (head channel = lane, tokens down the registers).  In these
-//      orientations every accumulator IS the next product's operand after bias + split: K (A) and Q^T (B) of
-//      S^T = K Q^T share the register order of the head channels; V^T (A) of O^T = V^T P^T has the keys in the order
-//      P^T's rows come out of the softmax.  q, k, v never exist in memory;
-//   3. softmax down the registers with the relative position bias and the shifted-window mask exactly as
-//      tok_window_attention_kernel; O^T -> pair rows in LDS (natural channel order);
-//   4. wave w: output channels 32 w .. 32 w + 31 of  Wp^T O^T  for both token tiles, + bias + residual, written back to
-//      the rows the window came from.
-// The weights never touch LDS: each wave streams its own fragments (image per wave: parts k | v | q | proj, each
-// [C/16][2 planes][64 lanes][8], MFMA lane order) from L2 into a register ring of AB_D steps, one whole part ahead of
-// their use -- the first part is requested before the LayerNorm's rows.
-// f16x3 arithmetic as everywhere: weights x activations = three products into one accumulator, activations x activations
-// = main + 2^-11 correction accumulators.
+//      from the window's position: no row map) -> pair rows (xh, xl') in LDS; padding and rows 49 .. 63 are zero rows;
+//   2. wave (head, 0) forms K^T = Wk^T xn^T (weights = A operand; tokens across the lanes, head channels down the
+//      accumulator registers), wave (head, 1) forms V = xn Wv (head channel = lane, tokens down the registers), both token
+//      tiles each; in these orientations the accumulators ARE MFMA A fragments after bias + split (K for S^T = K Q^T, V^T
+//      for O^T = V^T P^T with the keys in the order P^T's rows leave the softmax), written to LDS lane-linear: 1 KB per
+//      (tile, channel step, plane), read back conflict-free.  Both waves form Q^T of their own query tile (registers).
+//      q, k, v never exist in memory;
+//   3. each wave: S^T, softmax down the registers (relative position bias from the table, shifted-window regions as a bit
+//      mask per query: no LDS, no branch per element), O^T of its query tile -> pair rows in LDS (over the normalised
+//      rows, dead after the barrier that publishes K and V);
+//   4. each wave: output channels 32 head .. + 31 of Wp^T O^T for its token tile, + bias + residual, written back to the
+//      rows the window came from.
+// The weights never touch LDS: each wave streams its fragments (image per head: parts k | v | q | proj, each
+// [C/16][2 planes][64 lanes][8], MFMA lane order) from L2 into a register ring AB_D2 steps ahead; the first steps are
+// requested before the LayerNorm's rows.  160 registers: three waves per SIMD.  A workgroup's waves are dealt to the four
+// SIMDs round-robin from SIMD 0, so a workgroup holds a multiple of four waves: twelve = one window at C = 192, TWO windows
+// at C = 96 (WPB).  f16x3 arithmetic as everywhere: weights x activations = three products into one accumulator,
+// activations x activations = main + 2^-11 correction accumulators.
+// (A first form -- one wave per head, K / V / both query tiles in registers, 256 registers, 1.5 waves per SIMD -- measured
+// 0.90 / 0.64 ms per launch at C = 96 / 192 against 0.80 / 0.51 for this one)
 struct TokAttnBlockParams {
     float* x;                // [B * H * W][C] residual stream, updated in place
     const _Float16* image;
@@ -1171,168 +1161,150 @@ struct TokAttnBlockParams {
     int B, H, W, nwy, nwx, shift;
 };
 
-#define AB_D 6               // ring depth in channel steps (2 fragments of 16 bytes per lane each)
-
-template <int C>
-__global__ __launch_bounds__(C * 2, 2) void tok_attn_block_f16x3_kernel(TokAttnBlockParams p)
+// the f16x3 split of 8 values with the packed conversions of sp_split8 (3 instructions per element instead of 5); the
+// inputs are pinned first (see tk_split: the high part and the residual must see the same rounded fp32 value)
+__device__ __forceinline__ void tk_split8p(float (&v)[8], f16x8& ph, f16x8& pl)
 {
-    constexpr int NH = C / 32, KC = C / 16, NTHR = NH * 64, PITCH = C * 4 + 16, NG = C / 8;
-    constexpr int RPP = NTHR / 16, NR = (TK_NT + RPP - 1) / RPP, NT = (NG + 15) / 16;
-    constexpr int NSTEP = 4 * KC;
-    static_assert(KC % AB_D == 0, "the ring holds a whole number of steps per part");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
+    uint4 hi, lo;
+    sp_split8(v, hi, lo);
+    ph = __builtin_bit_cast(f16x8, hi);
+    pl = __builtin_bit_cast(f16x8, lo);
+}
+// 13 y + x of key position min(key, 48) in the 7 x 7 window: the key's part of the relative position index
+__host__ __device__ constexpr int tk_kcode(int key) { return (key < TK_NT ? key : TK_NT - 1) + 6 * ((key < TK_NT ? key : TK_NT - 1) / TK_WS); }
+
+#define AB_D2 3              // ring depth of the two-wave form (registers: three waves per SIMD)
+
+template <int C, int WPB>
+__global__ __launch_bounds__(C * 4 * WPB, 3) void tok_attn_block_f16x3_kernel(TokAttnBlockParams p)
+{
+    constexpr int NH = C / 32, NWV = 2 * NH, KC = C / 16, NTHR = NWV * 64, PITCH = C * 4 + 16;
+    constexpr int LDSW = 64 * PITCH + NH * 16384 + NH * 176 * 4 + NWV * 128 * 4;       // bytes of LDS per window
+    constexpr int NSTEP = 3 * KC;                         // this wave's stream: k or v | q | proj
+    static_assert(KC % AB_D2 == 0, "the ring holds a whole number of steps per part");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ab_smem[];
-    unsigned char* xn = ab_smem;                          // 64 pair rows (pitch + 16 B: conflict-free fragment reads)
-    unsigned char* ob = ab_smem + 64 * PITCH;             // 64 pair rows of attention output
-    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int lw = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR);          // window of this workgroup
+    unsigned char* xn = ab_smem + lw * LDSW;              // 64 pair rows; after barrier 2: the attention output
+    unsigned char* kb = xn + 64 * PITCH;                  // [head][tile][step s][plane][64 lanes][16 B]
+    unsigned char* vb = kb + NH * 8192;
+    const int tid = threadIdx.x - lw * NTHR, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* tbl = reinterpret_cast<float*>(ab_smem + 128 * PITCH) + wave * 176;
-    // this wave's bias rows k | q | proj | v (32 each): staged once, so that no global load sits between the weight stream's
-    // requests and their use (vmcnt retires in order: a bias load issued after a refill would wait for it)
-    float* bsm = reinterpret_cast<float*>(ab_smem + 128 * PITCH + NH * 176 * 4) + wave * 128;
-    const int win = blockIdx.x;
+    const int hd = wave >> 1, role = wave & 1;            // role = 0: forms K; 1: forms V; also this wave's query / token tile
+    float* tbl = reinterpret_cast<float*>(vb + NH * 8192) + hd * 176;
+    float* bsm = reinterpret_cast<float*>(vb + NH * 8192 + NH * 176 * 4) + wave * 128;      // k | q | proj | v rows of this head
+    const int nwin = p.B * p.nwy * p.nwx;
+    const bool live = (int)blockIdx.x * WPB + lw < nwin;   // the last workgroup of an odd window count runs one window dry
+    const int win = live ? blockIdx.x * WPB + lw : nwin - 1;
     const int wi = win % (p.nwy * p.nwx), b = win / (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
-    // token row of window position `row` (ty, tx), or -1 for padding: shifted[hp] = padded[(hp + shift) % Hp]
     auto token_of = [&](int row) __attribute__((always_inline)) -> int {
         const int ty = row / TK_WS, tx = row - ty * TK_WS;
         int hs = wy * TK_WS + ty + p.shift, ws = wx * TK_WS + tx + p.shift;
         hs -= hs >= p.nwy * TK_WS ? p.nwy * TK_WS : 0;
         ws -= ws >= p.nwx * TK_WS ? p.nwx * TK_WS : 0;
-        return row < TK_NT && hs < p.H && ws < p.W ? (b * p.H + hs) * p.W + ws : -1;
+        return live && row < TK_NT && hs < p.H && ws < p.W ? (b * p.H + hs) * p.W + ws : -1;
     };
 
-    // ---- the weight stream: step g = (part, channel step); fragments of step g live in ring slot g % AB_D
-    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.image) + (size_t)wave * (NSTEP * 2048) + lane * 16;
-    f16x8 rwh[AB_D], rwl[AB_D];
+    // ---- the weight stream of this wave: steps [0, KC) = k or v part, [KC, 2 KC) = q, [2 KC, 3 KC) = proj
+    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(p.image) + (size_t)hd * (4 * KC * 2048) + lane * 16;
+    f16x8 rwh[AB_D2], rwl[AB_D2];
     auto issue = [&](int g) __attribute__((always_inline)) {
         if (g < NSTEP) {
-            rwh[g % AB_D] = *reinterpret_cast<const f16x8*>(wimg + g * 2048);
-            rwl[g % AB_D] = *reinterpret_cast<const f16x8*>(wimg + g * 2048 + 1024);
+            const int f = g < KC ? role * KC + g : g + KC;           // image parts: k | v | q | proj
+            rwh[g % AB_D2] = *reinterpret_cast<const f16x8*>(wimg + f * 2048);
+            rwl[g % AB_D2] = *reinterpret_cast<const f16x8*>(wimg + f * 2048 + 1024);
         }
     };
 #pragma unroll
-    for (int g = 0; g < AB_D; ++g) issue(g);
+    for (int g = 0; g < AB_D2; ++g) issue(g);
 
-    for (int t = lane; t < 169; t += 64) tbl[t] = p.table[t * NH + wave];
+    if (role == 0)
+        for (int t = lane; t < 169; t += 64) tbl[t] = p.table[t * NH + hd];
     {
         const int part = lane >> 5;                        // lanes 0-31: k, proj; 32-63: q, v
-        bsm[lane] = p.bias_qkv[(part == 0 ? C : 0) + 32 * wave + fr];
-        bsm[64 + lane] = part == 0 ? p.bias_proj[32 * wave + fr] : p.bias_qkv[2 * C + 32 * wave + fr];
+        bsm[lane] = p.bias_qkv[(part == 0 ? C : 0) + 32 * hd + fr];
+        bsm[64 + lane] = part == 0 ? p.bias_proj[32 * hd + fr] : p.bias_qkv[2 * C + 32 * hd + fr];
     }
-    // shifted-window regions of the window's 7 rows / 7 columns, two bits each (uniform): tokens attend inside a region
     int rycode = 0, rxcode = 0;
     if (p.shift > 0)
         for (int t = 0; t < TK_WS; ++t) {
             rycode |= tk_region1(wy * TK_WS + t, p.nwy * TK_WS, p.shift) << (2 * t);
             rxcode |= tk_region1(wx * TK_WS + t, p.nwx * TK_WS, p.shift) << (2 * t);
         }
-    // ---- 1. LayerNorm (tok_layernorm_kernel<16>'s arithmetic: same sums, same shuffles)
+    // ---- 1. LayerNorm: C / 24 lanes per row (4 or 8), three groups of 8 channels per lane, every row of the window in one
+    // pass (the per-row work -- token index, divisions, root -- is then done by 4 or 8 lanes, not by 16 for three passes);
+    // rows 49 .. 63 and padding positions come out as zero rows: keys with zero weight, finite values
     {
-        const int sub = tid & 15, grp = tid >> 4;
-        float v[NR][NT][8];
-        int src[NR];
+        constexpr int LPR = C / 24;
+        static_assert(NTHR / LPR >= 64, "one pass covers the 64 rows of the tile");
+        const int sub = tid % LPR, row = tid / LPR;
+        const int src = token_of(row);
+        float v[3][8];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int row = grp + i * RPP;
-            src[i] = token_of(row);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int g = sub + 16 * t;
-                // unconditional (clamped) loads, zeroed afterwards: a load inside a branch would be waited for inside it,
-                // one memory round trip per row instead of one for all
-                const bool ok = src[i] >= 0 && g < NG;
-                const float* s = p.x + (int64_t)(ok ? src[i] : 0) * C + 8 * (ok ? g : 0);
-                const float4 a = *reinterpret_cast<const float4*>(s), b4 = *reinterpret_cast<const float4*>(s + 4);
-                v[i][t][0] = ok ? a.x : 0.f; v[i][t][1] = ok ? a.y : 0.f; v[i][t][2] = ok ? a.z : 0.f; v[i][t][3] = ok ? a.w : 0.f;
-                v[i][t][4] = ok ? b4.x : 0.f; v[i][t][5] = ok ? b4.y : 0.f; v[i][t][6] = ok ? b4.z : 0.f; v[i][t][7] = ok ? b4.w : 0.f;
-            }
+        for (int t = 0; t < 3; ++t) {
+            const int g = sub + LPR * t;
+            const float* s = p.x + (int64_t)(src < 0 ? 0 : src) * C + 8 * g;          // unconditional (clamped) loads
+            const float4 a = *reinterpret_cast<const float4*>(s), b4 = *reinterpret_cast<const float4*>(s + 4);
+            v[t][0] = a.x; v[t][1] = a.y; v[t][2] = a.z; v[t][3] = a.w; v[t][4] = b4.x; v[t][5] = b4.y; v[t][6] = b4.z; v[t][7] = b4.w;
         }
-        for (int i = tid; i < (64 - TK_NT) * PITCH / 16; i += NTHR)          // rows 49 .. 63: keys with zero weight, finite values
-            *reinterpret_cast<uint4*>(xn + TK_NT * PITCH + i * 16) = make_uint4(0u, 0u, 0u, 0u);
-        float ga[NT][8], be[NT][8];
+        float ga[3][8], be[3][8];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int g = sub + 16 * t < NG ? sub + 16 * t : 0;
+        for (int t = 0; t < 3; ++t) {
+            const int g = sub + LPR * t;
             const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + 8 * g), g1 = *reinterpret_cast<const float4*>(p.gamma + 8 * g + 4);
             const float4 b0 = *reinterpret_cast<const float4*>(p.beta + 8 * g), b1 = *reinterpret_cast<const float4*>(p.beta + 8 * g + 4);
             ga[t][0] = g0.x; ga[t][1] = g0.y; ga[t][2] = g0.z; ga[t][3] = g0.w; ga[t][4] = g1.x; ga[t][5] = g1.y; ga[t][6] = g1.z; ga[t][7] = g1.w;
             be[t][0] = b0.x; be[t][1] = b0.y; be[t][2] = b0.z; be[t][3] = b0.w; be[t][4] = b1.x; be[t][5] = b1.y; be[t][6] = b1.z; be[t][7] = b1.w;
         }
+        // sum over the row's LPR adjacent lanes: quad exchanges, then (8 lanes) the mirrored half row, whose lanes all hold
+        // their quad's sum by then
+        auto rowsum = [](float x) __attribute__((always_inline)) -> float {
+#define TK_DPP(ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+            x += TK_DPP(0xb1);                               // quad_perm [1, 0, 3, 2]
+            x += TK_DPP(0x4e);                               // quad_perm [2, 3, 0, 1]
+            if (LPR == 8) x += TK_DPP(0x141);                // row_half_mirror
+#undef TK_DPP
+            return x;
+        };
+        float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int row = grp + i * RPP;
-            float sum = 0.f;
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int e = 0; e < 8; ++e) sum += v[t][e];
+        const float mean = rowsum(sum) / (float)C;
+        float sq = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sum += v[i][t][e];
-            sum = tk_row16_sum(sum);
-            const float mean = sum / (float)C;
-            float sq = 0.f;
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (sub + 16 * t >= NG) continue;
+            for (int e = 0; e < 8; ++e) { const float d = v[t][e] - mean; sq += d * d; }
+        const float rstd = 1.0f / sqrtf(rowsum(sq) / (float)C + p.eps);
+        if (row < 64) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v[i][t][e] - mean; sq += d * d; }
-            }
-            sq = tk_row16_sum(sq);
-            const float rstd = 1.0f / sqrtf(sq / (float)C + p.eps);
-            if (row >= TK_NT) continue;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int g = sub + 16 * t;
-                if (g >= NG) continue;
+            for (int t = 0; t < 3; ++t) {
+                const int g = sub + LPR * t;
                 float y[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = src[i] < 0 ? 0.f : ((v[i][t][e] - mean) * rstd) * ga[t][e] + be[t][e];
+                for (int e = 0; e < 8; ++e) y[e] = src < 0 ? 0.f : ((v[t][e] - mean) * rstd) * ga[t][e] + be[t][e];
                 uint4 hi, lo;
                 sp_split8(y, hi, lo);
-                *reinterpret_cast<uint4*>(xn + row * PITCH + g * 32) = hi;
-                *reinterpret_cast<uint4*>(xn + row * PITCH + g * 32 + 16) = lo;
+                uint4* o = reinterpret_cast<uint4*>(__builtin_assume_aligned(xn + row * PITCH + g * 32, 16));
+                o[0] = hi;
+                o[1] = lo;
             }
         }
     }
     __syncthreads();
 
-    // ---- 2. this head's K, V, Q (both token tiles each)
-    auto xfrag = [&](const unsigned char* buf, int t, int kc, f16x8& xh, f16x8& xl) __attribute__((always_inline)) {
-        const unsigned char* s = buf + (32 * t + fr) * PITCH + (2 * kc + fh) * 32;
+    auto xfrag = [&](int t, int kc, f16x8& xh, f16x8& xl) __attribute__((always_inline)) {
+        const unsigned char* s = xn + (32 * t + fr) * PITCH + (2 * kc + fh) * 32;
         xh = *reinterpret_cast<const f16x8*>(s);
         xl = *reinterpret_cast<const f16x8*>(s + 16);
-    };
-    // weights x activations over the C / 16 channel steps of stream part `part`; WA: the weights are the A operand
-    // (transposed product).  The step's ring slot is refilled with the fragments AB_D steps later.
-    auto gemm2 = [&](int part, const unsigned char* buf, bool WA, bool refill, f32x16& a0, f32x16& a1) __attribute__((always_inline)) {
-        f16x8 fx[2][4];                                     // [parity of the step][tile 0 h, l, tile 1 h, l]: read one step ahead
-        xfrag(buf, 0, 0, fx[0][0], fx[0][1]);
-        xfrag(buf, 1, 0, fx[0][2], fx[0][3]);
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const int g = part * KC + kc;
-            const f16x8 wh = rwh[g % AB_D], wl = rwl[g % AB_D];
-            const f16x8 wd = tk_lift_down(wh);
-            if (kc + 1 < KC) {
-                xfrag(buf, 0, kc + 1, fx[(kc + 1) & 1][0], fx[(kc + 1) & 1][1]);
-                xfrag(buf, 1, kc + 1, fx[(kc + 1) & 1][2], fx[(kc + 1) & 1][3]);
-            }
-            const f16x8 xh0 = fx[kc & 1][0], xl0 = fx[kc & 1][1], xh1 = fx[kc & 1][2], xl1 = fx[kc & 1][3];
-            if (WA) {
-                a0 = TK_MFMA(wd, xl0, a0); a1 = TK_MFMA(wd, xl1, a1);
-                a0 = TK_MFMA(wl, xh0, a0); a1 = TK_MFMA(wl, xh1, a1);
-                a0 = TK_MFMA(wh, xh0, a0); a1 = TK_MFMA(wh, xh1, a1);
-            } else {
-                a0 = TK_MFMA(xl0, wd, a0); a1 = TK_MFMA(xl1, wd, a1);
-                a0 = TK_MFMA(xh0, wl, a0); a1 = TK_MFMA(xh1, wl, a1);
-                a0 = TK_MFMA(xh0, wh, a0); a1 = TK_MFMA(xh1, wh, a1);
-            }
-            if (refill || g + AB_D < (part + 1) * KC) issue(g + AB_D);     // !refill: the next part is requested later
-            __builtin_amdgcn_sched_barrier(0);             // the request stays HERE (hipcc otherwise sinks it to its use)
-        }
     };
     auto zero16 = [](f32x16& a) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.f;
     };
-    // bias of the accumulator's 16 rows: head channel (r & 3) + 8 (r >> 2) + 4 fh
     auto bias16 = [&](const float* bsrc, float (&o)[16]) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1340,113 +1312,141 @@ __global__ __launch_bounds__(C * 2, 2) void tok_attn_block_f16x3_kernel(TokAttnB
             o[4 * g] = b4.x; o[4 * g + 1] = b4.y; o[4 * g + 2] = b4.z; o[4 * g + 3] = b4.w;
         }
     };
-
-    f16x8 kh[2][2], kl[2][2], vh[2][2], vl[2][2], qh[2][2], ql[2][2];
+    // ---- 2a. K (role 0) or V (role 1) of both token tiles -> LDS as A fragments
     {
         f32x16 a0, a1;
         zero16(a0); zero16(a1);
-        gemm2(0, xn, true, true, a0, a1);
+        auto kv_loop = [&](auto wa) __attribute__((always_inline)) {      // wa: the weights are the A operand (K^T = Wk^T xn^T); else V = xn Wv
+            constexpr bool WA = decltype(wa)::value;
+            f16x8 fx[2][4];
+            xfrag(0, 0, fx[0][0], fx[0][1]);
+            xfrag(1, 0, fx[0][2], fx[0][3]);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const f16x8 wh = rwh[kc % AB_D2], wl = rwl[kc % AB_D2];
+                const f16x8 wd = tk_lift_down(wh);
+                if (kc + 1 < KC) {
+                    xfrag(0, kc + 1, fx[(kc + 1) & 1][0], fx[(kc + 1) & 1][1]);
+                    xfrag(1, kc + 1, fx[(kc + 1) & 1][2], fx[(kc + 1) & 1][3]);
+                }
+                const f16x8 xh0 = fx[kc & 1][0], xl0 = fx[kc & 1][1], xh1 = fx[kc & 1][2], xl1 = fx[kc & 1][3];
+                if constexpr (WA) {
+                    a0 = TK_MFMA(wd, xl0, a0); a1 = TK_MFMA(wd, xl1, a1);
+                    a0 = TK_MFMA(wl, xh0, a0); a1 = TK_MFMA(wl, xh1, a1);
+                    a0 = TK_MFMA(wh, xh0, a0); a1 = TK_MFMA(wh, xh1, a1);
+                } else {
+                    a0 = TK_MFMA(xl0, wd, a0); a1 = TK_MFMA(xl1, wd, a1);
+                    a0 = TK_MFMA(xh0, wl, a0); a1 = TK_MFMA(xh1, wl, a1);
+                    a0 = TK_MFMA(xh0, wh, a0); a1 = TK_MFMA(xh1, wh, a1);
+                }
+                issue(kc + AB_D2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (role == 0) kv_loop(std::true_type{});
+        else kv_loop(std::false_type{});
         float bk[16];
         bias16(bsm, bk);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float v0[8], v1[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v0[e] = a0[8 * s + e] * p.scale_qkv + bk[8 * s + e];
-                v1[e] = a1[8 * s + e] * p.scale_qkv + bk[8 * s + e];
-            }
-            tk_split8(v0, kh[0][s], kl[0][s]);
-            tk_split8(v1, kh[1][s], kl[1][s]);
-        }
-    }
-    {
-        f32x16 a0, a1;
-        zero16(a0); zero16(a1);
-        gemm2(1, xn, false, true, a0, a1);
         const float bv = bsm[96 + fr];
+        unsigned char* dstb = (role == 0 ? kb : vb) + hd * 8192 + lane * 16;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float v0[8], v1[8];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v0[e] = a0[8 * s + e] * p.scale_qkv + bv;
-                v1[e] = a1[8 * s + e] * p.scale_qkv + bv;
+            for (int s = 0; s < 2; ++s) {
+                const f32x16& a = t == 0 ? a0 : a1;
+                float vv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = a[8 * s + e] * p.scale_qkv + (role == 0 ? bk[8 * s + e] : bv);
+                f16x8 oh, ol;
+                tk_split8p(vv, oh, ol);
+                *reinterpret_cast<f16x8*>(dstb + ((t * 2 + s) * 2) * 1024) = oh;
+                *reinterpret_cast<f16x8*>(dstb + ((t * 2 + s) * 2 + 1) * 1024) = ol;
             }
-            tk_split8(v0, vh[0][s], vl[0][s]);
-            tk_split8(v1, vh[1][s], vl[1][s]);
-        }
     }
+    // ---- 2b. Q^T of this wave's query tile
+    f16x8 qh[2], ql[2];
     {
-        f32x16 a0, a1;
-        zero16(a0); zero16(a1);
-        gemm2(2, xn, true, false, a0, a1);
+        f32x16 aq;
+        zero16(aq);
+        f16x8 fx[2][2];
+        xfrag(role, 0, fx[0][0], fx[0][1]);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int g = KC + kc;
+            const f16x8 wh = rwh[g % AB_D2], wl = rwl[g % AB_D2];
+            const f16x8 wd = tk_lift_down(wh);
+            if (kc + 1 < KC) xfrag(role, kc + 1, fx[(kc + 1) & 1][0], fx[(kc + 1) & 1][1]);
+            aq = TK_MFMA(wd, fx[kc & 1][1], aq);
+            aq = TK_MFMA(wl, fx[kc & 1][0], aq);
+            aq = TK_MFMA(wh, fx[kc & 1][0], aq);
+            if (g + AB_D2 < 2 * KC) issue(g + AB_D2);          // the projection's fragments are requested after the attention
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float bq[16];
         bias16(bsm + 32, bq);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            float v0[8], v1[8];
+            float vv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v0[e] = (a0[8 * s + e] * p.scale_qkv + bq[8 * s + e]) * p.scale;
-                v1[e] = (a1[8 * s + e] * p.scale_qkv + bq[8 * s + e]) * p.scale;
-            }
-            tk_split8(v0, qh[0][s], ql[0][s]);
-            tk_split8(v1, qh[1][s], ql[1][s]);
+            for (int e = 0; e < 8; ++e) vv[e] = (aq[8 * s + e] * p.scale_qkv + bq[8 * s + e]) * p.scale;
+            tk_split8p(vv, qh[s], ql[s]);
         }
     }
-    // ---- 3. per query tile: S^T, softmax, O^T
-    const bool masked = p.shift > 0;
-#pragma unroll 1
-    for (int j = 0; j < 2; ++j) {                            // a real loop: a tile's logits and outputs are live in one iteration only
-        const int query = 32 * j + fr;
-        f16x8 qhj[2], qlj[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { qhj[s] = j ? qh[1][s] : qh[0][s]; qlj[s] = j ? ql[1][s] : ql[0][s]; }
+    __syncthreads();                                         // K and V are in LDS; the normalised rows are dead
+
+    // ---- 3. S^T, softmax, O^T of query tile `role`
+    {
+        const bool masked = p.shift > 0;
+        const int query = 32 * role + fr;
         f32x16 sm[2], sc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { zero16(sm[i]); zero16(sc[i]); }
+        const unsigned char* kf = kb + hd * 8192 + lane * 16;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                sc[i] = TK_MFMA(kl[i][s], qhj[s], sc[i]);
-                sc[i] = TK_MFMA(kh[i][s], qlj[s], sc[i]);
-                sm[i] = TK_MFMA(kh[i][s], qhj[s], sm[i]);
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kf + ((i * 2 + s) * 2) * 1024);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kf + ((i * 2 + s) * 2 + 1) * 1024);
+                sc[i] = TK_MFMA(kl, qh[s], sc[i]);
+                sc[i] = TK_MFMA(kh, ql[s], sc[i]);
+                sm[i] = TK_MFMA(kh, qh[s], sm[i]);
             }
         const int qq = query < TK_NT ? query : TK_NT - 1;
         const int qy = (qq * 37) >> 8, qx = qq - TK_WS * qy;
         const int qcode = qq + 6 * qy + 84;                          // 13 y + x + 84
-        // bit k of `same`: key k lies in this query's region (all ones without a shift).  No LDS, no branch per element:
-        // the per-element form (a region lookup behind `if (masked)`) made hipcc serialise 64 LDS round trips per tile
-        unsigned long long same = ~0ull;
+        // bit k of `diff`: key k lies in ANOTHER shifted-window region than this query (-100 on its logit)
+        unsigned dlo = 0u, dhi = 0u;
         if (masked) {
             const int myry = (rycode >> (2 * qy)) & 3, myrx = (rxcode >> (2 * qx)) & 3;
             unsigned colmask = 0u;
-            same = 0ull;
+            unsigned long long same = 0ull;
 #pragma unroll
             for (int t = 0; t < TK_WS; ++t) colmask |= (unsigned)(((rxcode >> (2 * t)) & 3) == myrx) << t;
 #pragma unroll
             for (int t = 0; t < TK_WS; ++t)
                 if (((rycode >> (2 * t)) & 3) == myry) same |= (unsigned long long)colmask << (TK_WS * t);
+            const unsigned long long diff = ~same >> (4 * fh);       // the lane's keys are c + 4 fh with compile-time c
+            dlo = (unsigned)diff;
+            dhi = (unsigned)(diff >> 32);
         }
+        const float* tq = tbl + qcode;
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float tb[16];                                            // the tile's 16 bias lookups first, then their uses
+            float tb[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const int kk = key < TK_NT ? key : TK_NT - 1;
-                tb[r] = tbl[qcode - (kk + 6 * ((kk * 37) >> 8))];
+                const int c = 32 * i + (r & 3) + 8 * (r >> 2);       // key = c + 4 fh
+                tb[r] = tq[-(fh ? tk_kcode(c + 4) : tk_kcode(c))];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int c = 32 * i + (r & 3) + 8 * (r >> 2);
                 float v = sm[i][r] + sc[i][r] * 0.00048828125f;
                 v += tb[r];
-                v += ((same >> key) & 1ull) ? 0.0f : -100.0f;
-                v = key < TK_NT ? v : -INFINITY;
+                if (masked) v += (float)(((c < 32 ? dlo : dhi) >> (c & 31)) & 1u) * -100.0f;
+                if (c + 4 >= TK_NT) v = (c >= TK_NT || fh) ? -INFINITY : v;
                 sm[i][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -1467,21 +1467,23 @@ __global__ __launch_bounds__(C * 2, 2) void tok_attn_block_f16x3_kernel(TokAttnB
         const float inv = 1.0f / sum;
         f32x16 om, oc;
         zero16(om); zero16(oc);
+        const unsigned char* vf = vb + hd * 8192 + lane * 16;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(vf + ((i * 2 + s) * 2) * 1024);
+                const f16x8 vl = *reinterpret_cast<const f16x8*>(vf + ((i * 2 + s) * 2 + 1) * 1024);
                 float pv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pv[e] = sm[i][8 * s + e];
                 f16x8 ph, pl;
-                tk_split8(pv, ph, pl);
-                oc = TK_MFMA(vl[i][s], ph, oc);
-                oc = TK_MFMA(vh[i][s], pl, oc);
-                om = TK_MFMA(vh[i][s], ph, om);
+                tk_split8p(pv, ph, pl);
+                oc = TK_MFMA(vl, ph, oc);
+                oc = TK_MFMA(vh, pl, oc);
+                om = TK_MFMA(vh, ph, om);
             }
-        // rows of O^T are head channels (r & 3) + 8 (r >> 2) + 4 fh: a register quad = four consecutive channels
-        unsigned char* orow = ob + query * PITCH + (4 * wave) * 32;
+        unsigned char* orow = xn + query * PITCH + (4 * hd) * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             _Float16 hh[4], ll[4];
@@ -1493,36 +1495,42 @@ __global__ __launch_bounds__(C * 2, 2) void tok_attn_block_f16x3_kernel(TokAttnB
             *reinterpret_cast<uint2*>(orow + g * 32 + 16 + 8 * fh) = __builtin_bit_cast(uint2, vl4);
         }
     }
-    // the projection's fragments (not held across the attention: registers) and the residual pieces this lane will add to:
-    // requested before the barrier
 #pragma unroll
-    for (int g = 3 * KC; g < 3 * KC + AB_D; ++g) issue(g);
-    int dst[2];
-    float4 rs[2][4];
+    for (int g = 2 * KC; g < 2 * KC + AB_D2; ++g) issue(g);
+    const int dst = token_of(32 * role + fr);
+    float4 rs[4];
+    {
+        const float* xr = p.x + (int64_t)(dst < 0 ? 0 : dst) * C + 32 * hd + 4 * fh;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        dst[t] = token_of(32 * t + fr);
-        const float* xr = p.x + (int64_t)(dst[t] < 0 ? 0 : dst[t]) * C + 32 * wave + 4 * fh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) rs[t][g] = *reinterpret_cast<const float4*>(xr + 8 * g);
+        for (int g = 0; g < 4; ++g) rs[g] = *reinterpret_cast<const float4*>(xr + 8 * g);
     }
     __syncthreads();
 
-    // ---- 4. output channels 32 wave .. + 31 of the projection, both token tiles; + bias + residual
+    // ---- 4. output channels 32 hd .. + 31 of the projection for token tile `role`
     {
-        f32x16 a0, a1;
-        zero16(a0); zero16(a1);
-        gemm2(3, ob, true, false, a0, a1);
+        f32x16 a;
+        zero16(a);
+        f16x8 fx[2][2];
+        xfrag(role, 0, fx[0][0], fx[0][1]);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int g = 2 * KC + kc;
+            const f16x8 wh = rwh[g % AB_D2], wl = rwl[g % AB_D2];
+            const f16x8 wd = tk_lift_down(wh);
+            if (kc + 1 < KC) xfrag(role, kc + 1, fx[(kc + 1) & 1][0], fx[(kc + 1) & 1][1]);
+            a = TK_MFMA(wd, fx[kc & 1][1], a);
+            a = TK_MFMA(wl, fx[kc & 1][0], a);
+            a = TK_MFMA(wh, fx[kc & 1][0], a);
+            issue(g + AB_D2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float bp[16];
         bias16(bsm + 64, bp);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (dst[t] < 0) continue;
-            float* xr = p.x + (int64_t)dst[t] * C + 32 * wave + 4 * fh;
-            const f32x16& a = t == 0 ? a0 : a1;
+        if (dst >= 0) {
+            float* xr = p.x + (int64_t)dst * C + 32 * hd + 4 * fh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 r4 = rs[t][g];
+                float4 r4 = rs[g];
                 float y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = a[4 * g + e] * p.scale_proj + bp[4 * g + e];
@@ -1552,18 +1560,18 @@ extern "C" int al3d_tok_attn_block_f16x3(float* x, int B, int H, int W, int C, i
     TokAttnBlockParams p{x, (const _Float16*)image, gamma, beta, bias_qkv, bias_proj, table, eps, scale_qkv, scale_proj,
                          attn_scale, B, H, W, nwy, nwx, shift};
     const int NH = C / 32;
-    const size_t lds = (size_t)128 * (C * 4 + 16) + (size_t)NH * (176 + 128) * 4;
+    const size_t lds = (size_t)64 * (C * 4 + 16) + (size_t)NH * 16384 + (size_t)NH * 176 * 4 + (size_t)NH * 2 * 128 * 4;   // per window
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)tok_attn_block_f16x3_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)tok_attn_block_f16x3_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)tok_attn_block_f16x3_kernel<96, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)tok_attn_block_f16x3_kernel<192, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return al3d_fail(AL3D_ELAUNCH, "al3d_tok_attn_block_f16x3: cannot raise the dynamic LDS limit");
         attr = true;
     }
     hipStream_t s = (hipStream_t)stream;
     const unsigned nwin = (unsigned)(B * nwy * nwx);
-    if (C == 96) hipLaunchKernelGGL(tok_attn_block_f16x3_kernel<96>, dim3(nwin), dim3(192), lds, s, p);
-    else hipLaunchKernelGGL(tok_attn_block_f16x3_kernel<192>, dim3(nwin), dim3(384), lds, s, p);
+    if (C == 96) hipLaunchKernelGGL((tok_attn_block_f16x3_kernel<96, 2>), dim3((nwin + 1) / 2), dim3(768), 2 * lds, s, p);
+    else hipLaunchKernelGGL((tok_attn_block_f16x3_kernel<192, 1>), dim3(nwin), dim3(768), lds, s, p);
     AL3D_CHECK_LAUNCH("tok_attn_block_f16x3_kernel");
     return AL3D_OK;
 }

@@ -678,7 +678,7 @@ int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const fl
  *   H x W token rows x [B*H*W][C], for C = 96 / 192 (stages 0-1: their LN1 / qkv / attention / proj launches are
  *   bandwidth-bound; q, k, v and the attention output never exist in memory).  The cyclic shift by `shift`, the padding to
  *   multiples of 7 (after the norm: a padded position is a zero row, a key like any other, never written back) and the
- *   window partition are evaluated from the window's position; one workgroup per window, one wave per 32-channel head.
+ *   window partition are evaluated from the window's position; two waves per (window, 32-channel head).
  *   image (al3d_tok_attn_block_image_bytes): per head h the MFMA fragments [C/16][2 planes][64 lanes][8] of qkv.weight
  *   rows C + 32h + lane%32 (k), 2C + 32h + lane%32 (v), 32h + lane%32 (q) and of proj.weight rows 32h + lane%32,
  *   element = column 16kc + 8(lane/32) + e, planes (wh, wl) of al3d_split_f16x3 (one split per matrix: scale_qkv,

@@ -483,13 +483,15 @@ def _attn_half_float64(x, hw, blk):
 
 
 @pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 23, 96, 3, 3), (2, 14, 21, 96, 3, 0), (2, 9, 16, 192, 6, 3),
-                                                 (1, 7, 7, 192, 6, 0), (3, 20, 11, 96, 3, 3)])
+                                                 (1, 7, 7, 192, 6, 0), (3, 20, 11, 96, 3, 3), (1, 7, 20, 96, 3, 3),
+                                                 (1, 5, 6, 96, 3, 0)])
 def test_fused_attention_half_matches_float64_and_the_split_path(B, H, W, C, heads, shift):
-    """``al3d_tok_attn_block_f16x3`` (LN1 + qkv + 7 x 7 window attention + proj + residual as one kernel: one workgroup per
-    window, one wave per head, q / k / v / attention output never in memory) against the same half block in float64 and
-    against the four-launch path (LayerNorm kernel, token GEMM, attention kernel, token GEMM with the scatter): not further
-    from float64 than 3x the four launches, within 1e-5 of the output scale; maps that need padding, shifted and
-    unshifted windows, both embed dims the kernel is built for."""
+    """``al3d_tok_attn_block_f16x3`` (LN1 + qkv + 7 x 7 window attention + proj + residual as one kernel: two waves per
+    (window, head), q / k / v / attention output never in memory) against the same half block in float64 and against the
+    four-launch path (LayerNorm kernel, token GEMM, attention kernel, token GEMM with the scatter): not further from
+    float64 than 3x the four launches, within 1e-5 of the output scale; maps that need padding, shifted and unshifted
+    windows, both embed dims the kernel is built for, odd window counts (at embed dim 96 a workgroup holds two windows: the
+    last one runs its second window dry) and a map smaller than one window."""
     from al3d import token_ops as Tk
     from al3d.models import swin as S
     from al3d.synthetic import seed_modules_
