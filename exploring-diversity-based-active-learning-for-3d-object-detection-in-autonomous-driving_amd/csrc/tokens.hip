@@ -723,6 +723,10 @@ struct TokAttnParams {
     int shift;              // cyclic shift of the block (0: no mask)
     float scale;
     int pair;
+    // token-order mode (bias != null): qkv / out rows are the B maps' H x W tokens; the cyclic shift, the padding and the
+    // window partition are evaluated from the window's position, a padded position's q / k / v row is the qkv bias
+    const float* bias;      // [3 C] or null (window-order mode: rows win * 49 + position)
+    int H, W;
 };
 
 #define TK_WS 7
@@ -732,6 +736,20 @@ __device__ __forceinline__ int tk_region1(int v, int n, int shift)
 {
     return (v >= n - TK_WS ? 1 : 0) + (v >= n - shift ? 1 : 0);
 }
+
+// the f16x3 split of 8 values with the packed conversions of sp_split8 (3 instructions per element instead of 5); the
+// inputs are pinned first (see tk_split: the high part and the residual must see the same rounded fp32 value)
+__device__ __forceinline__ void tk_split8p(float (&v)[8], f16x8& ph, f16x8& pl)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
+    uint4 hi, lo;
+    sp_split8(v, hi, lo);
+    ph = __builtin_bit_cast(f16x8, hi);
+    pl = __builtin_bit_cast(f16x8, lo);
+}
+// 13 y + x of key position min(key, 48) in the 7 x 7 window: the key's part of the relative position index
+__host__ __device__ constexpr int tk_kcode(int key) { return (key < TK_NT ? key : TK_NT - 1) + 6 * ((key < TK_NT ? key : TK_NT - 1) / TK_WS); }
 
 // One wave (= one 64-thread workgroup) per (window, head).  The head's q, k, v rows (49 x 128 B each, 1152+ B apart in
 // the qkv matrix) come in by LDS-DMA, eight whole rows per instruction (every 128-byte line fetched once, by one
@@ -756,7 +774,6 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
 {
     __shared__ __attribute__((aligned(1024))) unsigned char stg[3 * TK_ABYTES];    // k | q | v
     __shared__ float tbl[1][176];
-    __shared__ int treg[1][64];
     const int lane = threadIdx.x;
     constexpr int wave = 0;
     const int item = blockIdx.x;
@@ -766,12 +783,22 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
     const float* base = p.qkv + (int64_t)win * TK_NT * ld + head * 32;
     const unsigned stg_base = (unsigned)(size_t)(tk_lds_void*)stg;
     for (int t = lane; t < 169; t += 64) tbl[wave][t] = p.table[t * p.heads + head];
-    {
-        const int wi = win % (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
-        const int ty = lane / TK_WS, tx = lane - ty * TK_WS;
-        treg[wave][lane] = lane < TK_NT && p.shift > 0
-            ? tk_region1(wy * TK_WS + ty, p.nwy * TK_WS, p.shift) * 3 + tk_region1(wx * TK_WS + tx, p.nwx * TK_WS, p.shift)
-            : 0;
+    const int wi = win % (p.nwy * p.nwx), wb = win / (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
+    // token-order mode: token row of window position `row`, -1 for padding (shifted[hp] = padded[(hp + shift) % Hp])
+    auto token_of = [&](int row) __attribute__((always_inline)) -> int {
+        const int ty = (row * 37) >> 8, tx = row - ty * TK_WS;
+        int hs = wy * TK_WS + ty + p.shift, ws = wx * TK_WS + tx + p.shift;
+        hs -= hs >= p.nwy * TK_WS ? p.nwy * TK_WS : 0;
+        ws -= ws >= p.nwx * TK_WS ? p.nwx * TK_WS : 0;
+        return hs < p.H && ws < p.W ? (wb * p.H + hs) * p.W + ws : -1;
+    };
+    // shifted-window regions of the window's 7 rows / 7 columns, two bits each (uniform): tokens attend inside a region
+    int rycode = 0, rxcode = 0;
+    if (p.shift > 0) {
+        for (int t = 0; t < TK_WS; ++t) {
+            rycode |= tk_region1(wy * TK_WS + t, p.nwy * TK_WS, p.shift) << (2 * t);
+            rxcode |= tk_region1(wx * TK_WS + t, p.nwx * TK_WS, p.shift) << (2 * t);
+        }
     }
     {
         const int rl = lane >> 3, pos = lane & 7;
@@ -783,6 +810,10 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
                 const int row = it * 8 + rl;
                 const int chunk = pos ^ ((row >> 1) & 7);
                 const float* src = row < TK_NT ? base + (int64_t)row * ld + aoff + chunk * 4 : g_tok_zero + chunk * 4;
+                if (p.bias && row < TK_NT) {
+                    const int tok = token_of(row);
+                    src = (tok >= 0 ? p.qkv + (int64_t)tok * ld : p.bias) + head * 32 + aoff + chunk * 4;
+                }
                 const unsigned dst = __builtin_amdgcn_readfirstlane(stg_base + arr * TK_ABYTES + it * 1024);
                 __builtin_amdgcn_global_load_lds((tk_gbl_void*)src, (tk_lds_void*)(size_t)dst, 16, 0, 0);
             }
@@ -839,24 +870,46 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
             }
         // logits -> probabilities, in place in sm[i] (rows = keys, column = this lane's query)
         const int qq = query < TK_NT ? query : TK_NT - 1;
-        const int qcode = qq + 6 * ((qq * 37) >> 8) + 84;           // 13 y + x + 84
-        const int qreg = treg[wave][qq];
+        const int qy = (qq * 37) >> 8, qx = qq - TK_WS * qy;
+        const int qcode = qq + 6 * qy + 84;                          // 13 y + x + 84
+        // bit k of `diff`: key k lies in ANOTHER shifted-window region than this query (-100 on its logit).  A bit mask per
+        // query instead of a region lookup per element: that form (an LDS read behind `if (masked)`) made hipcc serialise
+        // 64 LDS round trips per tile
+        unsigned dlo = 0u, dhi = 0u;
+        if (masked) {
+            const int myry = (rycode >> (2 * qy)) & 3, myrx = (rxcode >> (2 * qx)) & 3;
+            unsigned colmask = 0u;
+            unsigned long long same = 0ull;
+#pragma unroll
+            for (int t = 0; t < TK_WS; ++t) colmask |= (unsigned)(((rxcode >> (2 * t)) & 3) == myrx) << t;
+#pragma unroll
+            for (int t = 0; t < TK_WS; ++t)
+                if (((rycode >> (2 * t)) & 3) == myry) same |= (unsigned long long)colmask << (TK_WS * t);
+            const unsigned long long diff = ~same >> (4 * h);        // the lane's keys are c + 4 h with compile-time c
+            dlo = (unsigned)diff;
+            dhi = (unsigned)(diff >> 32);
+        }
+        const float* tq = tbl[wave] + qcode;
         float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            float tb[16];                                            // the tile's 16 bias lookups first, then their uses
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int cc = 32 * i + (r & 3) + 8 * (r >> 2);      // key = cc + 4 h
+                tb[r] = tq[-(h ? tk_kcode(cc + 4) : tk_kcode(cc))];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cc = 32 * i + (r & 3) + 8 * (r >> 2);
                 float v = sm[i][r] + sc[i][r] * 0.00048828125f;
-                if (key < TK_NT) {
-                    v += tbl[wave][qcode - (key + 6 * ((key * 37) >> 8))];
-                    if (masked && treg[wave][key] != qreg) v += -100.0f;
-                } else {
-                    v = -INFINITY;
-                }
+                v += tb[r];
+                if (masked) v += (float)(((cc < 32 ? dlo : dhi) >> (cc & 31)) & 1u) * -100.0f;
+                if (cc + 4 >= TK_NT) v = (cc >= TK_NT || h) ? -INFINITY : v;
                 sm[i][r] = v;
                 mx = fmaxf(mx, v);
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
 #pragma unroll
@@ -908,7 +961,12 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
             }
         if (query >= TK_NT) continue;
         // rows of O^T are d = (r & 3) + 8 (r >> 2) + 4 h: four consecutive channels per register quad
-        float* orow = p.out + ((int64_t)win * TK_NT + query) * p.C + head * 32;
+        int64_t out_row = (int64_t)win * TK_NT + query;
+        if (p.bias) {
+            out_row = token_of(query);
+            if (out_row < 0) continue;                       // a padded position's output is cropped
+        }
+        float* orow = p.out + out_row * p.C + head * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float y[4];
@@ -941,8 +999,27 @@ extern "C" int al3d_tok_window_attention_f32(const float* qkv, const float* tabl
     AL3D_REQUIRE(shift >= 0 && shift < TK_WS, "al3d_tok_window_attention_f32: shift=%d outside [0, 7)", shift);
     AL3D_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "al3d_tok_window_attention_f32: qkv / out must be 16-byte aligned");
     if (nwin == 0) return AL3D_OK;
-    TokAttnParams p{qkv, table, out, nwin, C, heads, win_rows, win_cols, shift, scale, out_pair};
+    TokAttnParams p{qkv, table, out, nwin, C, heads, win_rows, win_cols, shift, scale, out_pair, nullptr, 0, 0};
     const int64_t items = (int64_t)nwin * heads;
+    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("tok_window_attention_kernel");
+    return AL3D_OK;
+}
+
+extern "C" int al3d_tok_window_attention_tokens_f32(const float* qkv, const float* bias_qkv, const float* table, int B, int H,
+                                                    int W, int C, int heads, int shift, float scale, int out_pair,
+                                                    float* out, void* stream)
+{
+    AL3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (int64_t)B * H * W < ((int64_t)1 << 31), "al3d_tok_window_attention_tokens_f32: bad map size");
+    if (B == 0) return AL3D_OK;
+    AL3D_REQUIRE(qkv && bias_qkv && table && out, "al3d_tok_window_attention_tokens_f32: null pointer (a model without qkv bias passes zeros)");
+    AL3D_REQUIRE(heads >= 1 && C == heads * 32, "al3d_tok_window_attention_tokens_f32: C=%d must be heads (%d) x 32", C, heads);
+    AL3D_REQUIRE(shift >= 0 && shift < TK_WS, "al3d_tok_window_attention_tokens_f32: shift=%d outside [0, 7)", shift);
+    AL3D_REQUIRE((((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)bias_qkv) & 15) == 0, "al3d_tok_window_attention_tokens_f32: qkv / bias / out must be 16-byte aligned");
+    const int nwy = (H + TK_WS - 1) / TK_WS, nwx = (W + TK_WS - 1) / TK_WS;
+    const int64_t items = (int64_t)B * nwy * nwx * heads;
+    AL3D_REQUIRE(items < ((int64_t)1 << 31), "al3d_tok_window_attention_tokens_f32: too many (window, head) items");
+    TokAttnParams p{qkv, table, out, B * nwy * nwx, C, heads, nwy, nwx, shift, scale, out_pair, bias_qkv, H, W};
     hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("tok_window_attention_kernel");
     return AL3D_OK;
@@ -1160,20 +1237,6 @@ struct TokAttnBlockParams {
     float eps, scale_qkv, scale_proj, scale;
     int B, H, W, nwy, nwx, shift;
 };
-
-// the f16x3 split of 8 values with the packed conversions of sp_split8 (3 instructions per element instead of 5); the
-// inputs are pinned first (see tk_split: the high part and the residual must see the same rounded fp32 value)
-__device__ __forceinline__ void tk_split8p(float (&v)[8], f16x8& ph, f16x8& pl)
-{
-#pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
-    uint4 hi, lo;
-    sp_split8(v, hi, lo);
-    ph = __builtin_bit_cast(f16x8, hi);
-    pl = __builtin_bit_cast(f16x8, lo);
-}
-// 13 y + x of key position min(key, 48) in the 7 x 7 window: the key's part of the relative position index
-__host__ __device__ constexpr int tk_kcode(int key) { return (key < TK_NT ? key : TK_NT - 1) + 6 * ((key < TK_NT ? key : TK_NT - 1) / TK_WS); }
 
 #define AB_D2 3              // ring depth of the two-wave form (registers: three waves per SIMD)
 

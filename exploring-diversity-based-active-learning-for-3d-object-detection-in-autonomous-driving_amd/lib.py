@@ -186,6 +186,8 @@ SIGNATURES = {
                                    c_p]),
     "al3d_tok_window_attention_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_flt, c_int, c_p,
                                               c_p]),
+    "al3d_tok_window_attention_tokens_f32": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_flt, c_int, c_p,
+                                                     c_p]),
 }
 
 _lib = None

@@ -82,6 +82,14 @@ class WindowMSA(nn.Module):
             T.PackedLinear(self.qkv.weight, self.qkv.bias), T.PackedLinear(self.proj.weight, self.proj.bias),
             self.relative_position_bias_table.detach().float().contiguous()))
 
+    def qkv_bias_rows(self, device):
+        """The qkv bias as the q / k / v row of a padded window position (zeros for a layer without bias)."""
+        if getattr(self, "_pkb", None) is None:
+            object.__setattr__(self, "_pkb", _Packed())
+        return self._pkb.get(device, (self.qkv,), lambda: (
+            torch.zeros(3 * self.embed_dims, device=device) if self.qkv.bias is None
+            else self.qkv.bias.detach().float().to(device).contiguous()))
+
     def packed_fused(self, device, norm):
         """LN1 + qkv + attention + proj in the fused kernel's format (``al3d_tok_attn_block_f16x3``; embed dim 96 / 192)."""
         if getattr(self, "_pkf", None) is None:
@@ -105,6 +113,9 @@ class ShiftWindowMSA(nn.Module):
 # embed dims it is built for -- stages 0-1, whose four launches are bound by the activation bytes they move)
 FUSED_ATTN = _os.environ.get("AL3D_SWIN_ATTN", "fused") != "split"
 FUSED_ATTN_DIMS = tuple(int(v) for v in _os.environ.get("AL3D_SWIN_ATTN_DIMS", "96,192").split(",") if v)
+# AL3D_SWIN_ROWS=window: the unfused attention half on window-ordered, padded rows (LN1 gathers through the row map, the
+# projection scatters back); default "token": its GEMMs run on the map's tokens and the attention kernel does the gathering
+TOKEN_ORDER = _os.environ.get("AL3D_SWIN_ROWS", "token") != "window"
 # AL3D_SWIN_MLP=split: LN2 / fc1 / fc2 as three launches everywhere (default "fused": one kernel where it is faster)
 FUSED_MLP = _os.environ.get("AL3D_SWIN_MLP", "fused") != "split"
 # (embed dim 96 only: at 192 the kernel needs 255 registers and a 96 KB ring and measured slower than the three launches)
@@ -149,6 +160,15 @@ class SwinBlock(nn.Module):
         if FUSED_ATTN and x.shape[-1] in FUSED_ATTN_DIMS:
             # LN1 + qkv + attention + proj + residual as one kernel: q, k, v and the attention output stay on the CU
             T.attn_block(x, geom.B, geom.H, geom.W, msa.packed_fused(x.device, n1), self.attn.shift_size, msa.scale)
+        elif TOKEN_ORDER:
+            # LN1, qkv and proj on the map's own tokens; the attention kernel gathers its windows (shift, padding: a padded
+            # position's q / k / v is the qkv bias) and writes token order back -- no GEMM row for the window padding
+            qkv_w, proj_w, table = msa.packed(x.device)
+            xw = T.layernorm(x, n1.weight, n1.bias, n1.eps, pair=True)
+            qkv = T.linear(xw, qkv_w, a_pair=True)
+            ao = T.window_attention_tokens(qkv, msa.qkv_bias_rows(x.device), table, geom.B, geom.H, geom.W, msa.num_heads,
+                                           self.attn.shift_size, msa.scale, pair=True)
+            T.linear(ao, proj_w, a_pair=True, residual=x, out=x)
         else:
             rowmap, (nwy, nwx) = geom.window_map(self.attn.shift_size)
             qkv_w, proj_w, table = msa.packed(x.device)

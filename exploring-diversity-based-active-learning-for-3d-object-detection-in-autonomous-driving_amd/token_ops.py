@@ -189,6 +189,20 @@ def window_attention(qkv, table, heads, win_rows, win_cols, shift, scale, pair=T
     return out
 
 
+def window_attention_tokens(qkv, bias_qkv, table, B, H, W, heads, shift, scale, pair=True):
+    """qkv ``[B * H * W, 3 C]`` in TOKEN order -> attention output ``[B * H * W, C]`` in token order (pair rows by default):
+    shift, padding and window partition from the window's position; a padded position's q / k / v is ``bias_qkv``."""
+    qkv = _dev(qkv, torch.float32, "qkv")
+    rows, c3 = qkv.shape
+    C = c3 // 3
+    if rows != B * H * W:
+        raise lib.Al3dError(f"window_attention_tokens: qkv has {rows} rows, {B} maps of {H} x {W} need {B * H * W}")
+    out = torch.empty((rows, C), dtype=torch.float32, device=qkv.device)
+    lib.call("al3d_tok_window_attention_tokens_f32", _ptr(qkv), _ptr(_dev(bias_qkv, torch.float32, "bias_qkv")),
+             _ptr(_dev(table, torch.float32, "table")), B, H, W, C, heads, int(shift), float(scale), int(pair), _ptr(out), _stream())
+    return out
+
+
 def mha16(q, k, v, B, Pq, Pk, heads, scale):
     """Attention core of ``nn.MultiheadAttention`` for 16-channel heads: q ``[B * Pq, >= heads * 16]``, k / v
     ``[B * Pk, ...]`` (column slices of wider row matrices are fine: the row pitch is the tensor's stride) ->

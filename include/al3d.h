@@ -668,6 +668,11 @@ int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const fl
  * al3d_tok_window_attention_f32: qkv [nwin*49][3C] (q | k | v, each [heads][32]) -> softmax(q scale k^T + B + mask) v,
  *   [nwin*49][C]; B = table[(yq-yk+6)*13 + (xq-xk+6)][head]; mask = -100 between tokens of different shifted-window
  *   regions, derived from the window's position in its win_rows x win_cols grid and `shift` (0 = none).
+ * al3d_tok_window_attention_tokens_f32: the same attention with qkv / out in TOKEN order ([B*H*W][3C] -> [B*H*W][C]): the
+ *   cyclic shift, the padding to multiples of 7 and the window partition are evaluated from the window's position, a padded
+ *   position's q / k / v row is bias_qkv [3C] (what the qkv layer makes of the zero row the padding puts after the norm) and
+ *   its output is cropped -- so LN1, the qkv and the projection GEMMs run on the H x W tokens, not on the padded windows
+ *   (16 x 44 tokens pad to 21 x 49: 1.46x the rows; 8 x 22 to 14 x 28: 2.2x).
  * al3d_tok_mlp_f16x3: the MLP half of a block as one kernel, x[t] += fc2(GELU(fc1(LN(x[t])))) in place, for C = 96
  *   (stage 0, whose separate LN / fc1 / fc2 launches are bandwidth-bound; the [T, hidden] activation stays in registers).
  *   image (al3d_tok_mlp_image_bytes): per 32 hidden units t the MFMA A-operand fragments [64 lanes][8 halves] of
@@ -700,6 +705,8 @@ int al3d_tok_linear_f16x3(const float* a, int a_pair, const void* wgt_image, con
                           float* out, int ldc, int out_pair, void* stream);
 int al3d_tok_window_attention_f32(const float* qkv, const float* table, int nwin, int C, int heads, int win_rows,
                                   int win_cols, int shift, float scale, int out_pair, float* out, void* stream);
+int al3d_tok_window_attention_tokens_f32(const float* qkv, const float* bias_qkv, const float* table, int B, int H, int W,
+                                         int C, int heads, int shift, float scale, int out_pair, float* out, void* stream);
 /* Multi-head attention with 16-channel heads, any number of keys (the TransFusion query decoder,
  * bevfusion/mmdet3d/models/utils/transformer.py:71-112 -> nn.MultiheadAttention's core: softmax(q scale k^T) v after
  * the input projections, before the output projection).  q [B][Pq][ldq], k [B][Pk][ldk], v [B][Pk][ldv] f32 with head

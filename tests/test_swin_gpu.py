@@ -567,3 +567,27 @@ def test_fused_attention_half_edge_cases():
         seed.attn.w_msa.packed_fused(torch.device(DEV), seed.norm1)
     with pytest.raises(lib.Al3dError):
         Tk.attn_block(x.clone(), B, H, W + 1, pk, 0, 32 ** -0.5)
+
+
+@pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 23, 384, 12, True), (1, 8, 22, 768, 24, True), (2, 14, 21, 384, 12, False),
+                                                 (1, 5, 6, 384, 12, True)])
+def test_swin_block_token_order_equals_window_order(B, H, W, C, heads, shift):
+    """The unfused attention half in token order (LN1 / qkv / proj on the map's tokens, ``al3d_tok_window_attention_tokens_f32``
+    gathers the shifted, padded windows and writes token order back; a padded position's q / k / v is the qkv bias) against
+    the window-order path (LN1 gathers through the row map, zero rows for padding, the projection scatters back): every GEMM
+    row and every window sees the same numbers, so the residual stream is bit-identical."""
+    from al3d.models import swin as S
+    from al3d.synthetic import seed_modules_
+    blk = seed_modules_(S.SwinBlock(C, heads, 4 * C, 7, shift), 31).to(DEV)
+    x = torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(C + H)).to(DEV)
+    geom = S._Geometry.of(B, H, W, 7, torch.device(DEV))
+    saved = S.TOKEN_ORDER
+    try:
+        with torch.no_grad():
+            S.TOKEN_ORDER = True
+            a = blk(x.clone(), geom)
+            S.TOKEN_ORDER = False
+            b = blk(x.clone(), geom)
+    finally:
+        S.TOKEN_ORDER = saved
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
