@@ -29,5 +29,12 @@ with torch.no_grad():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
 gflop = 194.0 * S
+import json
+# algorithmic HBM bytes per launch of the kernels that serve ONE shape here (tools/rocpd_summary.py hbm reads this line):
+# the fused halves read the residual stream once and write it once
+t0_, t1_ = S * 6 * 64 * 176, S * 6 * 32 * 88
+print(json.dumps({"algorithmic_mb": {"tok_attn_block_f16x3_kernel<96,": t0_ * 96 * 8 / 1e6,
+                                     "tok_attn_block_f16x3_kernel<192,": t1_ * 192 * 8 / 1e6,
+                                     "tok_mlp_f16x3_kernel<96,": t0_ * 96 * 8 / 1e6}}))
 print(f"swin-t {S} samples ({S * 6} images): {dt * 1e3:.2f} ms per forward = {dt * 1e3 / S:.2f} ms per sample, "
       f"{gflop / dt / 1e3:.1f} TFLOP/s algorithmic")

@@ -37,6 +37,13 @@ if [ "$PART" = pmc ]; then
   [ $rc -eq 0 ] || exit $rc
   python3 $R/tools/rocpd_summary.py hbm $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) $O/r04_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, AL3D_PIPELINE=${AL3D_PIPELINE:-ahead} bench.py $ARGS (640 frames = 5 batches of 128, AL3D_MATH=f16x3)" $O/r04_pmc_fetch_line.json
 fi
+if [ "$PART" = swin ]; then
+  # HBM traffic of the Swin-T token kernels (16 samples per forward), with the algorithmic bytes of the fused halves
+  rm -rf /tmp/p_sf /tmp/p_sw
+  timeout -k 10 170 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_sf -o f -- python3 $R/tools/bench_swin.py 16 1 > $O/r04_pmc_swin_fetch.log 2> $O/r04_prof_swin_fetch.err || exit 1
+  timeout -k 10 170 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_sw -o w -- python3 $R/tools/bench_swin.py 16 1 > $O/r04_pmc_swin_write.log 2> $O/r04_prof_swin_write.err || exit 1
+  python3 $R/tools/rocpd_summary.py hbm $(find /tmp/p_sf -name "*.db" | head -1) $(find /tmp/p_sw -name "*.db" | head -1) $O/r04_pmc_swin_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/bench_swin.py 16 1 (96 images of 256 x 704; 3 forwards per process)" $O/r04_pmc_swin_fetch.log
+fi
 if [ "$PART" = sq ]; then
   BENCH_L0_MODES=off,raster16p bash $R/tools/pmc_sq_l0.sh
   cp $O/pmc_l0.txt $O/r04_pmc_sq_l0.txt

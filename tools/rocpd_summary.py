@@ -64,10 +64,10 @@ def algorithmic_from_bench_line(path):
     table it streams, from ``roofline_sparse.layers``) and the streamed 3x3 dense kernel (its launch mix at the bench's
     batch size).  -> {kernel-name prefix: MB}."""
     try:
-        line = json.loads(open(path).read().strip().split("\n")[-1])
+        line = json.loads([l for l in open(path).read().strip().split("\n") if l.startswith("{")][-1])
     except Exception:
         return {}
-    out = {}
+    out = dict(line.get("algorithmic_mb") or {})                        # a tool's own {kernel-name prefix: MB}
     sp = line.get("roofline_sparse") or {}
     groups = {}
     for L in sp.get("layers", []):
