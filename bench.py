@@ -137,7 +137,7 @@ class ConvTimer:
         else:
             out.update(kernel="conv2d_mfma_kernel", peak=MFMA_F32_PEAK_TFLOPS,
                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
-        for pmc in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for pmc in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", pmc)
             if not os.path.exists(pmc):      # PMC passes are separate runs (rocprofv3 --pmc); see DESIGN.md
                 continue
@@ -413,7 +413,8 @@ def bevfusion_camera_lidar_leg(dev, frames=48, batch=16):
         roof = {"stage": "camera backbone (Swin-T)", "bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 3),
                 "note": "algorithmic flops (194 GFLOP per sample) / stage time from HIP events; peak = dense f16 MFMA "
-                        "2.5 PFLOP/s / 3 products per MAC (f16x3); the stage-0/1 GEMMs (C = 96, 192) are HBM-bound"}
+                        "2.5 PFLOP/s / 3 products per MAC (f16x3); stages 0-1 run fused attention / MLP halves (VALU-issue bound), "
+                        "stages 2-3 token GEMMs with K = 384 / 768"}
     try:
         files = bevfusion_camera_lidar_from_files(cfg, model, frames, batch, dev)
     except Exception as e:                                              # the figure is auxiliary: never fail the line
