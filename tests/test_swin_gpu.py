@@ -591,3 +591,25 @@ def test_swin_block_token_order_equals_window_order(B, H, W, C, heads, shift):
     finally:
         S.TOKEN_ORDER = saved
     assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,heads", [(96, 3), (384, 12)])
+def test_swin_block_without_qkv_bias(C, heads):
+    """``qkv_bias=False``: the fused attention half (embed dim 96) gets a zero bias vector, the token-order attention
+    (embed dim 384) reads a zero row for padded window positions -- both against the window-order four-launch path."""
+    from al3d.models import swin as S
+    from al3d.synthetic import seed_modules_
+    blk = seed_modules_(S.SwinBlock(C, heads, 4 * C, 7, shift=True, qkv_bias=False), 11).to(DEV)
+    assert blk.attn.w_msa.qkv.bias is None
+    B, H, W = 2, 9, 16
+    x = torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(7)).to(DEV)
+    geom = S._Geometry.of(B, H, W, 7, torch.device(DEV))
+    saved = (S.FUSED_ATTN, S.TOKEN_ORDER)
+    try:
+        with torch.no_grad():
+            a = blk(x.clone(), geom)
+            S.FUSED_ATTN, S.TOKEN_ORDER = False, False
+            b = blk(x.clone(), geom)
+    finally:
+        S.FUSED_ATTN, S.TOKEN_ORDER = saved
+    assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) <= 4e-6 * float(b.abs().max())
