@@ -28,15 +28,17 @@ def gap_embedding(neck_out):
     return neck_out.mean(dim=-1).mean(dim=-1)
 
 
-def gather_in_dataset_order(local_feats, local_index, num_frames):
+def gather_in_dataset_order(local_feats, local_index, num_frames, collective_at_world_1=False):
     """All-gather per-rank rows and scatter them back to dataset order.
 
     ``local_index[r]`` is the dataset index of ``local_feats[r]``.  Ranks may hold
     different row counts (padding rows carry index -1) and sampler wrap-around
     duplicates are harmless: every copy of a frame holds the same embedding.
+    ``collective_at_world_1``: run the collectives even in a one-rank group (the one-GPU RCCL
+    test: the same calls as at N > 1 through the nccl backend).
     """
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not collective_at_world_1):
         out = torch.empty((num_frames, local_feats.shape[1]), dtype=local_feats.dtype,
                           device=local_feats.device)
         out[local_index] = local_feats

@@ -122,3 +122,39 @@ def test_three_rank_selection_equals_oracle(oracle, tmp_path):
     rc, picks = oracle.greedy(D, [], first, np.array([int(b) * 0.04 for b in n_boxes]), 0.12, 0.0, 120.0)
     assert rc == 0
     assert all(results[r] == picks.tolist() for r in range(world))
+
+
+def _rccl_worker(port, q):
+    """One rank, backend nccl (= RCCL on ROCm): the collectives of the N > 1 sweep -- the row-count all_gather, the two
+    all_gather_into_tensor of embeddings and indices, the ranks_seen all_reduce of bench.py -- on device tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from al3d.sweep import gather_in_dataset_order
+        dev = torch.device("cuda:0")
+        n = 1003
+        full = torch.randn(n, 512, generator=torch.Generator().manual_seed(1)).to(dev)
+        idx = torch.randperm(n, generator=torch.Generator().manual_seed(2)).to(dev)
+        out = gather_in_dataset_order(full[idx], idx, n, collective_at_world_1=True)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        dist.barrier()
+        torch.cuda.synchronize()
+        q.put((dist.get_backend(), bool(torch.equal(out, full)), float(ones.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_carries_the_sweeps_collectives_on_one_gpu():
+    """The N > 1 data path has only ever been rehearsed over gloo (no multi-GPU box for the builder).  This runs its exact
+    collective calls through RCCL itself in a one-rank group on the box's GPU: communicator set-up, all_gather,
+    all_gather_into_tensor, all_reduce and barrier on device memory; the gathered tensor must be the dataset-ordered one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    backend, ok, seen = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and ok and seen == 1.0
