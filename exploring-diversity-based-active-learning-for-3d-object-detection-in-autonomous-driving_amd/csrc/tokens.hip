@@ -1638,3 +1638,152 @@ extern "C" int al3d_tok_attn_block_f16x3(float* x, int B, int H, int W, int C, i
     AL3D_CHECK_LAUNCH("tok_attn_block_f16x3_kernel");
     return AL3D_OK;
 }
+
+// ------------------------------------------------------------------ fused patch embedding (embed dim 96)
+// mmdet PatchEmbed = Conv2d(3, 96, 4, stride 4) + LayerNorm(96) as ONE kernel: the three launches it replaces (patch rows,
+// token GEMM with K = 48, LayerNorm) read and write the 415 MB token matrix (16 samples) two and a half times; this one
+// reads the image once (208 MB) and writes the tokens once.  A wave owns 32 tokens at a time: the 48 values of a token's
+// 4 x 4 x 3 patch are its B-operand rows (k = (ky * 4 + kx) * 3 + c: every aligned group of four k is 16 contiguous bytes
+// of one image row -- W % 4 == 0 keeps a patch inside the image horizontally), split in registers; out^T = W P^T with the
+// weights as A operand (nine fragments per plane, 18 KB in LDS, lane order); the accumulators
+// hold a token's 96 channels in the lane pair (l, l ^ 32): bias, LayerNorm (two-pass, one exchange per moment), and the rows
+// leave through the wave's LDS transposition as 16-byte pieces of 128-byte segments.  f16x3 arithmetic.
+struct TokPatchEmbedParams {
+    const float* img;        // [B][H][W][3] channels-last
+    const _Float16* image;   // [3 tiles u][3 steps s][2 planes][64 lanes][8]: projection.weight[32u + lane%32][16s + 8(lane/32) + e]
+    const float* bias;       // [96]
+    const float* gamma;      // [96] or null: no LayerNorm
+    const float* beta;
+    float* out;              // [B * TH * TW][96]
+    float scale, eps;
+    int B, H, W, TH, TW, gpw;
+    int64_t T;
+};
+
+__global__ __launch_bounds__(256, 2) void tok_patch_embed_f16x3_kernel(TokPatchEmbedParams p)
+{
+    __shared__ float par[3][96];                          // bias | gamma | beta
+    __shared__ float scr_all[4][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* scr = scr_all[wave];
+    for (int i = tid; i < 96; i += 256) {
+        par[0][i] = p.bias ? p.bias[i] : 0.f;
+        par[1][i] = p.gamma ? p.gamma[i] : 1.f;
+        par[2][i] = p.gamma ? p.beta[i] : 0.f;
+    }
+    __shared__ __attribute__((aligned(16))) unsigned char wsm[18 * 1024];    // the nine fragments x two planes, lane order
+    for (int i = tid; i < 18 * 64; i += 256)
+        *reinterpret_cast<uint4*>(wsm + i * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.image) + i * 16);
+    const unsigned char* wf = wsm + lane * 16;
+    __syncthreads();
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wave) * p.gpw;
+    for (int gi = 0; gi < p.gpw; ++gi) {
+        const int64_t tok0 = (g0 + gi) * 32;
+        if (tok0 >= p.T) break;                              // uniform per wave
+        const int64_t tok = tok0 + fr;
+        const bool live = tok < p.T;
+        const int64_t tc = live ? tok : 0;
+        const int tx = (int)(tc % p.TW), ty = (int)((tc / p.TW) % p.TH), b = (int)(tc / ((int64_t)p.TW * p.TH));
+        // the lane's three 8-value chunks of the patch: k = 16 s + 8 fh + e; four consecutive k = 16 bytes of one image row
+        f16x8 ph[3], pl[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float v[8];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int k0 = 16 * s + 8 * fh + 4 * hlf;       // a multiple of 4: inside one (ky) segment of 12
+                const int ky = k0 / 12, off = k0 - 12 * ky;
+                const int y = 4 * ty + ky;
+                const bool ok = live && y < p.H;
+                const float4 q = *reinterpret_cast<const float4*>(p.img + (((int64_t)b * p.H + (ok ? y : 0)) * p.W + 4 * tx) * 3 + off);
+                v[4 * hlf] = ok ? q.x : 0.f; v[4 * hlf + 1] = ok ? q.y : 0.f; v[4 * hlf + 2] = ok ? q.z : 0.f; v[4 * hlf + 3] = ok ? q.w : 0.f;
+            }
+            tk_split8p(v, ph[s], pl[s]);
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(wf + ((u * 3 + s) * 2) * 1024);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(wf + ((u * 3 + s) * 2 + 1) * 1024);
+                acc[u] = TK_MFMA(tk_lift_down(wh), pl[s], acc[u]);
+                acc[u] = TK_MFMA(wl, ph[s], acc[u]);
+                acc[u] = TK_MFMA(wh, ph[s], acc[u]);
+            }
+        }
+        // channel of register r of tile u: 32 u + (r & 3) + 8 (r >> 2) + 4 fh; the other 48 channels of the token sit in lane ^ 32
+        float y[3][16];
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(&par[0][32 * u + 8 * g + 4 * fh]);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { y[u][4 * g + e] = acc[u][4 * g + e] * p.scale + bb[e]; sum += y[u][4 * g + e]; }
+            }
+        if (p.gamma) {
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / 96.0f;
+            float sq = 0.f;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = y[u][r] - mean; sq += d * d; }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq / 96.0f + p.eps);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(&par[1][32 * u + 8 * g + 4 * fh]);
+                    const float4 b4 = *reinterpret_cast<const float4*>(&par[2][32 * u + 8 * g + 4 * fh]);
+                    const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[u][4 * g + e] = ((y[u][4 * g + e] - mean) * rstd) * ga[e] + be[e];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[fr * 33 + (r & 3) + 8 * (r >> 2) + 4 * fh] = y[u][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q, tk = i >> 3, g = i & 7;        // token tk, channels 4 g .. 4 g + 3 of the tile
+                if (tok0 + tk < p.T)
+                    *reinterpret_cast<float4*>(p.out + (tok0 + tk) * 96 + 32 * u + 4 * g) =
+                        make_float4(scr[tk * 33 + 4 * g], scr[tk * 33 + 4 * g + 1], scr[tk * 33 + 4 * g + 2], scr[tk * 33 + 4 * g + 3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+extern "C" int64_t al3d_tok_patch_embed_image_bytes(void) { return 3 * 3 * 2 * 1024; }
+
+extern "C" int al3d_tok_patch_embed_f16x3(const float* img, int B, int H, int W, const void* image, float scale, const float* bias,
+                                          const float* gamma, const float* beta, float eps, float* out, void* stream)
+{
+    AL3D_REQUIRE(B >= 0 && H >= 1 && W >= 4 && W % 4 == 0, "al3d_tok_patch_embed_f16x3: W=%d must be a multiple of 4 (a patch row is read as aligned 16-byte pieces); other widths: al3d_tok_patch_rows_f32 + al3d_tok_linear_f16x3 + al3d_tok_layernorm_f32", W);
+    if (B == 0) return AL3D_OK;
+    AL3D_REQUIRE(img && image && out && (!gamma || beta), "al3d_tok_patch_embed_f16x3: null pointer");
+    AL3D_REQUIRE((((uintptr_t)img | (uintptr_t)image | (uintptr_t)out) & 15) == 0, "al3d_tok_patch_embed_f16x3: img / image / out must be 16-byte aligned");
+    TokPatchEmbedParams p;
+    p.img = img; p.image = (const _Float16*)image; p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out;
+    p.scale = scale; p.eps = eps; p.B = B; p.H = H; p.W = W; p.TH = (H + 3) / 4; p.TW = W / 4;
+    p.T = (int64_t)B * p.TH * p.TW;
+    AL3D_REQUIRE(p.T < ((int64_t)1 << 31), "al3d_tok_patch_embed_f16x3: too many tokens");
+    p.gpw = 8;                                               // 32-token groups per wave (the weights are staged once per workgroup)
+    const int64_t groups = al3d_cdiv(p.T, 32);
+    const dim3 grid((unsigned)al3d_cdiv(groups, 4 * p.gpw));
+    hipLaunchKernelGGL(tok_patch_embed_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    AL3D_CHECK_LAUNCH("tok_patch_embed_f16x3_kernel");
+    return AL3D_OK;
+}

@@ -174,6 +174,8 @@ SIGNATURES = {
     "al3d_conv3x3_nhwc_f16x3_wino": (c_int, [c_p, c_p, c_p, c_p, c_p] + [c_int] * 9 + [c_p]),
     "al3d_tok_patch_rows_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_tok_layernorm_f32": (c_int, [c_p, c_p, c_i64, c_int, c_int, c_int, c_p, c_p, c_flt, c_int, c_p, c_p]),
+    "al3d_tok_patch_embed_image_bytes": (c_i64, []),
+    "al3d_tok_patch_embed_f16x3": (c_int, [c_p, c_int, c_int, c_int, c_p, c_flt, c_p, c_p, c_p, c_flt, c_p, c_p]),
     "al3d_tok_attn_block_image_bytes": (c_i64, [c_int]),
     "al3d_tok_attn_block_f16x3": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_flt, c_p, c_flt, c_p, c_flt,
                                           c_p, c_p, c_flt, c_p]),

@@ -113,6 +113,8 @@ class ShiftWindowMSA(nn.Module):
 # embed dims it is built for -- stages 0-1, whose four launches are bound by the activation bytes they move)
 FUSED_ATTN = _os.environ.get("AL3D_SWIN_ATTN", "fused") != "split"
 FUSED_ATTN_DIMS = tuple(int(v) for v in _os.environ.get("AL3D_SWIN_ATTN_DIMS", "96,192").split(",") if v)
+# AL3D_SWIN_PATCH=split: patch rows + token GEMM + LayerNorm as three launches (default "fused": one kernel at embed dim 96)
+FUSED_PATCH_EMBED = _os.environ.get("AL3D_SWIN_PATCH", "fused") != "split"
 # AL3D_SWIN_ROWS=window: the unfused attention half on window-ordered, padded rows (LN1 gathers through the row map, the
 # projection scatters back); default "token": its GEMMs run on the map's tokens and the attention kernel does the gathering
 TOKEN_ORDER = _os.environ.get("AL3D_SWIN_ROWS", "token") != "window"
@@ -278,6 +280,15 @@ class _PatchEmbed(nn.Module):
     def forward(self, x):
         """x channels-last [B,H,W,3] -> token rows [B * H/4 * W/4, C], (H/4, W/4)."""
         pr = self.projection
+        if FUSED_PATCH_EMBED and pr.out_channels == 96 and x.shape[2] % 4 == 0:
+            # projection + LayerNorm as one kernel: the image is read once, the tokens are written once
+            if getattr(self, "_pkf", None) is None:
+                object.__setattr__(self, "_pkf", _Packed())
+            n = self.norm
+            pk = self._pkf.get(x.device, (pr,) + ((n,) if n is not None else ()), lambda: T.PackedPatchEmbed(
+                pr.weight.to(x.device), pr.bias, None if n is None else n.weight, None if n is None else n.bias,
+                1e-5 if n is None else n.eps))
+            return T.patch_embed(x, pk)
         w = self._pk.get(x.device, (pr,), lambda: T.PackedLinear(
             pr.weight.detach().permute(0, 2, 3, 1).reshape(pr.out_channels, -1), pr.bias))      # [C, (ky, kx, c)]
         rows, hw = T.patch_rows(x, pair=True)

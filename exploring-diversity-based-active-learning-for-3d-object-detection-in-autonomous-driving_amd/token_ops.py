@@ -122,6 +122,39 @@ def mlp(x, packed):
     return x
 
 
+class PackedPatchEmbed:
+    """Conv2d(3, 96, 4, stride 4) (+ LayerNorm(96)) in the fused patch-embedding kernel's format
+    (``al3d_tok_patch_embed_f16x3``): the MFMA A fragments of the projection weight reordered to k = (ky, kx, c)."""
+
+    def __init__(self, weight, bias, norm_weight=None, norm_bias=None, eps=1e-5):
+        w = weight.detach().float()
+        if tuple(w.shape) != (96, 3, 4, 4):
+            raise lib.Al3dError(f"PackedPatchEmbed: weight {tuple(w.shape)}, the fused kernel is built for (96, 3, 4, 4)")
+        w2 = w.permute(0, 2, 3, 1).reshape(96, 48).contiguous()
+        planes, sc = split_f16x3(w2.view(96, 1, 48))
+        # [plane, u, fr, s, fh, e] -> [u, s, plane, fh, fr, e]   (lane = fh * 32 + fr)
+        self.image = planes.view(2, 3, 32, 3, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+        assert self.image.numel() * 2 == lib.load().al3d_tok_patch_embed_image_bytes()
+        self.scale, self.eps = float(sc[0]), float(eps)
+        dev = self.image.device
+        f = lambda v: None if v is None else v.detach().float().to(dev).contiguous()
+        self.bias, self.gamma, self.beta = f(bias), f(norm_weight), f(norm_bias)
+
+
+def patch_embed(img, packed):
+    """img ``[B, H, W, 3]`` channels-last (W a multiple of 4) -> token rows ``[B * ceil(H/4) * (W/4), 96]`` f32: projection
+    (+ LayerNorm) in one launch."""
+    img = _dev(img, torch.float32, "img")
+    B, H, W, ch = img.shape
+    if ch != 3 or W % 4:
+        raise lib.Al3dError("patch_embed: expected 3 image channels and a width that is a multiple of 4")
+    th, tw = (H + 3) // 4, W // 4
+    out = torch.empty((B * th * tw, 96), dtype=torch.float32, device=img.device)
+    lib.call("al3d_tok_patch_embed_f16x3", _ptr(img), B, H, W, _ptr(packed.image), packed.scale, _ptr(packed.bias),
+             _ptr(packed.gamma), _ptr(packed.beta), packed.eps, _ptr(out), _stream())
+    return out, (th, tw)
+
+
 def patch_rows(img, pair=True):
     """img ``[B, H, W, 3]`` channels-last -> 4 x 4 patch rows ``[B * ceil(H/4) * ceil(W/4), 48]`` (k = (ky*4 + kx)*3 + c)."""
     img = _dev(img, torch.float32, "img")

@@ -691,6 +691,14 @@ int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const fl
 /* img [B][H][W][3] f32 -> patch rows [B*ceil(H/4)*ceil(W/4)][48], k = (ky*4 + kx)*3 + c, zeros beyond the image: the A
  * matrix of the 4x4 / stride-4 patch embedding (mmdet PatchEmbed: Conv2d(3, 96, 4, 4)) as a token GEMM with K = 48. */
 int al3d_tok_patch_rows_f32(const float* img, int B, int H, int W, int out_pair, float* out, void* stream);
+/* The whole patch embedding as one kernel for embed dim 96 (mmdet PatchEmbed: Conv2d(3, 96, 4, 4) + LayerNorm(96)):
+ * out[b*TH*TW + ty*TW + tx][:] = LN(projection(patch)) (gamma null: no LayerNorm), img channels-last, W % 4 == 0 (rows of a
+ * patch are read as aligned 16-byte pieces; pixels beyond H are zero).  image (al3d_tok_patch_embed_image_bytes): the MFMA
+ * A fragments [3 tiles][3 steps][2 planes][64 lanes][8] of projection.weight reordered to k = (ky*4 + kx)*3 + c:
+ * element = w[32u + lane%32][16s + 8(lane/32) + e], planes (wh, wl) of al3d_split_f16x3, scale = 2^-s. */
+int64_t al3d_tok_patch_embed_image_bytes(void);
+int al3d_tok_patch_embed_f16x3(const float* img, int B, int H, int W, const void* image, float scale, const float* bias,
+                               const float* gamma, const float* beta, float eps, float* out, void* stream);
 int al3d_tok_layernorm_f32(const float* x, const int* rowmap, int64_t rows_out, int C, int G, int zero_out,
                            const float* gamma, const float* beta, float eps, int out_pair, float* out, void* stream);
 int64_t al3d_tok_mlp_image_bytes(int C, int hidden);

@@ -613,3 +613,39 @@ def test_swin_block_without_qkv_bias(C, heads):
     finally:
         S.FUSED_ATTN, S.TOKEN_ORDER = saved
     assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) <= 4e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,norm", [(2, 64, 96, True), (1, 30, 44, True), (3, 9, 8, False), (1, 256, 704, True)])
+def test_fused_patch_embedding_matches_float64_and_the_three_launches(B, H, W, norm):
+    """``al3d_tok_patch_embed_f16x3`` (4 x 4 / stride-4 projection + LayerNorm as one kernel) against conv2d + layer_norm in
+    float64 and against the three-launch path (patch rows, token GEMM, LayerNorm kernel): heights that are not multiples of
+    4 (zero rows below the image), with and without the norm, the configs[4] image size."""
+    from al3d.models import swin as S
+    from al3d.synthetic import seed_modules_
+    pe = seed_modules_(S._PatchEmbed(3, 96, 4, norm), 13).to(DEV)
+    if norm:
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(5)
+            pe.norm.weight.copy_(torch.randn(96, generator=g) * 0.2 + 1.0)
+            pe.norm.bias.copy_(torch.randn(96, generator=g) * 0.1)
+    img = (torch.randn(B, H, W, 3, generator=torch.Generator().manual_seed(H + W)) * 1.2 + 0.1).to(DEV)
+    with torch.no_grad():
+        xd = img.double().permute(0, 3, 1, 2)
+        xd = F.pad(xd, (0, 0, 0, (-H) % 4))
+        ref = F.conv2d(xd, pe.projection.weight.double(), pe.projection.bias.double(), stride=4).flatten(2).transpose(1, 2)
+        if norm:
+            ref = F.layer_norm(ref, (96,), pe.norm.weight.double(), pe.norm.bias.double(), pe.norm.eps)
+        ref = ref.reshape(-1, 96)
+        saved = S.FUSED_PATCH_EMBED
+        try:
+            S.FUSED_PATCH_EMBED = True
+            fused, hw = pe(img)
+            S.FUSED_PATCH_EMBED = False
+            split, hw2 = pe(img)
+        finally:
+            S.FUSED_PATCH_EMBED = saved
+    assert hw == hw2 == ((H + 3) // 4, W // 4) and fused.shape == split.shape == ref.shape
+    scale = float(ref.abs().max())
+    e_f, e_s = float((fused.double() - ref).abs().max()), float((split.double() - ref).abs().max())
+    print("fused", e_f / scale, "split", e_s / scale)
+    assert e_f <= 3.0 * e_s + 2e-7 * scale and e_f <= 2e-6 * scale, (e_f, e_s, scale)
