@@ -243,7 +243,8 @@ class ConvFuser(nn.Sequential):
         self.in_channels, self.out_channels = in_channels, out_channels
         super().__init__(nn.Conv2d(sum(in_channels), out_channels, 3, padding=1, bias=False),
                          nn.BatchNorm2d(out_channels), nn.ReLU(True))
-        self._run = _ConvBNReLU(self[0], self[1])
+        # kept OUT of the module tree: the state dict holds the reference's keys (0.weight, 1.*) and nothing else
+        object.__setattr__(self, "_run", _ConvBNReLU(self[0], self[1]))
 
     def forward(self, inputs):
         assert [t.shape[-1] for t in inputs] == list(self.in_channels)
