@@ -751,7 +751,7 @@ __device__ __forceinline__ void tk_split8p(float (&v)[8], f16x8& ph, f16x8& pl)
 // 13 y + x of key position min(key, 48) in the 7 x 7 window: the key's part of the relative position index
 __host__ __device__ constexpr int tk_kcode(int key) { return (key < TK_NT ? key : TK_NT - 1) + 6 * ((key < TK_NT ? key : TK_NT - 1) / TK_WS); }
 
-// One wave (= one 64-thread workgroup) per (window, head).  The head's q, k, v rows (49 x 128 B each, 1152+ B apart in
+// Two waves (= one 128-thread workgroup) per (window, head), one 32-query tile each.  The head's q, k, v rows (49 x 128 B each, 1152+ B apart in
 // the qkv matrix) come in by LDS-DMA, eight whole rows per instruction (every 128-byte line fetched once, by one
 // instruction); a row's eight 16-byte chunks are stored permuted (chunk q at position q ^ ((row >> 1) & 7), applied
 // on the SOURCE side: the LDS side of a DMA is lane-linear) so that the fragment reads are conflict-free.
@@ -770,19 +770,22 @@ __device__ __forceinline__ unsigned tk_arow_off(int row, int chunk)      // byte
     return (unsigned)(r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
 }
 
-__global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams p)
+__global__ __launch_bounds__(128, 3) void tok_window_attention_kernel(TokAttnParams p)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char stg[3 * TK_ABYTES];    // k | q | v
     __shared__ float tbl[1][176];
-    const int lane = threadIdx.x;
-    constexpr int wave = 0;
+    // two waves per (window, head): they share the staged q / k / v rows and take one 32-query tile each; K fragments are
+    // read (and split) where they are used instead of being held: <= 168 registers, three waves per SIMD, six workgroups
+    // per CU by LDS -- twelve resident waves with half the dependent chain each (one wave per item held 7 per CU)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int item = blockIdx.x;
     const int win = item / p.heads, head = item - win * p.heads;
     const int c = lane & 31, h = lane >> 5;
     const int ld = 3 * p.C;
     const float* base = p.qkv + (int64_t)win * TK_NT * ld + head * 32;
     const unsigned stg_base = (unsigned)(size_t)(tk_lds_void*)stg;
-    for (int t = lane; t < 169; t += 64) tbl[wave][t] = p.table[t * p.heads + head];
+    for (int t = threadIdx.x; t < 169; t += 128) tbl[0][t] = p.table[t * p.heads + head];
     const int wi = win % (p.nwy * p.nwx), wb = win / (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
     // token-order mode: token row of window position `row`, -1 for padding (shifted[hp] = padded[(hp + shift) % Hp])
     auto token_of = [&](int row) __attribute__((always_inline)) -> int {
@@ -806,7 +809,9 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
         for (int arr = 0; arr < 3; ++arr) {
             const int aoff = arr == 0 ? p.C : arr == 1 ? 0 : 2 * p.C;
 #pragma unroll
-            for (int it = 0; it < 7; ++it) {
+            for (int it0 = 0; it0 < 4; ++it0) {
+                const int it = 2 * it0 + wave;                  // the row groups of an array alternate between the waves
+                if (it >= 7) continue;
                 const int row = it * 8 + rl;
                 const int chunk = pos ^ ((row >> 1) & 7);
                 const float* src = row < TK_NT ? base + (int64_t)row * ld + aoff + chunk * 4 : g_tok_zero + chunk * 4;
@@ -819,28 +824,15 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
             }
         }
     }
-    tk_wait_vm<7>();                                   // k and q have landed (v: 7 instructions still in flight)
+    tk_wait_vm<0>();
+    __syncthreads();                                   // both waves' shares of k, q and v have landed
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
-    // K fragments (A operand: rows = keys) stay in registers for both query tiles
-    f16x8 kh[2][2], kl[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            tk_f32x4 lo, hi;
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(lo), "=&v"(hi)
-                         : "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h)), "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h + 1))
-                         : "memory");
-            tk_split8v(lo, hi, kh[i][s], kl[i][s]);
-        }
     const bool masked = p.shift > 0;
     // one 32-query tile at a time (a real loop: the state of a tile -- 64 logit + 32 output accumulators -- is live only
     // inside its iteration, which is what lets several waves share a SIMD)
-#pragma unroll 1
-    for (int j = 0; j < 2; ++j) {
+    for (int j = wave; j <= wave; ++j) {                // this wave's query tile
         const int query = 32 * j + c;
         f16x8 qh[2], ql[2];
 #pragma unroll
@@ -864,9 +856,16 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                sc[i] = TK_MFMA(kl[i][s], qh[s], sc[i]);
-                sc[i] = TK_MFMA(kh[i][s], ql[s], sc[i]);
-                sm[i] = TK_MFMA(kh[i][s], qh[s], sm[i]);
+                tk_f32x4 lo, hi;                                 // K fragment (A operand: rows = keys), split here
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo), "=&v"(hi)
+                             : "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h)), "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h + 1))
+                             : "memory");
+                f16x8 kh, kl;
+                tk_split8v(lo, hi, kh, kl);
+                sc[i] = TK_MFMA(kl, qh[s], sc[i]);
+                sc[i] = TK_MFMA(kh, ql[s], sc[i]);
+                sm[i] = TK_MFMA(kh, qh[s], sm[i]);
             }
         // logits -> probabilities, in place in sm[i] (rows = keys, column = this lane's query)
         const int qq = query < TK_NT ? query : TK_NT - 1;
@@ -889,7 +888,7 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
             dlo = (unsigned)diff;
             dhi = (unsigned)(diff >> 32);
         }
-        const float* tq = tbl[wave] + qcode;
+        const float* tq = tbl[0] + qcode;
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -927,7 +926,6 @@ __global__ __launch_bounds__(64) void tok_window_attention_kernel(TokAttnParams 
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         // O^T[d][query] = sum_key V[key][d] P[query][key]; P is normalised AFTER the product (one multiply per output)
-        tk_wait_vm<0>();                               // v has landed (no-op for the second tile)
         f32x16 om, oc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { om[r] = 0.f; oc[r] = 0.f; }
@@ -1001,7 +999,7 @@ extern "C" int al3d_tok_window_attention_f32(const float* qkv, const float* tabl
     if (nwin == 0) return AL3D_OK;
     TokAttnParams p{qkv, table, out, nwin, C, heads, win_rows, win_cols, shift, scale, out_pair, nullptr, 0, 0};
     const int64_t items = (int64_t)nwin * heads;
-    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(128), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("tok_window_attention_kernel");
     return AL3D_OK;
 }
@@ -1020,7 +1018,7 @@ extern "C" int al3d_tok_window_attention_tokens_f32(const float* qkv, const floa
     const int64_t items = (int64_t)B * nwy * nwx * heads;
     AL3D_REQUIRE(items < ((int64_t)1 << 31), "al3d_tok_window_attention_tokens_f32: too many (window, head) items");
     TokAttnParams p{qkv, table, out, B * nwy * nwx, C, heads, nwy, nwx, shift, scale, out_pair, bias_qkv, H, W};
-    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tok_window_attention_kernel, dim3((unsigned)items), dim3(128), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("tok_window_attention_kernel");
     return AL3D_OK;
 }
