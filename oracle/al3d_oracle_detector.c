@@ -233,6 +233,20 @@ static float clip_area(const float* ax, const float* ay, const float* bx, const 
     return n < 3 ? 0.f : poly_area(px, py, n);
 }
 
+/* The geometry of one pair, exported for the cross-check against the reference's OTHER implementation of the same quantity
+ * (det3d/ops/nms/nms_gpu.py:343-420, `rbbox_to_corners` / `inter` / `devRotateIoU`, numba.cuda device functions run as plain
+ * Python by oracle/gen_golden_rotated_iou.py): corners [x0..x3 | y0..y3] of both boxes, intersection area, IoU as the NMS
+ * loop below forms it. */
+void al3d_oracle_rbox_pair(const float* a5, const float* b5, float* corners_a, float* corners_b, float* inter, float* iou)
+{
+    corners_of(a5, corners_a, corners_a + 4);
+    corners_of(b5, corners_b, corners_b + 4);
+    const float in = clip_area(corners_a, corners_a + 4, corners_b, corners_b + 4);
+    const float uni = poly_area(corners_a, corners_a + 4, 4) + poly_area(corners_b, corners_b + 4, 4) - in;
+    *inter = in;
+    *iou = uni > 0.f ? in / uni : 0.f;
+}
+
 int64_t al3d_oracle_rotate_nms(const float* dets, int64_t n, float thresh, int64_t post_max, int* keep)
 {
     float* cx = (float*)malloc(sizeof(float) * 4 * (size_t)(n + 1));

@@ -234,6 +234,18 @@ def box_decode(enc, anchors):
     return out
 
 
+def rbox_pair(a5, b5):
+    """Two boxes (x, y, w, l, r) -> (corners_a [8] = x0..x3 | y0..y3, corners_b [8], intersection area, IoU) as the rotated
+    NMS forms them."""
+    a, b = _c(a5, np.float32).reshape(5), _c(b5, np.float32).reshape(5)
+    ca, cb = np.zeros(8, np.float32), np.zeros(8, np.float32)
+    inter, iou = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    fn = lib().al3d_oracle_rbox_pair
+    fn.restype = None
+    fn(_p(a), _p(b), _p(ca), _p(cb), ctypes.byref(inter), ctypes.byref(iou))
+    return ca, cb, float(inter.value), float(iou.value)
+
+
 def rotate_nms(dets_sorted, thresh, post_max):
     """dets [n,5] (x,y,w,l,r) in descending score order -> kept indices."""
     d = _c(dets_sorted, np.float32)
