@@ -785,7 +785,6 @@ __global__ __launch_bounds__(128, 3) void tok_window_attention_kernel(TokAttnPar
     const int ld = 3 * p.C;
     const float* base = p.qkv + (int64_t)win * TK_NT * ld + head * 32;
     const unsigned stg_base = (unsigned)(size_t)(tk_lds_void*)stg;
-    for (int t = threadIdx.x; t < 169; t += 128) tbl[0][t] = p.table[t * p.heads + head];
     const int wi = win % (p.nwy * p.nwx), wb = win / (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi - wy * p.nwx;
     // token-order mode: token row of window position `row`, -1 for padding (shifted[hp] = padded[(hp + shift) % Hp])
     auto token_of = [&](int row) __attribute__((always_inline)) -> int {
@@ -795,6 +794,38 @@ __global__ __launch_bounds__(128, 3) void tok_window_attention_kernel(TokAttnPar
         ws -= ws >= p.nwx * TK_WS ? p.nwx * TK_WS : 0;
         return hs < p.H && ws < p.W ? (wb * p.H + hs) * p.W + ws : -1;
     };
+    // the rows first (their latency is the longest: per row group ONE source row address serves the k, q and v pieces), then
+    // the position-bias table and the region codes in its shadow -- with the table load in front every item began by
+    // waiting for it before a single row was requested (35 % of an item's life by per-phase time stamps)
+    {
+        const int rl = lane >> 3, pos = lane & 7;
+#pragma unroll
+        for (int it0 = 0; it0 < 4; ++it0) {
+            const int it = 2 * it0 + wave;                      // the row groups of an array alternate between the waves
+            if (it >= 7) continue;
+            const int row = it * 8 + rl;
+            const int chunk = pos ^ ((row >> 1) & 7);
+            const bool live = row < TK_NT;
+            const float* rp = g_tok_zero;
+            if (live) {
+                rp = base + (int64_t)row * ld;
+                if (p.bias) {
+                    const int tok = token_of(row);
+                    rp = (tok >= 0 ? p.qkv + (int64_t)tok * ld : p.bias) + head * 32;
+                }
+            }
+            rp += chunk * 4;
+#pragma unroll
+            for (int arr = 0; arr < 3; ++arr) {
+                const int aoff = live ? (arr == 0 ? p.C : arr == 1 ? 0 : 2 * p.C) : 0;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(stg_base + arr * TK_ABYTES + it * 1024);
+                __builtin_amdgcn_global_load_lds((tk_gbl_void*)(rp + aoff), (tk_lds_void*)(size_t)dst, 16, 0, 0);
+            }
+        }
+    }
+    float tv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int t = threadIdx.x + 128 * k; tv[k] = t < 169 ? p.table[t * p.heads + head] : 0.f; }
     // shifted-window regions of the window's 7 rows / 7 columns, two bits each (uniform): tokens attend inside a region
     int rycode = 0, rxcode = 0;
     if (p.shift > 0) {
@@ -803,27 +834,8 @@ __global__ __launch_bounds__(128, 3) void tok_window_attention_kernel(TokAttnPar
             rxcode |= tk_region1(wx * TK_WS + t, p.nwx * TK_WS, p.shift) << (2 * t);
         }
     }
-    {
-        const int rl = lane >> 3, pos = lane & 7;
 #pragma unroll
-        for (int arr = 0; arr < 3; ++arr) {
-            const int aoff = arr == 0 ? p.C : arr == 1 ? 0 : 2 * p.C;
-#pragma unroll
-            for (int it0 = 0; it0 < 4; ++it0) {
-                const int it = 2 * it0 + wave;                  // the row groups of an array alternate between the waves
-                if (it >= 7) continue;
-                const int row = it * 8 + rl;
-                const int chunk = pos ^ ((row >> 1) & 7);
-                const float* src = row < TK_NT ? base + (int64_t)row * ld + aoff + chunk * 4 : g_tok_zero + chunk * 4;
-                if (p.bias && row < TK_NT) {
-                    const int tok = token_of(row);
-                    src = (tok >= 0 ? p.qkv + (int64_t)tok * ld : p.bias) + head * 32 + aoff + chunk * 4;
-                }
-                const unsigned dst = __builtin_amdgcn_readfirstlane(stg_base + arr * TK_ABYTES + it * 1024);
-                __builtin_amdgcn_global_load_lds((tk_gbl_void*)src, (tk_lds_void*)(size_t)dst, 16, 0, 0);
-            }
-        }
-    }
+    for (int k = 0; k < 2; ++k) { const int t = threadIdx.x + 128 * k; if (t < 176) tbl[0][t] = tv[k]; }
     tk_wait_vm<0>();
     __syncthreads();                                   // both waves' shares of k, q and v have landed
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1280,12 +1292,15 @@ __global__ __launch_bounds__(C * 4 * WPB, 3) void tok_attn_block_f16x3_kernel(To
 #pragma unroll
     for (int g = 0; g < AB_D2; ++g) issue(g);
 
-    if (role == 0)
-        for (int t = lane; t < 169; t += 64) tbl[t] = p.table[t * NH + hd];
+    // the position-bias table and this wave's bias rows are REQUESTED here and stored to LDS after the LayerNorm's rows have
+    // been requested: a load -> LDS copy in front would make every wave wait one memory round trip before it asks for its rows
+    float tv[3], bv[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tv[k] = lane + 64 * k < 169 ? p.table[(lane + 64 * k) * NH + hd] : 0.f;
     {
         const int part = lane >> 5;                        // lanes 0-31: k, proj; 32-63: q, v
-        bsm[lane] = p.bias_qkv[(part == 0 ? C : 0) + 32 * hd + fr];
-        bsm[64 + lane] = part == 0 ? p.bias_proj[32 * hd + fr] : p.bias_qkv[2 * C + 32 * hd + fr];
+        bv[0] = p.bias_qkv[(part == 0 ? C : 0) + 32 * hd + fr];
+        bv[1] = part == 0 ? p.bias_proj[32 * hd + fr] : p.bias_qkv[2 * C + 32 * hd + fr];
     }
     int rycode = 0, rxcode = 0;
     if (p.shift > 0)
@@ -1318,6 +1333,12 @@ __global__ __launch_bounds__(C * 4 * WPB, 3) void tok_attn_block_f16x3_kernel(To
             ga[t][0] = g0.x; ga[t][1] = g0.y; ga[t][2] = g0.z; ga[t][3] = g0.w; ga[t][4] = g1.x; ga[t][5] = g1.y; ga[t][6] = g1.z; ga[t][7] = g1.w;
             be[t][0] = b0.x; be[t][1] = b0.y; be[t][2] = b0.z; be[t][3] = b0.w; be[t][4] = b1.x; be[t][5] = b1.y; be[t][6] = b1.z; be[t][7] = b1.w;
         }
+        if (role == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (lane + 64 * k < 176) tbl[lane + 64 * k] = tv[k];
+        }
+        bsm[lane] = bv[0];
+        bsm[64 + lane] = bv[1];
         // sum over the row's LPR adjacent lanes: quad exchanges, then (8 lanes) the mirrored half row, whose lanes all hold
         // their quad's sum by then
         auto rowsum = [](float x) __attribute__((always_inline)) -> float {
