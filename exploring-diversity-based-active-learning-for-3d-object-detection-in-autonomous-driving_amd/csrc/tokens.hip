@@ -855,9 +855,9 @@ __global__ __launch_bounds__(128, 3) void tok_window_attention_kernel(TokAttnPar
                          : "v"(stg_base + TK_ABYTES + tk_arow_off(query, 4 * s + 2 * h)),
                            "v"(stg_base + TK_ABYTES + tk_arow_off(query, 4 * s + 2 * h + 1))
                          : "memory");
-            const float qv[8] = {lo[0] * p.scale, lo[1] * p.scale, lo[2] * p.scale, lo[3] * p.scale,
+            float qv[8] = {lo[0] * p.scale, lo[1] * p.scale, lo[2] * p.scale, lo[3] * p.scale,
                                  hi[0] * p.scale, hi[1] * p.scale, hi[2] * p.scale, hi[3] * p.scale};
-            tk_split8(qv, qh[s], ql[s]);
+            tk_split8p(qv, qh[s], ql[s]);
         }
         f32x16 sm[2], sc[2];
 #pragma unroll
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(128, 3) void tok_window_attention_kernel(TokAttnPar
                              : "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h)), "v"(stg_base + tk_arow_off(32 * i + c, 4 * s + 2 * h + 1))
                              : "memory");
                 f16x8 kh, kl;
-                tk_split8v(lo, hi, kh, kl);
+                { float kv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; tk_split8p(kv, kh, kl); }
                 sc[i] = TK_MFMA(kl, qh[s], sc[i]);
                 sc[i] = TK_MFMA(kh, ql[s], sc[i]);
                 sm[i] = TK_MFMA(kh, qh[s], sm[i]);
@@ -960,11 +960,11 @@ __global__ __launch_bounds__(128, 3) void tok_window_attention_kernel(TokAttnPar
                              : "v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]), "v"(va[6]), "v"(va[7])
                              : "memory");
                 f16x8 vh, vl, ph, pl;
-                tk_split8(vv, vh, vl);
+                tk_split8p(vv, vh, vl);
                 float pv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pv[e] = sm[i][8 * s + e];
-                tk_split8(pv, ph, pl);
+                tk_split8p(pv, ph, pl);
                 oc = TK_MFMA(vl, ph, oc);
                 oc = TK_MFMA(vh, pl, oc);
                 om = TK_MFMA(vh, ph, om);
