@@ -256,9 +256,25 @@ def rotate_nms(dets_sorted, thresh, post_max):
     return keep[:k].copy()
 
 
+def task_detections(boxes, cls_logits, score_thresh, iou_thresh, pre_max, post_max, rng):
+    """One (sample, task) after the box decoding: numpy restatement of get_task_detections' class-agnostic branch
+    (mg_head.py:981-1063) around the C NMS.  boxes [N, 9] decoded, cls_logits [N, nc] -> (boxes [K, 9], scores, labels)."""
+    cls = np.asarray(cls_logits, dtype=np.float32)
+    boxes = np.asarray(boxes, dtype=np.float32)
+    sc = (1.0 / (1.0 + np.exp(-cls.astype(np.float64)))).astype(np.float32)
+    top = sc.max(1); lab = sc.argmax(1)
+    idx = np.nonzero(top >= np.float32(score_thresh))[0] if score_thresh > 0.0 else np.arange(len(top))
+    order = idx[np.lexsort((idx, -top[idx].astype(np.float64)))][:pre_max]   # score desc, index asc
+    cand = boxes[order]
+    keep = rotate_nms(cand[:, [0, 1, 3, 4, 8]], iou_thresh, post_max)
+    b, s, l = cand[keep], top[order][keep], lab[order][keep]
+    m = np.all(b[:, :3] >= np.asarray(rng[:3], np.float32), 1) & np.all(b[:, :3] <= np.asarray(rng[3:], np.float32), 1)
+    return b[m], s[m], l[m]
+
+
 def head_predict(hout, anchors, na, nc, box_off, cls_off, score_thresh, iou_thresh, pre_max,
                  post_max, rng):
-    """One (sample, task): numpy restatement of get_task_detections around the C pieces.
+    """One (sample, task): the box decoding of the candidates + task_detections.
     hout [HW, CH].  Returns (boxes [K,9], scores [K], labels [K])."""
     hw = hout.shape[0]
     cls = hout[:, cls_off:cls_off + na * nc].reshape(hw * na, nc).astype(np.float32)
