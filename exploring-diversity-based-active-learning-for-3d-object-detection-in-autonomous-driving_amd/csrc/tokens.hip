@@ -15,11 +15,18 @@
 //                                3-stage ring exactly as conv2d_f16x3_dma2_kernel, rows addressed directly;
 //                                epilogue: bias, exact (erf) GELU, residual, row SCATTER (window order -> token
 //                                order, padding rows dropped), f32 or pair rows out
-//   tok_window_attention_kernel  one wave per (window, head): S^T = K (Q scale)^T on the matrix cores with both
-//                                operands split (main + 2^-11 correction accumulators), + relative position bias
-//                                + shifted-window region mask computed from the window's position (no mask tensor),
-//                                softmax down the accumulator registers, O^T = V^T P^T with P taken straight from
-//                                the accumulators as the B operand (no LDS round trip), pair rows out
+//   tok_window_attention_kernel  two waves per (window, head), one per query tile: S^T = K (Q scale)^T on the matrix
+//                                cores with both operands split (main + 2^-11 correction accumulators), + relative
+//                                position bias + shifted-window region mask computed from the window's position (no
+//                                mask tensor), softmax down the accumulator registers, O^T = V^T P^T with P taken
+//                                straight from the accumulators as the B operand (no LDS round trip), pair rows out;
+//                                reads qkv in window order or (token-order mode, embed 384 / 768) in the map's own order
+//   tok_mlp_f16x3_kernel         embed 96: LN2 + fc1 + exact GELU + fc2 + residual in one kernel (hidden rows stay in
+//                                registers, weights through an LDS-DMA ring)
+//   tok_attn_block_f16x3_kernel  embed 96 / 192: LN1 + qkv + window attention + proj + residual in one kernel; 2 NH
+//                                waves per window, K^T / V fragments through LDS, everything else in accumulators
+//   tok_patch_embed_f16x3_kernel Conv2d(3, 96, 4, 4) + LayerNorm of the patch embedding in one kernel
+//   tok_mha16_kernel (+ combine) the TransFusion decoder's multi-head attention (head dim 16)
 //
 // Nothing here calls a BLAS / MIOpen routine.  gfx950 only.
 #include "al3d_common.h"
