@@ -9,7 +9,12 @@ nms_cpu.h, boost).  It is replaced by a function that sorts by score as ``rotate
 into it, in which order, how its result is indexed back, the range filter, label / score bookkeeping), not the polygon clipping
 (cross-checked separately: oracle/gen_golden_rotated_iou.py).  Other stand-ins are content-free: empty modules for the model
 zoo's packages, placeholder names for the loss / checkpoint helpers mg_head.py imports, an attribute dict for the config.
-Run in the build container only (needs /root/reference); writes tests/golden/head_predict.npz.
+
+A second fixture pins what surrounds that call: ``MultiGroupHead.predict`` itself (mg_head.py:697-803) -- the view of each
+task's head output as [anchors, 10] / [anchors, classes], ``GroundBox3dCoderTorch.decode_torch`` on ALL anchors
+(box_coders.py:106-109), one ``get_task_detections`` per task and the merge of the six tasks with the label offsets -- called
+unbound on seeded head outputs of a 16 x 16 map with the CBGS tasks' anchors (tests/golden/head_predict_tasks.npz).
+Run in the build container only (needs /root/reference); writes tests/golden/head_predict.npz and head_predict_tasks.npz.
 """
 import importlib
 import os
@@ -95,6 +100,53 @@ def main():
     out = os.path.join(os.path.dirname(HERE), "tests", "golden", "head_predict.npz")
     np.savez_compressed(out, **store)
     print("wrote", out)
+    predict_fixture(mg)
+
+
+def predict_fixture(mg):
+    """``MultiGroupHead.predict`` on the six CBGS tasks over a 16 x 16 map, two samples."""
+    import functools
+    ref_import.import_box_np_ops()
+    coders = importlib.import_module("det3d.core.bbox.box_coders")
+    sys.path.insert(0, os.path.dirname(HERE))
+    from al3d.datasets.anchors import generate_task_anchors             # equal to the reference generator's: anchors golden
+    from al3d.utils import Config
+    cfgm = Config.fromfile(os.path.join(os.path.dirname(HERE), "examples", "active", "cbgs_spatial_temporal.py"))
+    B, H, W = 2, 16, 16
+    gens = [dict(g, anchor_ranges=[-12.8, -12.8, g["anchor_ranges"][2], 12.8, 12.8, g["anchor_ranges"][5]])
+            for g in cfgm.target_assigner.anchor_generators]
+    anchors = generate_task_anchors(cfgm.tasks, gens, [1, H, W])
+    num_classes = [t["num_class"] for t in cfgm.tasks]
+    na = [2 * c for c in num_classes]
+    rng = np.random.default_rng(77)
+    coder = coders.GroundBox3dCoderTorch(linear_dim=False, vec_encode=True, n_dim=9, norm_velo=False)
+    head = types.SimpleNamespace(use_direction_classifier=False, encode_background_as_zeros=True, use_sigmoid_score=True,
+                                 num_anchor_per_locs=na, num_classes=num_classes, anchor_dim=9, bev_only=False,
+                                 box_n_dim=coder.code_size, box_coder=coder)
+    head.get_task_detections = functools.partial(mg.MultiGroupHead.get_task_detections, head)
+    cfg = _Cfg(score_threshold=0.1, post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+               nms=_Cfg(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000, nms_post_max_size=83,
+                        nms_iou_threshold=0.2))
+    store = {"num_classes": np.array(num_classes, np.int64), "shape": np.array([B, H, W], np.int64)}
+    preds = []
+    for t, nc in enumerate(num_classes):
+        box = rng.normal(0.0, 0.3, (B, H, W, na[t] * 10)).astype(np.float32)
+        cls = rng.normal(-1.5 if t % 2 == 0 else -3.5, 2.0, (B, H, W, na[t] * nc)).astype(np.float32)
+        if t == 3:
+            cls[1] = -20.0                                                # one (sample, task) without any candidate
+        preds.append({"box_preds": torch.from_numpy(box), "cls_preds": torch.from_numpy(cls)})
+        store.update({f"box{t}": box, f"cls{t}": cls, f"anchors{t}": anchors[t]})
+    example = {"voxels": None, "num_points": None, "coordinates": None,
+               "anchors": [torch.from_numpy(np.broadcast_to(a, (B,) + a.shape).copy()) for a in anchors]}
+    with torch.no_grad():
+        out = mg.MultiGroupHead.predict(head, example, preds, cfg)
+    for b in range(B):
+        store.update({f"out{b}.boxes": out[b]["box3d_lidar"].numpy(), f"out{b}.scores": out[b]["scores"].numpy(),
+                      f"out{b}.labels": out[b]["label_preds"].numpy()})
+        print("sample", b, "->", tuple(out[b]["box3d_lidar"].shape), "labels", np.bincount(out[b]["label_preds"].numpy(), minlength=10))
+    path = os.path.join(os.path.dirname(HERE), "tests", "golden", "head_predict_tasks.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path))
 
 
 if __name__ == "__main__":

@@ -493,6 +493,34 @@ def test_head_predict_vs_oracle(oracle, score_bias):
             assert len(ss) > 50
 
 
+def test_head_predict_matches_the_reference_predict_golden():
+    """The product's ``MultiGroupHead.predict`` (decode + NMS kernel over the fused head output) against the REFERENCE's own
+    ``MultiGroupHead.predict`` (mg_head.py:697-803; oracle/gen_golden_head_predict.py): six tasks, two samples, one (sample,
+    task) without a candidate.  Same detections in the same order; scores 1e-6; boxes 1e-4 (device exp / atan2)."""
+    z = np.load(os.path.join(G, "head_predict_tasks.npz"))
+    B, H, W = (int(v) for v in z["shape"])
+    cfg, head, anchors = _head_setup(7, H, W)
+    assert head.num_classes == [int(v) for v in z["num_classes"]]
+    head._prepare(torch.device(DEV))
+    fused = torch.zeros((B, H, W, head._ch), dtype=torch.float32)
+    for t, task in enumerate(head.tasks):
+        np.testing.assert_array_equal(anchors[t], z[f"anchors{t}"])
+        fused[..., head._box_off[t]:head._box_off[t] + task.conv_box.out_channels] = torch.from_numpy(z[f"box{t}"])
+        fused[..., head._cls_off[t]:head._cls_off[t] + task.conv_cls.out_channels] = torch.from_numpy(z[f"cls{t}"])
+    fused = fused.to(DEV)
+    out = head.predict({"anchors": [_t(a) for a in anchors], "metadata": [None] * B},
+                       [{"_fused": fused} for _ in head.tasks], cfg.test_cfg)
+    for b in range(B):
+        rb, rs, rl = z[f"out{b}.boxes"], z[f"out{b}.scores"], z[f"out{b}.labels"]
+        got = out[b]
+        assert got["label_preds"].cpu().numpy().tolist() == rl.tolist()
+        np.testing.assert_allclose(got["scores"].cpu().numpy(), rs, rtol=1e-6, atol=1e-7)
+        gb = got["box3d_lidar"].cpu().numpy()
+        np.testing.assert_allclose(gb[:, :8], rb[:, :8], rtol=1e-4, atol=1e-4)
+        d = np.abs(gb[:, 8] - rb[:, 8])
+        assert np.minimum(d, 2 * np.pi - d).max() < 1e-4
+
+
 @pytest.mark.parametrize("levels", [3, 40])
 def test_head_predict_with_massive_score_ties(oracle, levels):
     """Class logits quantised to a few levels: thousands of anchors share the score of the 1000th candidate, so the

@@ -27,3 +27,28 @@ def test_task_detections_equal_the_reference_head(oracle, case):
     else:
         assert 10 < len(b) <= post and np.all(np.diff(s) <= 0)               # survivors best first
         assert np.all(np.abs(b[:, :2]) <= 61.2)                              # the range filter removed the far ones
+
+
+def test_predict_over_six_tasks_equals_the_reference_head(oracle):
+    """``MultiGroupHead.predict`` of the reference (mg_head.py:697-803) on seeded head outputs of a 16 x 16 map: the oracle's
+    per-task view of the head output + decode of the candidates + NMS glue, merged with the label offsets, gives the same
+    detections in the same order.  Boxes: C float32 decode against torch's (2e-6, angle 1e-5, as in the decode golden)."""
+    z = np.load(os.path.join(os.path.dirname(GOLD), "head_predict_tasks.npz"))
+    B, H, W = (int(v) for v in z["shape"])
+    ncs = [int(v) for v in z["num_classes"]]
+    off = np.concatenate([[0], np.cumsum(ncs)])
+    for b in range(B):
+        bb, ss, ll = [], [], []
+        for t, nc in enumerate(ncs):
+            na = 2 * nc
+            hout = np.concatenate([z[f"box{t}"][b].reshape(H * W, -1), z[f"cls{t}"][b].reshape(H * W, -1)], axis=1)
+            bx, sc, lb = oracle.head_predict(hout, z[f"anchors{t}"], na, nc, 0, na * 10, 0.1, 0.2, 1000, 83, RANGE)
+            bb.append(bx); ss.append(sc); ll.append(lb + off[t])
+        bb, ss, ll = np.concatenate(bb), np.concatenate(ss), np.concatenate(ll)
+        rb, rs, rl = z[f"out{b}.boxes"], z[f"out{b}.scores"], z[f"out{b}.labels"]
+        assert ll.tolist() == rl.tolist() and len(rl) > 300
+        assert np.all(np.abs(ss - rs) <= 1.2e-7 * np.maximum(np.abs(rs), 1e-3))
+        np.testing.assert_allclose(bb[:, :8], rb[:, :8], rtol=2e-6, atol=2e-6)
+        d = np.abs(bb[:, 8] - rb[:, 8])
+        assert np.minimum(d, 2 * np.pi - d).max() < 1e-5
+    assert not np.any(z["out1.labels"] == off[3])                                # the (sample, task) without a candidate
