@@ -551,7 +551,7 @@ __device__ __forceinline__ void r16_read_b1(f16x8& wh, f16x8& wl, unsigned wb)
 }
 
 template <int COUT, int NW, int P, int CAP, bool RES>
-__global__ __launch_bounds__(64 * NW) void sp_conv_r16_kernel(const float* __restrict__ fin, const int* __restrict__ nbr,
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 1)) void sp_conv_r16_kernel(const float* __restrict__ fin, const int* __restrict__ nbr,
                                                                 int pitch, const int4* __restrict__ items,
                                                                 const int* __restrict__ first, int ntiles, int tpw,
                                                                 const unsigned char* __restrict__ wimg,
@@ -863,18 +863,24 @@ extern "C" int al3d_sp_conv_r16_f16x3(const float* fin, const int* nbr, int nbr_
     // tiles per wave: longer item streams amortise the pipeline's fill (8: -1.5 % at 240k tiles), shorter ones keep small
     // launches balanced over the CUs (4: -7 % at 60k tiles)
     const int tpw = tiles_per_wave > 0 ? tiles_per_wave : (ntiles >= 150000 ? 8 : 4);
-    // workgroup shapes: (waves, items in flight per wave); AL3D_R16_SHAPE (dev knob): 0 = 12 x 2 (default: the kernel is bound
-    // by the latency chain of a wave's item times the resident waves), 2 = 8 x 3 (measured +4..18 %)
-    static const int shape = getenv("AL3D_R16_SHAPE") ? atoi(getenv("AL3D_R16_SHAPE")) : 0;
+    // workgroup shapes: (waves, items in flight per wave); AL3D_R16_SHAPE (dev knob).  The kernel is bound by the latency chain
+    // of a wave's item times the resident waves: 12 waves per CU at two items in flight (8 x 3 measured +4..18 %).  At 16
+    // output channels those twelve waves are THREE workgroups of four (default, shape 4) rather than one of twelve (shape 0):
+    // a 12-wave workgroup needs a whole CU's registers at once, so every CU on which a side-stream workgroup sits is closed to
+    // it until that drains -- the first level-0 layer of a batch ran 2.0 ms beside the previous batch's decode + NMS against
+    // 1.0 ms now (serial: 625 -> 587 us per layer; bench +0.8 %, tools/ab_r16_shape.sh).
+    static const int shape = getenv("AL3D_R16_SHAPE") ? atoi(getenv("AL3D_R16_SHAPE")) : 4;
     static const int abl = getenv("AL3D_R16_ABL") ? atoi(getenv("AL3D_R16_ABL")) : 0;
     {
         if (cout == 16) {
             if (residual) {
                 if (shape == 2) R16_LAUNCH(16, 8, 3, 48, true);
-                R16_LAUNCH(16, 12, 2, 48, true);
+                if (shape == 0) R16_LAUNCH(16, 12, 2, 48, true);
+                R16_LAUNCH(16, 4, 2, 48, true);
             }
             if (shape == 2) R16_LAUNCH(16, 8, 3, 48, false);
-            R16_LAUNCH(16, 12, 2, 48, false);
+            if (shape == 0) R16_LAUNCH(16, 12, 2, 48, false);
+            R16_LAUNCH(16, 4, 2, 48, false);
         }
         if (cout == 32) {
             AL3D_REQUIRE(!residual, "al3d_sp_conv_r16_f16x3: no residual form at 32 output channels");
