@@ -572,6 +572,13 @@ static int sp_conv_wave2_f16x3_impl(const float* fin, const int* nbr, int nbr_pi
     const void* wgt = wgt_f16x2;
     // f16x3 halves the MFMA time of a unit, so the 32-channel layers take four units per slab (one barrier
     // per 12 MFMAs instead of 6: -3 %); the LDS this needs is below the epilogue scratch anyway
+    // 128 output channels: two 8-wave workgroups per CU (default) instead of one of 16 waves (AL3D_SW2_NW128=16, round 1's
+    // choice on a quiet machine): a 16-wave workgroup at 128 VGPRs needs a CU's whole register file at once, so it cannot
+    // start on a CU where any side-stream wave sits; and a workgroup walks the union of its waves' live taps, which is smaller
+    // over 256 rows than over 512.  Same box, bench: 2,237 / 2,234 -> 2,262 / 2,248 frames/s, 128 -> 128 layers -3..5 %,
+    // 64 -> 128 -9 % (profiles/r04_ab_sw2_nw128.txt).  Same arithmetic in the same order: bit-identical.
+    static const int nw128 = getenv("AL3D_SW2_NW128") ? atoi(getenv("AL3D_SW2_NW128")) : 8;
+    if (nw128 != 16) { SW2_DISPATCH(64, 128, 8, 2, 2, 2) SW2_DISPATCH(128, 128, 8, 2, 2, 2) }
     SW2_DISPATCH(16, 16, 4, 4, 4, 2) SW2_DISPATCH(16, 32, 8, 4, 2, 2) SW2_DISPATCH(32, 32, 8, 4, 2, 2) SW2_DISPATCH(32, 64, 8, 4, 2, 2)
     SW2_DISPATCH(64, 64, 8, 4, 2, 2) SW2_DISPATCH(64, 128, 16, 2, 2, 2) SW2_DISPATCH(128, 128, 16, 2, 2, 2)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_wave2_f16x3: unsupported channel pair %d -> %d", cin, cout);
