@@ -576,7 +576,9 @@ static int sp_conv_wave2_f16x3_impl(const float* fin, const int* nbr, int nbr_pi
     // choice on a quiet machine): a 16-wave workgroup at 128 VGPRs needs a CU's whole register file at once, so it cannot
     // start on a CU where any side-stream wave sits; and a workgroup walks the union of its waves' live taps, which is smaller
     // over 256 rows than over 512.  Same box, bench: 2,237 / 2,234 -> 2,262 / 2,248 frames/s, 128 -> 128 layers -3..5 %,
-    // 64 -> 128 -9 % (profiles/r04_ab_sw2_nw128.txt).  Same arithmetic in the same order: bit-identical.
+    // 64 -> 128 -9 % (profiles/r04_ab_sw2_nw128.txt).  Same arithmetic in the same order: bit-identical.  (4-wave workgroups
+    // for the strided 16 -> 32 / 32 -> 64 layers: the first 2,261 -> 1,549 us, the layer after it 1,818 -> 2,382 -- the side
+    // stream's work only moves; bench tie, not kept.)
     static const int nw128 = getenv("AL3D_SW2_NW128") ? atoi(getenv("AL3D_SW2_NW128")) : 8;
     if (nw128 != 16) { SW2_DISPATCH(64, 128, 8, 2, 2, 2) SW2_DISPATCH(128, 128, 8, 2, 2, 2) }
     SW2_DISPATCH(16, 16, 4, 4, 4, 2) SW2_DISPATCH(16, 32, 8, 4, 2, 2) SW2_DISPATCH(32, 32, 8, 4, 2, 2) SW2_DISPATCH(32, 64, 8, 4, 2, 2)
