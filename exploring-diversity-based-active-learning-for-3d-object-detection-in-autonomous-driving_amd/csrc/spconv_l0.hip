@@ -861,8 +861,10 @@ extern "C" int al3d_sp_conv_r16_f16x3(const float* fin, const int* nbr, int nbr_
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (int)al3d_cdiv(n_out, 32);
     // tiles per wave: longer item streams amortise the pipeline's fill (8: -1.5 % at 240k tiles), shorter ones keep small
-    // launches balanced over the CUs (4: -7 % at 60k tiles)
-    const int tpw = tiles_per_wave > 0 ? tiles_per_wave : (ntiles >= 150000 ? 8 : 4);
+    // launches balanced over the CUs (4: -7 % at 60k tiles); AL3D_R16_TPW (dev knob) overrides: 4 / 8 / 16 / 32 measure
+    // 2,207 / 2,211 / 2,215 / 2,204 frames/s in the bench with the 4-wave workgroups
+    static const int tpw_env = getenv("AL3D_R16_TPW") ? atoi(getenv("AL3D_R16_TPW")) : 0;
+    const int tpw = tiles_per_wave > 0 ? tiles_per_wave : tpw_env > 0 ? tpw_env : (ntiles >= 150000 ? 8 : 4);
     // workgroup shapes: (waves, items in flight per wave); AL3D_R16_SHAPE (dev knob).  The kernel is bound by the latency chain
     // of a wave's item times the resident waves: 12 waves per CU at two items in flight (8 x 3 measured +4..18 %).  At 16
     // output channels those twelve waves are THREE workgroups of four (default, shape 4) rather than one of twelve (shape 0):
