@@ -685,6 +685,153 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void tok_mlp_f16x3_kern
     }
 }
 
+// ---- the same MLP half at C = 192 on the 16 x 16 x 32 product: a wave owns SIXTEEN tokens.  At 32 tokens per wave the
+// operands of the kernel above (xn^T 96 + out^T 96 registers + a hidden tile) need ~270 registers; with 16-token tiles they
+// are 48 + 48 and three waves per SIMD fit (<= 168).  Lane (lr = lane & 15, lq = lane >> 4): a B fragment holds k-block lq
+// (8 consecutive k) of column lr = token lr, an A fragment k-block lq of row lr, an accumulator rows 4 lq .. 4 lq + 3 of
+// column lr.  So the x row pieces a lane loads (channels 32 ks + 8 lq .. + 7 of token lr) ARE fc1's B fragments after LN + split;
+// the two 16-row tiles of a 32-unit hidden group, after bias + GELU + split, ARE fc2's B fragment in the k order
+// (e < 4: unit 4 lq + e, e >= 4: unit 16 + 4 lq + e - 4) the host bakes into the W2 image; and out^T leaves as one float4 per
+// lane and 16-channel tile (channels 16 u + 4 lq .. + 3 of token lr): no LDS transposition.  Weights: per hidden group 24 KB
+// of W1 fragments [j][ks][plane][64][8] and 24 KB of W2 fragments [u][plane][64][8], one after the other through a four-stage
+// LDS-DMA ring shared by the workgroup's twelve waves (192 tokens; one barrier per half group).
+template <int C>
+__global__ __launch_bounds__(768, 3) void tok_mlp16_f16x3_kernel(TokMlpParams p)
+{
+    constexpr int KS = C / 32, U = C / 16, HALF = C * 128, NW = 12, NS = 4;        // HALF: bytes of one ring stage
+    constexpr int DPW = HALF / (NW * 1024);                                        // DMA instructions per stage and wave
+    static_assert(HALF % (NW * 1024) == 0, "a stage must be whole DMA rounds of the workgroup");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char mlp_smem[];
+    unsigned char* ring = mlp_smem;                                     // NS x HALF
+    float* b1s = reinterpret_cast<float*>(mlp_smem + NS * HALF);        // [32 NT]
+    float* gs = b1s + 32 * p.NT;                                        // gamma [C] | beta [C] | bias2 [C]
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned ring_base = (unsigned)(size_t)(tk_lds_void*)ring;
+    const int nstage = 2 * p.NT;
+
+    auto issue = [&](int st) {                                          // stage st (clamped) -> ring slot st % NS
+        const int sc = st < nstage ? st : nstage - 1;                   // past the end: a harmless re-fetch into a finished slot
+        const char* src = reinterpret_cast<const char*>(p.image) + (int64_t)sc * HALF + wave * 1024 + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (st % NS) * HALF + wave * 1024);
+#pragma unroll
+        for (int r = 0; r < DPW; ++r)
+            __builtin_amdgcn_global_load_lds((tk_gbl_void*)(src + r * (NW * 1024)), (tk_lds_void*)(size_t)(dst + r * (NW * 1024)), 16, 0, 0);
+    };
+    for (int i = tid; i < 32 * p.NT; i += 768) b1s[i] = p.bias1[i];
+    for (int i = tid; i < C; i += 768) { gs[i] = p.gamma[i]; gs[C + i] = p.beta[i]; gs[2 * C + i] = p.bias2[i]; }
+    __syncthreads();
+
+    // ---- LN2 of the wave's 16 tokens: lane (lr, lq) holds channels 32 ks + 8 lq + e of token lr
+    const int64_t tok = (int64_t)blockIdx.x * (NW * 16) + wave * 16 + lr;
+    const bool live = tok < p.T;
+    float* xrow = p.x + (live ? tok : 0) * C;
+    float xv[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (live) { a = *reinterpret_cast<const float4*>(xrow + 32 * ks + 8 * lq); b = *reinterpret_cast<const float4*>(xrow + 32 * ks + 8 * lq + 4); }
+        xv[ks][0] = a.x; xv[ks][1] = a.y; xv[ks][2] = a.z; xv[ks][3] = a.w;
+        xv[ks][4] = b.x; xv[ks][5] = b.y; xv[ks][6] = b.z; xv[ks][7] = b.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += xv[ks][e];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[ks][e] - mean; sq += d * d; }
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + p.eps);
+    f16x8 xh[KS], xl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = 32 * ks + 8 * lq + e;
+            v[e] = (xv[ks][e] - mean) * rstd * gs[ch] + gs[C + ch];
+        }
+        tk_split8(v, xh[ks], xl[ks]);
+    }
+
+    tk_f32x4 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = tk_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the x loads above have been consumed: only DMA requests are in flight from here on (DPW per stage and wave, in order)
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue(st);
+    f16x8 hh, hl;
+    for (int g = 0; g < p.NT; ++g) {
+        // ---- first half: H^T = W1[group g] xn^T, two 16-unit tiles, + bias + GELU + split
+        tk_wait_vm<(NS - 2) * DPW>();                        // this wave's share of stage 2 g has landed ...
+        __syncthreads();                                     // ... everyone's has, and nobody reads stage 2 g - 1 any more
+        issue(2 * g + NS - 1);
+        {
+            const unsigned char* st = ring + ((2 * g) % NS) * HALF + lane * 16;
+            tk_f32x4 h[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                h[j] = tk_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(st + ((j * KS + ks) * 2) * 1024);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(st + ((j * KS + ks) * 2 + 1) * 1024);
+                    const f16x8 wd = tk_lift_down(wh);
+                    h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd, xl[ks], h[j], 0, 0, 0);
+                    h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[ks], h[j], 0, 0, 0);
+                    h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], h[j], 0, 0, 0);
+                }
+            }
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 b4 = *reinterpret_cast<const float4*>(b1s + 32 * g + 16 * j + 4 * lq);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = tk_gelu(h[j][e] * p.scale1 + bb[e]);
+            }
+            tk_split8(v, hh, hl);
+        }
+        // ---- second half: out^T += W2[:, group g] H^T
+        tk_wait_vm<(NS - 2) * DPW>();
+        __syncthreads();
+        issue(2 * g + NS);
+        {
+            const unsigned char* st = ring + ((2 * g + 1) % NS) * HALF + lane * 16;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(st + (u * 2) * 1024);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(st + (u * 2 + 1) * 1024);
+                const f16x8 wd = tk_lift_down(wh);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd, hl, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, acc[u], 0, 0, 0);
+            }
+        }
+    }
+    tk_wait_vm<0>();                                         // the tail's dummy requests must not outlive the workgroup's LDS
+
+    // ---- out^T tiles are row pieces already: channels 16 u + 4 lq .. + 3 of token lr
+    if (live) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float* o = xrow + 16 * u + 4 * lq;
+            const float4 b2 = *reinterpret_cast<const float4*>(gs + 2 * C + 16 * u + 4 * lq);
+            float4 v = *reinterpret_cast<const float4*>(o);
+            v.x += acc[u][0] * p.scale2 + b2.x; v.y += acc[u][1] * p.scale2 + b2.y;
+            v.z += acc[u][2] * p.scale2 + b2.z; v.w += acc[u][3] * p.scale2 + b2.w;
+            *reinterpret_cast<float4*>(o) = v;
+        }
+    }
+}
+
 extern "C" int64_t al3d_tok_mlp_image_bytes(int C, int hidden) { return (int64_t)(hidden / 32) * C * 256; }
 
 extern "C" int al3d_tok_mlp_f16x3(float* x, int64_t T, int C, int hidden, const float* gamma, const float* beta, float eps,
@@ -693,12 +840,25 @@ extern "C" int al3d_tok_mlp_f16x3(float* x, int64_t T, int C, int hidden, const 
 {
     if (T == 0) return AL3D_OK;                      // an empty row matrix has no storage
     AL3D_REQUIRE(x && gamma && beta && image && bias1 && bias2, "al3d_tok_mlp_f16x3: null pointer");
-    AL3D_REQUIRE(C == 96, "al3d_tok_mlp_f16x3: built for C = 96 (at 192 the instance needs 255 registers and a 96 KB ring and measured slower than the three launches), got %d", C);
+    AL3D_REQUIRE(C == 96 || C == 192, "al3d_tok_mlp_f16x3: built for C = 96 (32-token waves) and C = 192 (16-token waves), got %d", C);
     AL3D_REQUIRE(hidden >= 32 && hidden % 32 == 0 && T >= 0, "al3d_tok_mlp_f16x3: hidden must be a multiple of 32");
     AL3D_REQUIRE((((uintptr_t)x | (uintptr_t)image) & 15) == 0, "al3d_tok_mlp_f16x3: x / image must be 16-byte aligned");
     TokMlpParams p;
     p.x = x; p.image = (const _Float16*)image; p.gamma = gamma; p.beta = beta; p.bias1 = bias1; p.bias2 = bias2;
     p.scale1 = scale1; p.scale2 = scale2; p.eps = eps; p.T = T; p.NT = hidden / 32;
+    if (C == 192) {
+        const size_t lds16 = (size_t)4 * C * 128 + ((size_t)hidden + 3 * C) * 4;
+        AL3D_REQUIRE(lds16 <= 160 * 1024, "al3d_tok_mlp_f16x3: hidden = %d does not fit the LDS at C = 192", hidden);
+        static bool attr16 = false;
+        if (!attr16) {
+            if (hipFuncSetAttribute((const void*)tok_mlp16_f16x3_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return al3d_fail(AL3D_ELAUNCH, "al3d_tok_mlp_f16x3: cannot raise the dynamic LDS limit");
+            attr16 = true;
+        }
+        hipLaunchKernelGGL((tok_mlp16_f16x3_kernel<192>), dim3((unsigned)al3d_cdiv(T, 192)), dim3(768), lds16, (hipStream_t)stream, p);
+        AL3D_CHECK_LAUNCH("tok_mlp16_f16x3_kernel");
+        return AL3D_OK;
+    }
     // four waves (128 tokens) on a two-stage ring, two workgroups per CU (default), or eight waves on a three-stage ring, one
     // workgroup per CU (AL3D_TOK_MLP=8x3: tiles requested two ahead; measured the same: the DMA round trip is not the bound)
     static int wide = -1;

@@ -120,8 +120,8 @@ FUSED_PATCH_EMBED = _os.environ.get("AL3D_SWIN_PATCH", "fused") != "split"
 TOKEN_ORDER = _os.environ.get("AL3D_SWIN_ROWS", "token") != "window"
 # AL3D_SWIN_MLP=split: LN2 / fc1 / fc2 as three launches everywhere (default "fused": one kernel where it is faster)
 FUSED_MLP = _os.environ.get("AL3D_SWIN_MLP", "fused") != "split"
-# (embed dim 96 only: at 192 the kernel needs 255 registers and a 96 KB ring and measured slower than the three launches)
-FUSED_MLP_DIMS = (96,)
+# embed dims 96 (32-token waves) and 192 (16-token waves on the 16 x 16 x 32 product); AL3D_SWIN_MLP_DIMS=96 keeps stage 1 split
+FUSED_MLP_DIMS = tuple(int(v) for v in _os.environ.get("AL3D_SWIN_MLP_DIMS", "96,192").split(",") if v)
 
 
 class _FFN(nn.Module):
@@ -139,7 +139,7 @@ class _FFN(nn.Module):
                                                          T.PackedLinear(fc2.weight, fc2.bias)))
 
     def packed_fused(self, device, norm):
-        """LN2 + fc1 + fc2 in the fused kernel's format (``al3d_tok_mlp_f16x3``; embed dim 96)."""
+        """LN2 + fc1 + fc2 in the fused kernel's format (``al3d_tok_mlp_f16x3``; embed dims 96 / 192)."""
         fc1, fc2 = self.layers[0][0], self.layers[1]
         if getattr(self, "_pkf", None) is None:
             object.__setattr__(self, "_pkf", _Packed())
@@ -179,7 +179,7 @@ class SwinBlock(nn.Module):
             ao = T.window_attention(qkv, table, msa.num_heads, nwy, nwx, self.attn.shift_size, msa.scale, pair=True)
             T.linear(ao, proj_w, a_pair=True, residual=x, rowmap=rowmap, out=x)
         if FUSED_MLP and x.shape[-1] in FUSED_MLP_DIMS:
-            # stage 0: LN2 + fc1 + GELU + fc2 + residual as one kernel (the hidden activation stays in registers)
+            # stages 0-1: LN2 + fc1 + GELU + fc2 + residual as one kernel (the hidden activation stays in registers)
             T.mlp(x, self.ffn.packed_fused(x.device, n2))
             return x
         fc1_w, fc2_w = self.ffn.packed(x.device)

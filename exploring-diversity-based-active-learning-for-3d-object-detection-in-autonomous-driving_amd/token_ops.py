@@ -48,15 +48,28 @@ class PackedMlp:
         w1 = fc1_weight.detach().float().contiguous()            # [hidden, C]
         w2 = fc2_weight.detach().float().contiguous()            # [C, hidden]
         hidden, C = w1.shape
-        if C != 96 or hidden % 32 or tuple(w2.shape) != (C, hidden):
-            raise lib.Al3dError(f"PackedMlp: C={C} (the fused kernel is built for 96), hidden={hidden} (multiple of 32), fc2 {tuple(w2.shape)}")
+        if C not in (96, 192) or hidden % 32 or tuple(w2.shape) != (C, hidden):
+            raise lib.Al3dError(f"PackedMlp: C={C} (the fused kernel is built for 96 / 192), hidden={hidden} (multiple of 32), fc2 {tuple(w2.shape)}")
         p1, s1 = split_f16x3(w1.view(hidden, 1, C))
         p2, s2 = split_f16x3(w2.view(C, 1, hidden))
-        NT, KC, U = hidden // 32, C // 16, C // 32
-        # fc1: [plane, t, fr, kc, fh, e] -> [t, kc, plane, fh, fr, e]  (lane = fh * 32 + fr)
-        a = p1.view(2, NT, 32, KC, 2, 8).permute(1, 3, 0, 4, 2, 5).reshape(NT, KC * 2 * 64 * 8)
-        # fc2: hidden unit inside tile = 16 q + 8 e_hi + 4 fh + e_lo: [plane, u, fr, t, q, e_hi, fh, e_lo] -> [t, u, q, plane, fh, fr, e_hi, e_lo]
-        b = p2.view(2, U, 32, NT, 2, 2, 2, 4).permute(3, 1, 4, 0, 6, 2, 5, 7).reshape(NT, U * 2 * 2 * 64 * 8)
+        NT = hidden // 32
+        if C == 96:
+            KC, U = C // 16, C // 32
+            # fc1: [plane, t, fr, kc, fh, e] -> [t, kc, plane, fh, fr, e]  (lane = fh * 32 + fr)
+            a = p1.view(2, NT, 32, KC, 2, 8).permute(1, 3, 0, 4, 2, 5).reshape(NT, KC * 2 * 64 * 8)
+            # fc2: hidden unit inside tile = 16 q + 8 e_hi + 4 fh + e_lo: [plane, u, fr, t, q, e_hi, fh, e_lo] -> [t, u, q, plane, fh, fr, e_hi, e_lo]
+            b = p2.view(2, U, 32, NT, 2, 2, 2, 4).permute(3, 1, 4, 0, 6, 2, 5, 7).reshape(NT, U * 2 * 2 * 64 * 8)
+        else:
+            # 16 x 16 x 32 fragments (tok_mlp16_f16x3_kernel): lane = lq * 16 + lr holds k-block lq of row lr
+            KS, U = C // 32, C // 16
+            # fc1: [plane, g, j, lr, ks, lq, e] -> [g, j, ks, plane, lq, lr, e]
+            a = p1.view(2, NT, 2, 16, KS, 4, 8).permute(1, 2, 4, 0, 5, 3, 6).reshape(NT, 2 * KS * 2 * 64 * 8)
+            # fc2: the k order of the accumulator-made B fragment: (lq, e) -> unit 4 lq + e (e < 4), 16 + 4 lq + e - 4 (e >= 4)
+            lq = torch.arange(4).view(4, 1)
+            e = torch.arange(8).view(1, 8)
+            perm = torch.where(e < 4, 4 * lq + e, 16 + 4 * lq + e - 4).reshape(32).to(p2.device)
+            # [plane, u, lr, g, unit] -> units permuted -> [plane, u, lr, g, lq, e] -> [g, u, plane, lq, lr, e]
+            b = p2.view(2, U, 16, NT, 32)[..., perm].view(2, U, 16, NT, 4, 8).permute(3, 1, 0, 4, 2, 5).reshape(NT, U * 2 * 64 * 8)
         self.image = torch.cat([a, b], dim=1).contiguous()
         assert self.image.numel() * 2 == lib.load().al3d_tok_mlp_image_bytes(C, hidden)
         self.C, self.hidden, self.eps = C, hidden, float(eps)

@@ -673,11 +673,15 @@ int al3d_conv3x3_nhwc_f16x3_wino(const float* in, const void* wgt_wino, const fl
  *   position's q / k / v row is bias_qkv [3C] (what the qkv layer makes of the zero row the padding puts after the norm) and
  *   its output is cropped -- so LN1, the qkv and the projection GEMMs run on the H x W tokens, not on the padded windows
  *   (16 x 44 tokens pad to 21 x 49: 1.46x the rows; 8 x 22 to 14 x 28: 2.2x).
- * al3d_tok_mlp_f16x3: the MLP half of a block as one kernel, x[t] += fc2(GELU(fc1(LN(x[t])))) in place, for C = 96
- *   (stage 0, whose separate LN / fc1 / fc2 launches are bandwidth-bound; the [T, hidden] activation stays in registers).
- *   image (al3d_tok_mlp_image_bytes): per 32 hidden units t the MFMA A-operand fragments [64 lanes][8 halves] of
+ * al3d_tok_mlp_f16x3: the MLP half of a block as one kernel, x[t] += fc2(GELU(fc1(LN(x[t])))) in place, for C = 96 / 192
+ *   (stages 0-1, whose separate LN / fc1 / fc2 launches are bandwidth-bound; the [T, hidden] activation stays in registers).
+ *   image (al3d_tok_mlp_image_bytes): C = 96 (32 x 32 x 16 products, 32 tokens per wave): per 32 hidden units t the MFMA
+ *   A-operand fragments [64 lanes][8 halves] of
  *   fc1.weight[32t + lane%32][16kc + 8(lane/32) + e], kc < C/16, planes (wh, wl) of al3d_split_f16x3, then of
  *   fc2.weight[32u + lane%32][32t + 16q + 8(e/4) + 4(lane/32) + e%4], u < C/32, q < 2, planes (wh, wl);
+ *   C = 192 (16 x 16 x 32 products, 16 tokens per wave): per 32 hidden units t the fragments of
+ *   fc1.weight[32t + 16j + lane%16][32ks + 8(lane/16) + e], j < 2, ks < C/32, planes (wh, wl), then of
+ *   fc2.weight[16u + lane%16][32t + (e < 4 ? 4(lane/16) + e : 16 + 4(lane/16) + e - 4)], u < C/16, planes (wh, wl);
  *   scale1 / scale2 = 2^-s of the two splits; bias1 [hidden], bias2 [C]; hidden % 32 == 0.
  * al3d_tok_attn_block_f16x3: the attention half of a block as one kernel, x += proj(W-MSA(LN(x))) in place on the B maps of
  *   H x W token rows x [B*H*W][C], for C = 96 / 192 (stages 0-1: their LN1 / qkv / attention / proj launches are

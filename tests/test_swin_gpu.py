@@ -375,7 +375,7 @@ def test_assembled_camera_lidar_model_runs_and_is_deterministic():
     assert len(preds) == 1 and preds[0]["bboxes"].shape[1] == 9 and len(preds[0]["scores"]) > 0
 
 
-@pytest.mark.parametrize("T_,C", [(1000, 96), (129, 96), (257, 96), (32, 96)])
+@pytest.mark.parametrize("T_,C", [(1000, 96), (129, 96), (257, 96), (32, 96), (1000, 192), (193, 192), (385, 192), (16, 192), (5, 192)])
 def test_fused_mlp_kernel_matches_float64_and_the_split_path(T_, C):
     """``al3d_tok_mlp_f16x3`` (LN2 + fc1 + exact GELU + fc2 + residual as one kernel, hidden activation in registers,
     everything transposed so an accumulator is the next product's operand) against the same formula in float64, at the
@@ -404,14 +404,16 @@ def test_fused_mlp_kernel_matches_float64_and_the_split_path(T_, C):
     assert e_fused <= 1e-5 * scale, (e_fused, scale)
 
 
-def test_swin_block_fused_and_split_mlp_agree():
+@pytest.mark.parametrize("C,heads", [(96, 3), (192, 6)])
+def test_swin_block_fused_and_split_mlp_agree(C, heads):
     """A whole block with the fused MLP (default at embed dims 96 / 192) against the same block with AL3D_SWIN_MLP=split
     semantics: agreement at fp32 rounding level of the residual stream."""
     from al3d.models import swin as S
     from al3d.synthetic import seed_modules_
-    blk = seed_modules_(S.SwinBlock(96, 3, 384, 7, shift=True), 5).to(DEV)
+    assert C in S.FUSED_MLP_DIMS
+    blk = seed_modules_(S.SwinBlock(C, heads, 4 * C, 7, shift=True), 5).to(DEV)
     B, H, W = 2, 14, 21
-    x = torch.randn(B * H * W, 96, generator=torch.Generator().manual_seed(1)).to(DEV)
+    x = torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(1)).to(DEV)
     geom = S._Geometry.of(B, H, W, 7, torch.device(DEV))
     saved = S.FUSED_MLP
     try:
@@ -450,11 +452,11 @@ def test_gelu_epilogue_accuracy():
     assert torch.isnan(out[0]) and (out[1] == float("inf") or torch.isnan(out[1]))
 
 
-def test_fused_mlp_edge_cases():
+@pytest.mark.parametrize("C", [96, 192])
+def test_fused_mlp_edge_cases(C):
     """Empty input, a non-finite token (its row becomes NaN, the other rows of the same wave are untouched: tokens are the
     independent n dimension of every product) and the loud failures of the fused MLP entry point."""
     from al3d import lib, token_ops as Tk
-    C = 96
     g = torch.Generator().manual_seed(9)
     mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
     pk = Tk.PackedMlp(mk(C) * 0.1 + 1, mk(C) * 0.1, 1e-5, mk(4 * C, C) / C ** 0.5, mk(4 * C) * 0.1, mk(C, 4 * C) / (4 * C) ** 0.5, mk(C) * 0.1)
@@ -469,9 +471,9 @@ def test_fused_mlp_edge_cases():
     keep = [i for i in range(70) if i not in (5, 40)]
     assert torch.equal(out[keep], clean[keep])
     with pytest.raises(lib.Al3dError):
-        Tk.PackedMlp(mk(192), mk(192), 1e-5, mk(768, 192), mk(768), mk(192, 768), mk(192))      # built for C = 96
+        Tk.PackedMlp(mk(384), mk(384), 1e-5, mk(1536, 384), mk(1536), mk(384, 1536), mk(384))    # built for C = 96 / 192
     with pytest.raises(lib.Al3dError):
-        Tk.mlp(mk(8, 192), pk)
+        Tk.mlp(mk(8, 288 - C), pk)
 
 
 def _attn_half_float64(x, hw, blk):
