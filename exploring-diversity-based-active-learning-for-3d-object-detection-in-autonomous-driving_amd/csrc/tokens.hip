@@ -718,6 +718,8 @@ __global__ __launch_bounds__(768, 3) void tok_mlp16_f16x3_kernel(TokMlpParams p)
         for (int r = 0; r < DPW; ++r)
             __builtin_amdgcn_global_load_lds((tk_gbl_void*)(src + r * (NW * 1024)), (tk_lds_void*)(size_t)(dst + r * (NW * 1024)), 16, 0, 0);
     };
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue(st);                     // the ring fills while the rows are loaded and normalised
     for (int i = tid; i < 32 * p.NT; i += 768) b1s[i] = p.bias1[i];
     for (int i = tid; i < C; i += 768) { gs[i] = p.gamma[i]; gs[C + i] = p.beta[i]; gs[2 * C + i] = p.bias2[i]; }
     __syncthreads();
@@ -764,30 +766,36 @@ __global__ __launch_bounds__(768, 3) void tok_mlp16_f16x3_kernel(TokMlpParams p)
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = tk_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // the x loads above have been consumed: only DMA requests are in flight from here on (DPW per stage and wave, in order)
-#pragma unroll
-    for (int st = 0; st < NS - 1; ++st) issue(st);
+    // the x loads above have been consumed (and with them, in order, the ring's first stages): from here on only the DMA
+    // requests of the loop are in flight (DPW per stage and wave)
     f16x8 hh, hl;
     for (int g = 0; g < p.NT; ++g) {
-        // ---- first half: H^T = W1[group g] xn^T, two 16-unit tiles, + bias + GELU + split
+        // ---- first half: H^T = W1[group g] xn^T, two 16-unit tiles, + bias + GELU + split.  Fragments are requested one
+        // ahead of their products (the LDS round trip of fragment i + 1 runs under the products of fragment i); the
+        // correction product wh xl' goes to its own accumulator and is scaled once (2^-11) instead of scaling every wh.
+        // (Measured and not kept: a third of the waves one step behind the others, so that the GELU phases of a SIMD's
+        // three waves do not coincide -- 0.78 against 0.65 ms.)
         tk_wait_vm<(NS - 2) * DPW>();                        // this wave's share of stage 2 g has landed ...
         __syncthreads();                                     // ... everyone's has, and nobody reads stage 2 g - 1 any more
         issue(2 * g + NS - 1);
         {
             const unsigned char* st = ring + ((2 * g) % NS) * HALF + lane * 16;
-            tk_f32x4 h[2];
+            tk_f32x4 h[2], hc[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                h[j] = tk_f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) { h[j] = tk_f32x4{0.f, 0.f, 0.f, 0.f}; hc[j] = h[j]; }
+            f16x8 wh[2], wl[2];
+            wh[0] = *reinterpret_cast<const f16x8*>(st);
+            wl[0] = *reinterpret_cast<const f16x8*>(st + 1024);
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const f16x8 wh = *reinterpret_cast<const f16x8*>(st + ((j * KS + ks) * 2) * 1024);
-                    const f16x8 wl = *reinterpret_cast<const f16x8*>(st + ((j * KS + ks) * 2 + 1) * 1024);
-                    const f16x8 wd = tk_lift_down(wh);
-                    h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd, xl[ks], h[j], 0, 0, 0);
-                    h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[ks], h[j], 0, 0, 0);
-                    h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], h[j], 0, 0, 0);
+            for (int i = 0; i < 2 * KS; ++i) {
+                if (i + 1 < 2 * KS) {
+                    wh[(i + 1) & 1] = *reinterpret_cast<const f16x8*>(st + ((i + 1) * 2) * 1024);
+                    wl[(i + 1) & 1] = *reinterpret_cast<const f16x8*>(st + ((i + 1) * 2 + 1) * 1024);
                 }
+                const int j = i / KS, ks = i % KS;
+                hc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i & 1], xl[ks], hc[j], 0, 0, 0);
+                h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i & 1], xh[ks], h[j], 0, 0, 0);
+                h[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i & 1], xh[ks], h[j], 0, 0, 0);
             }
             float v[8];
 #pragma unroll
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(768, 3) void tok_mlp16_f16x3_kernel(TokMlpParams p)
                 const float4 b4 = *reinterpret_cast<const float4*>(b1s + 32 * g + 16 * j + 4 * lq);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * j + e] = tk_gelu(h[j][e] * p.scale1 + bb[e]);
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = tk_gelu((h[j][e] + hc[j][e] * 0.00048828125f) * p.scale1 + bb[e]);
             }
             tk_split8(v, hh, hl);
         }
@@ -805,14 +813,19 @@ __global__ __launch_bounds__(768, 3) void tok_mlp16_f16x3_kernel(TokMlpParams p)
         issue(2 * g + NS);
         {
             const unsigned char* st = ring + ((2 * g + 1) % NS) * HALF + lane * 16;
+            f16x8 wh[2], wl[2];
+            wh[0] = *reinterpret_cast<const f16x8*>(st);
+            wl[0] = *reinterpret_cast<const f16x8*>(st + 1024);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(st + (u * 2) * 1024);
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(st + (u * 2 + 1) * 1024);
-                const f16x8 wd = tk_lift_down(wh);
+                if (u + 1 < U) {
+                    wh[(u + 1) & 1] = *reinterpret_cast<const f16x8*>(st + ((u + 1) * 2) * 1024);
+                    wl[(u + 1) & 1] = *reinterpret_cast<const f16x8*>(st + ((u + 1) * 2 + 1) * 1024);
+                }
+                const f16x8 wd = tk_lift_down(wh[u & 1]);
                 acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd, hl, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u & 1], hh, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1], hh, acc[u], 0, 0, 0);
             }
         }
     }
