@@ -728,25 +728,33 @@ __global__ __launch_bounds__(768, 3) void tok_mlp16_f16x3_kernel(TokMlpParams p)
     const int64_t tok = (int64_t)blockIdx.x * (NW * 16) + wave * 16 + lr;
     const bool live = tok < p.T;
     float* xrow = p.x + (live ? tok : 0) * C;
-    float xv[KS][8];
+    // three passes over the lane's 6 x 32 bytes (sum; squared deviations; normalise + split), each re-reading them (L2 hits)
+    // instead of holding 48 values beside the 48 registers of the split: held, the prologue spilled 34 registers per lane --
+    // 150 MB of scratch writes and as many reads per launch (PMC WRITE_SIZE 346 MB against 208 MB of output)
+    auto ld8 = [&](int ks, float (&v)[8]) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (live) { a = *reinterpret_cast<const float4*>(xrow + 32 * ks + 8 * lq); b = *reinterpret_cast<const float4*>(xrow + 32 * ks + 8 * lq + 4); }
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    };
     float sum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (live) { a = *reinterpret_cast<const float4*>(xrow + 32 * ks + 8 * lq); b = *reinterpret_cast<const float4*>(xrow + 32 * ks + 8 * lq + 4); }
-        xv[ks][0] = a.x; xv[ks][1] = a.y; xv[ks][2] = a.z; xv[ks][3] = a.w;
-        xv[ks][4] = b.x; xv[ks][5] = b.y; xv[ks][6] = b.z; xv[ks][7] = b.w;
+        float v[8];
+        ld8(ks, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sum += xv[ks][e];
+        for (int e = 0; e < 8; ++e) sum += v[e];
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float mean = sum / (float)C;
     float sq = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+        ld8(ks, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = xv[ks][e] - mean; sq += d * d; }
+        for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
+    }
     sq += __shfl_xor(sq, 16);
     sq += __shfl_xor(sq, 32);
     const float rstd = 1.0f / sqrtf(sq / (float)C + p.eps);
@@ -754,14 +762,16 @@ __global__ __launch_bounds__(768, 3) void tok_mlp16_f16x3_kernel(TokMlpParams p)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         float v[8];
+        ld8(ks, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ch = 32 * ks + 8 * lq + e;
-            v[e] = (xv[ks][e] - mean) * rstd * gs[ch] + gs[C + ch];
+            v[e] = (v[e] - mean) * rstd * gs[ch] + gs[C + ch];
         }
         tk_split8(v, xh[ks], xl[ks]);
     }
 
+    __builtin_amdgcn_sched_barrier(0);                       // the accumulators start to live only here (the prologue spilled)
     tk_f32x4 acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = tk_f32x4{0.f, 0.f, 0.f, 0.f};

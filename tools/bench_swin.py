@@ -35,6 +35,7 @@ import json
 t0_, t1_ = S * 6 * 64 * 176, S * 6 * 32 * 88
 print(json.dumps({"algorithmic_mb": {"tok_attn_block_f16x3_kernel<96,": t0_ * 96 * 8 / 1e6,
                                      "tok_attn_block_f16x3_kernel<192,": t1_ * 192 * 8 / 1e6,
-                                     "tok_mlp_f16x3_kernel<96,": t0_ * 96 * 8 / 1e6}}))
+                                     "tok_mlp_f16x3_kernel<96,": t0_ * 96 * 8 / 1e6,
+                                     "tok_mlp16_f16x3_kernel<192>": t1_ * 192 * 8 / 1e6}}))
 print(f"swin-t {S} samples ({S * 6} images): {dt * 1e3:.2f} ms per forward = {dt * 1e3 / S:.2f} ms per sample, "
       f"{gflop / dt / 1e3:.1f} TFLOP/s algorithmic")
