@@ -107,6 +107,17 @@ __global__ void sp_down_claim_kernel(const int* __restrict__ coords_in, int n_in
 // packed to a bit mask + popcount per 32-cell word; the popcounts are scanned and one thread per
 // non-empty word numbers its set bits in ascending order -- the same (b, z, y, x) raster numbering a
 // cell-wise scan gives, for 1/16 of its traffic.
+// Blocked numbering (al3d_sp_down_sites_blocked): the flag map is laid out block-major -- 8 x 8 (y, x) columns
+// over all z, cell' = ((((b NYB + y/8) NXB + x/8) D + z) 8 + y%8) 8 + x%8 -- so the same pack / scan / assign passes
+// number the sites column by column: consecutive rows form compact patches whose z neighbours are in the patch
+// (csrc/spconv_blk.hip).  grid_out keeps the plain (b, z, y, x) layout.
+__device__ __forceinline__ int64_t sp_cell_blocked(const SpDims& g, int b, int z, int y, int x)
+{
+    const int nyb = (g.H + 7) >> 3, nxb = (g.W + 7) >> 3;
+    return (((((int64_t)b * nyb + (y >> 3)) * nxb + (x >> 3)) * g.D + z) << 6) | ((y & 7) << 3) | (x & 7);
+}
+
+template <bool BLOCKED>
 __global__ void sp_down_mark_kernel(const int* __restrict__ coords_in, int n_in, SpConvGeom q, SpDims go,
                                     unsigned char* __restrict__ flags)
 {
@@ -123,7 +134,7 @@ __global__ void sp_down_mark_kernel(const int* __restrict__ coords_in, int n_in,
             for (int kx = ax % q.sw; kx < q.kw; kx += q.sw) {
                 const int ox = (ax - kx) / q.sw;
                 if (ax - kx < 0 || ox >= go.W) continue;
-                flags[sp_cell(go, b, oz, oy, ox)] = 1;
+                flags[BLOCKED ? sp_cell_blocked(go, b, oz, oy, ox) : sp_cell(go, b, oz, oy, ox)] = 1;
             }
         }
     }
@@ -148,6 +159,7 @@ __global__ void sp_down_pack_kernel(const unsigned char* __restrict__ flags, int
     cnt[w] = __popc(m);
 }
 
+template <bool BLOCKED>
 __global__ void sp_down_assign_kernel(const unsigned* __restrict__ bits, const int* __restrict__ wscan,
                                       int64_t words, SpDims go, int* __restrict__ grid_out,
                                       int* __restrict__ coords_out, int cap)
@@ -161,14 +173,23 @@ __global__ void sp_down_assign_kernel(const unsigned* __restrict__ bits, const i
         const int bit = __builtin_ctz(m);
         m &= m - 1u;
         const int64_t cell = w * 32 + bit;
-        grid_out[cell] = row;
-        if (row < cap) {
-            int64_t t = cell;
-            const int x = (int)(t % go.W); t /= go.W;
-            const int y = (int)(t % go.H); t /= go.H;
-            const int z = (int)(t % go.D); t /= go.D;
-            *reinterpret_cast<int4*>(coords_out + 4 * (int64_t)row) = make_int4((int)t, z, y, x);
+        int64_t t = cell;
+        int x, y, z;
+        if constexpr (BLOCKED) {
+            const int nyb = (go.H + 7) >> 3, nxb = (go.W + 7) >> 3;
+            const int xx = (int)(t & 7), yy = (int)((t >> 3) & 7);
+            t >>= 6;
+            z = (int)(t % go.D); t /= go.D;
+            x = (int)(t % nxb) * 8 + xx; t /= nxb;
+            y = (int)(t % nyb) * 8 + yy; t /= nyb;
+            grid_out[sp_cell(go, (int)t, z, y, x)] = row;
+        } else {
+            x = (int)(t % go.W); t /= go.W;
+            y = (int)(t % go.H); t /= go.H;
+            z = (int)(t % go.D); t /= go.D;
+            grid_out[cell] = row;
         }
+        if (row < cap) *reinterpret_cast<int4*>(coords_out + 4 * (int64_t)row) = make_int4((int)t, z, y, x);
         ++row;
     }
 }
@@ -523,21 +544,36 @@ extern "C" int al3d_sp_down_claim(const int* coords_in, int n_in, const int* ksi
     return AL3D_OK;
 }
 
-extern "C" int64_t al3d_sp_down_sites_workspace_bytes(int B, int OD, int OH, int OW)
+static int64_t sp_down_cells(int B, int OD, int OH, int OW, bool blocked)
 {
-    const int64_t cells = (int64_t)B * OD * OH * OW;
-    const int64_t words = (cells + 31) / 32;
+    return blocked ? (int64_t)B * ((OH + 7) / 8) * ((OW + 7) / 8) * OD * 64 : (int64_t)B * OD * OH * OW;
+}
+
+static int64_t sp_down_sites_ws(int B, int OD, int OH, int OW, bool blocked)
+{
+    const int64_t words = (sp_down_cells(B, OD, OH, OW, blocked) + 31) / 32;
     return al3d_align(words * 32, 256) + 3 * al3d_align(words * 4, 256) + al3d_scan_workspace_bytes(words);
 }
 
-extern "C" int al3d_sp_down_sites(const int* coords_in, int n_in, const int* ksize, const int* stride,
-                                  const int* pad, int B, int OD, int OH, int OW, int* grid_out,
-                                  int* coords_out, int* counter, int cap, void* workspace, void* stream)
+extern "C" int64_t al3d_sp_down_sites_workspace_bytes(int B, int OD, int OH, int OW)
+{
+    return sp_down_sites_ws(B, OD, OH, OW, false);
+}
+
+extern "C" int64_t al3d_sp_down_sites_blocked_workspace_bytes(int B, int OD, int OH, int OW)
+{
+    return sp_down_sites_ws(B, OD, OH, OW, true);
+}
+
+template <bool BLOCKED>
+static int sp_down_sites_impl(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                              const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                              int* coords_out, int* counter, int cap, void* workspace, void* stream)
 {
     AL3D_REQUIRE(ksize && stride && pad && grid_out && coords_out && counter && workspace,
                  "al3d_sp_down_sites: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t cells = (int64_t)B * OD * OH * OW;
+    const int64_t cells = sp_down_cells(B, OD, OH, OW, BLOCKED);
     AL3D_REQUIRE(cells > 0 && cells < (1LL << 31), "al3d_sp_down_sites: bad grid");
     AL3D_REQUIRE(((uintptr_t)coords_out & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
                  "al3d_sp_down_sites: coords_out / workspace must be 16-byte aligned");
@@ -554,12 +590,12 @@ extern "C" int al3d_sp_down_sites(const int* coords_in, int n_in, const int* ksi
             return al3d_fail(AL3D_ELAUNCH, "al3d_sp_down_sites: memset failed");
         SpConvGeom q = {ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2]};
         SpDims go = {B, OD, OH, OW};
-        hipLaunchKernelGGL(sp_down_mark_kernel, dim3(blocks_for(n_in, 256)), dim3(256), 0, s, coords_in, n_in,
+        hipLaunchKernelGGL(sp_down_mark_kernel<BLOCKED>, dim3(blocks_for(n_in, 256)), dim3(256), 0, s, coords_in, n_in,
                            q, go, flags);
         hipLaunchKernelGGL(sp_down_pack_kernel, dim3(blocks_for(words, 256)), dim3(256), 0, s, flags, words, bits, cnt);
         int rc = al3d_exclusive_scan_i32(cnt, wscan, words, scan_ws, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(sp_down_assign_kernel, dim3(blocks_for(words, 256)), dim3(256), 0, s, bits, wscan,
+        hipLaunchKernelGGL(sp_down_assign_kernel<BLOCKED>, dim3(blocks_for(words, 256)), dim3(256), 0, s, bits, wscan,
                            words, go, grid_out, coords_out, cap);
         hipLaunchKernelGGL(sp_count_tail_kernel, dim3(1), dim3(64), 0, s, bits, wscan, words, counter);
     } else if (hipMemsetAsync(counter, 0, 4, s) != hipSuccess) {
@@ -567,6 +603,22 @@ extern "C" int al3d_sp_down_sites(const int* coords_in, int n_in, const int* ksi
     }
     AL3D_CHECK_LAUNCH("sp_down_sites");
     return AL3D_OK;
+}
+
+extern "C" int al3d_sp_down_sites(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                                  const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                                  int* coords_out, int* counter, int cap, void* workspace, void* stream)
+{
+    return sp_down_sites_impl<false>(coords_in, n_in, ksize, stride, pad, B, OD, OH, OW, grid_out, coords_out, counter, cap,
+                                     workspace, stream);
+}
+
+extern "C" int al3d_sp_down_sites_blocked(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                                          const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                                          int* coords_out, int* counter, int cap, void* workspace, void* stream)
+{
+    return sp_down_sites_impl<true>(coords_in, n_in, ksize, stride, pad, B, OD, OH, OW, grid_out, coords_out, counter, cap,
+                                    workspace, stream);
 }
 
 extern "C" int al3d_sp_down_table(const int* coords_out, int n_out, const int* ksize, const int* stride,

@@ -257,6 +257,46 @@ def sparse_rng(cin, cout):
     return (cin, cout) in (RNG_BUILT if SPCONV == "rng" else RNG_PAIRS & RNG_BUILT)
 
 
+# Block-staged kernel (csrc/spconv_blk.hip): 27-tap submanifold layers of these channel pairs stage the union of a
+# 128-row chunk's neighbourhoods once; the encoder then numbers the level's rows column by column
+# (al3d_sp_down_sites_blocked).  AL3D_BLK_PAIRS: dev override, e.g. "32x32,64x64,128x128" or "" for none
+BLK_BUILT = {(32, 32), (64, 64), (128, 128)}
+BLK_PAIRS = {(32, 32), (64, 64), (128, 128)}
+if _os.environ.get("AL3D_BLK_PAIRS") is not None:
+    BLK_PAIRS = {tuple(int(v) for v in t.split("x")) for t in _os.environ["AL3D_BLK_PAIRS"].split(",") if t}
+
+
+def sparse_blk(cin, cout, K=27):
+    """True when the 27-tap submanifold f16x3 layer cin -> cout runs on the block-staged kernel."""
+    return MATH == "f16x3" and SPCONV == "auto" and K == 27 and (cin, cout) in (BLK_PAIRS & BLK_BUILT)
+
+
+class BlkPlan:
+    """Per-level plan of the block-staged kernel (al3d_sp_block_plan): chunk headers, staged row lists, local indices."""
+
+    def __init__(self, hdr, rows, loc, R, cap):
+        self.hdr, self.rows, self.loc, self.R, self.cap = hdr, rows, loc, R, cap
+
+
+def block_shape(cin, cout):
+    import ctypes
+    R, cap = ctypes.c_int(0), ctypes.c_int(0)
+    lib.call("al3d_sp_block_shape", cin, cout, ctypes.byref(R), ctypes.byref(cap))
+    return R.value, cap.value
+
+
+def block_plan(nbr, n_out, cin, cout):
+    """Plan of a tiled 27-tap table for the block-staged kernel of cin -> cout."""
+    dev = nbr.device
+    R, cap = block_shape(cin, cout)
+    chunks = (max(n_out, 1) + R - 1) // R
+    hdr = torch.empty((chunks, 2), dtype=torch.int32, device=dev)
+    rows = torch.empty((chunks, cap), dtype=torch.int32, device=dev)
+    loc = torch.empty((chunks, 27, R), dtype=torch.int16, device=dev)
+    lib.call("al3d_sp_block_plan", _ptr(nbr), nbr.shape[1], 27, n_out, R, cap, _ptr(hdr), _ptr(rows), _ptr(loc), _stream())
+    return BlkPlan(hdr, rows, loc, R, cap)
+
+
 # Level-0 layers (16 input channels, 27 taps) on raster-ordered rows (csrc/spconv_l0.hip): AL3D_L0 = "raster"
 # (default: the encoder renumbers the voxelizer's rows in raster order and runs these layers as item streams with
 # LDS-resident weights) | "off" (first-appearance order, register-gather kernel: round 3's path).  R16_COUTS: the output
@@ -591,7 +631,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
     if mfma is None:
         mfma = (cin, cout) in MFMA_PAIRS and ({"bf16x6": "wave2", "f16x3": "glds_f16x3" if sparse_glds(cin, cout) else "wave2_f16x3"}
                                                .get(sparse_math(), True))
-    tiled = mfma in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3", "r16_f16x3")     # pitched table + per-tile tap masks
+    tiled = mfma in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3", "r16_f16x3", "blk_f16x3")     # pitched table + per-tile tap masks
     tmask = None
     if subm:
         if tiled:
@@ -628,7 +668,7 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
             lib.call("al3d_sp_down_table", _ptr(ocoords), n_out, I3(*k), I3(*s3), I3(*p3), batch, D_, H_, W_,
                      _ptr(grid_in), _ptr(nbr), st)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    if io and mfma not in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3", "r16_f16x3"):
+    if io and mfma not in ("glds_f16x3", "wave2_f16x3_tiles", "rng_f16x3", "r16_f16x3", "blk_f16x3"):
         raise lib.Al3dError("sparse_conv_layer: pair rows exist for the tiled f16x3 kernels only")
     if mfma == "glds_f16x3":
         w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
@@ -644,6 +684,16 @@ def sparse_conv_layer(feats, coords, batch, in_shape, weight, ksize, stride, pad
         lib.call("al3d_sp_tile_ranges", _ptr(nbr), nbr.shape[1], K, n_out, _ptr(trng), st)
         lib.call("al3d_sp_conv_rng_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), _ptr(trng), K,
                  _ptr(pk.data), cin, cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(out), n_out, io, st)
+    elif mfma == "blk_f16x3":
+        if not subm or K != 27:
+            raise lib.Al3dError("sparse_conv_layer: the block-staged kernel serves 27-tap submanifold layers")
+        w3, sc3 = split_f16x3(w.permute(2, 0, 1).contiguous(), scale)
+        pk = pack_glds_f16x3(w3)
+        plan = block_plan(nbr, n_out, cin, cout)
+        sparse_conv_layer.last_plan = plan
+        lib.call("al3d_sp_conv_blk_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), _ptr(plan.hdr), _ptr(plan.rows),
+                 _ptr(plan.loc), K, _ptr(pk.data), cin, cout, _ptr(sc3), _ptr(shift), _ptr(residual), 1 if relu else 0,
+                 _ptr(out), n_out, io, st)
     elif mfma == "r16_f16x3":
         if K != 27 or cin != 16:
             raise lib.Al3dError("sparse_conv_layer: the item-stream kernel serves 27-tap layers with 16 input channels")

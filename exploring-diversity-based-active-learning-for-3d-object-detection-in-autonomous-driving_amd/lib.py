@@ -64,6 +64,13 @@ SIGNATURES = {
     "al3d_sp_down_sites_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "al3d_sp_down_sites": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
                                    c_p, c_int, c_p, c_p]),
+    "al3d_sp_down_sites_blocked_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "al3d_sp_down_sites_blocked": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
+                                           c_p, c_int, c_p, c_p]),
+    "al3d_sp_block_shape": (c_int, [c_int, c_int, c_p, c_p]),
+    "al3d_sp_block_plan": (c_int, [c_p, c_i64, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p]),
+    "al3d_sp_conv_blk_f16x3": (c_int, [c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p,
+                                       c_int, c_p, c_int, c_int, c_p]),
     "al3d_sp_down_table": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
                                    c_p]),
     "al3d_sp_conv_f32": (c_int, [c_p, c_p, c_int, c_p, c_int, c_int, c_p, c_p, c_p, c_int, c_p, c_int,

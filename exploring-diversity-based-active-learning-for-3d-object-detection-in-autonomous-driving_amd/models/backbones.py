@@ -100,7 +100,8 @@ class _SparseEncoderBase(nn.Module):
 
     def _prepare(self, device):
         """Pack weights / fold BN once per device (eval only)."""
-        if getattr(self, "_packed_dev", None) == (device, D.MATH, D.SPCONV, D.L0, tuple(sorted(D.R16_COUTS))):
+        if getattr(self, "_packed_dev", None) == (device, D.MATH, D.SPCONV, D.L0, tuple(sorted(D.R16_COUTS)),
+                                                  tuple(sorted(D.BLK_PAIRS))):
             return
         plan = []
         # The input level's rows may be renumbered (raster order, csrc/spconv_l0.hip) only if they never leave the encoder:
@@ -135,7 +136,7 @@ class _SparseEncoderBase(nn.Module):
                     i += 1
             plan.append(dict(kind="stage_end"))
         self._plan = plan
-        self._packed_dev = (device, D.MATH, D.SPCONV, D.L0, tuple(sorted(D.R16_COUTS)))
+        self._packed_dev = (device, D.MATH, D.SPCONV, D.L0, tuple(sorted(D.R16_COUTS)), tuple(sorted(D.BLK_PAIRS)))
         self._levels = {}
 
     @staticmethod
@@ -161,12 +162,13 @@ class _SparseEncoderBase(nn.Module):
                 planes, scale = D.split_f16x3(w, scale)
                 if raster_ok and D.sparse_r16(cin, m.out_channels, w.shape[1]):
                     return D.pack_r16_f16x3(planes), scale
-                return (D.pack_glds_f16x3(planes) if D.sparse_glds(cin, m.out_channels) else planes), scale
+                blk = m.subm and D.sparse_blk(cin, m.out_channels, w.shape[1])    # block-staged kernel: the same image
+                return (D.pack_glds_f16x3(planes) if (blk or D.sparse_glds(cin, m.out_channels)) else planes), scale
             return (D.split_bf16x3(w) if D.sparse_math() == "bf16x6" else w), scale
         return w.contiguous().to(device), scale
 
     @staticmethod
-    def _conv(m, feats, nbr, K, step, residual, out, n, st, tmask=None, trng=None, io=0, items=None):
+    def _conv(m, feats, nbr, K, step, residual, out, n, st, tmask=None, trng=None, io=0, items=None, plan=None):
         """One fused sparse layer (conv + folded BN + optional residual + ReLU)."""
         res_ptr = None if residual is None else _ptr(residual)
         cin = feats.shape[-1]                    # == m.in_channels, or 16 for a zero-padded narrow first layer
@@ -176,6 +178,12 @@ class _SparseEncoderBase(nn.Module):
             lib.call("al3d_sp_conv_r16_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(items[1]), _ptr(items[0]), K,
                      _ptr(step["w"].data), cin, m.out_channels, _ptr(step["scale"]), _ptr(step["shift"]), res_ptr, 1,
                      _ptr(out), n, io, D.R16_TPW, st)
+            return
+        if plan is not None:
+            # f16x3 arithmetic, block-staged gather: the union of a chunk's neighbourhoods staged once (csrc/spconv_blk.hip)
+            lib.call("al3d_sp_conv_blk_f16x3", _ptr(feats), _ptr(nbr), nbr.shape[1], _ptr(tmask), _ptr(plan.hdr),
+                     _ptr(plan.rows), _ptr(plan.loc), K, _ptr(step["w"].data), cin, m.out_channels, _ptr(step["scale"]),
+                     _ptr(step["shift"]), res_ptr, 1, _ptr(out), n, io, st)
             return
         if mfma_pair and isinstance(step["w"], D.GldsPacked) and trng is not None and m.subm and K == 27 and \
                 D.sparse_rng(cin, m.out_channels):
@@ -247,9 +255,9 @@ class _SparseEncoderBase(nn.Module):
         lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W, _ptr(lv.grid),
                  1, st)
         used = [(lv, coords, n)]
-        nbr, nbr_key, trng, items = None, None, None, None
+        nbr, nbr_key, trng, items, plan = None, None, None, None, None
         steps = []
-        for step in self._plan:
+        for pi, step in enumerate(self._plan):
             if step["kind"] == "stage_end":
                 steps.append(dict(coords=coords, shape=shape, n=n))
                 continue
@@ -272,14 +280,17 @@ class _SparseEncoderBase(nn.Module):
                         lib.call("al3d_sp_subm_table", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W,
                                  _ptr(lv.grid), *m.kernel_size, _ptr(nbr), st)
                     nbr_key = key
-                    trng, items = None, None
-                if tiled and trng is None and K == 27 and D.sparse_rng(self._pad_cin(m), m.out_channels):
+                    trng, items, plan = None, None, None
+                blk = tiled and m.subm and isinstance(step["w"], D.GldsPacked) and D.sparse_blk(self._pad_cin(m), m.out_channels, K)
+                if blk and plan is None:
+                    plan = D.block_plan(nbr, n, self._pad_cin(m), m.out_channels)     # once per table, shared by the level
+                if tiled and not blk and trng is None and K == 27 and D.sparse_rng(self._pad_cin(m), m.out_channels):
                     # (lo, len) of every (tile, kz, ky) group: once per table, shared by the level's layers
                     trng = torch.empty((max(nbr.shape[1] // 32, 1), 9, 2), dtype=torch.int32, device=dev)
                     lib.call("al3d_sp_tile_ranges", _ptr(nbr), nbr.shape[1], K, n, _ptr(trng), st)
                 if isinstance(step["w"], D.R16Packed) and items is None:
                     items = D.tile_items(nbr, n, tmask)          # once per table, shared by the level's layers
-                steps.append(dict(nbr=nbr, n=n, K=K, tmask=tmask, trng=trng,
+                steps.append(dict(nbr=nbr, n=n, K=K, tmask=tmask, trng=None if blk else trng, plan=plan if blk else None,
                                   items=items if isinstance(step["w"], D.R16Packed) else None))
             else:
                 oshape = self._out_shape(shape, m.kernel_size, m.stride, m.padding)
@@ -288,9 +299,15 @@ class _SparseEncoderBase(nn.Module):
                 ocoords = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
                 counter = torch.zeros(1, dtype=torch.int32, device=dev)
                 ks, ss, ps = _i3(m.kernel_size), _i3(m.stride), _i3(m.padding)
-                ws = torch.empty(lib.load().al3d_sp_down_sites_workspace_bytes(batch_size, olv.D, olv.H, olv.W),
+                # the order of the new level's rows: column by column when its layers run on the block-staged kernel
+                # (csrc/spconv_blk.hip), raster otherwise
+                nxt = next((s_ for s_ in self._plan[pi + 1:] if s_["kind"] != "stage_end"), None)
+                blocked = nxt is not None and nxt["kind"] == "subm" and isinstance(nxt["w"], D.GldsPacked) and \
+                    D.sparse_blk(self._pad_cin(nxt["mod"]), nxt["mod"].out_channels, int(np.prod(nxt["mod"].kernel_size)))
+                sites = "al3d_sp_down_sites_blocked" if blocked else "al3d_sp_down_sites"
+                ws = torch.empty(getattr(lib.load(), sites + "_workspace_bytes")(batch_size, olv.D, olv.H, olv.W),
                                  dtype=torch.uint8, device=dev)
-                lib.call("al3d_sp_down_sites", _ptr(coords), n, ks, ss, ps, batch_size, olv.D, olv.H,
+                lib.call(sites, _ptr(coords), n, ks, ss, ps, batch_size, olv.D, olv.H,
                          olv.W, _ptr(olv.grid), _ptr(ocoords), _ptr(counter), cap, _ptr(ws), st)
                 n_out = int(counter.item())      # one small D2H per stage
                 ocoords = ocoords[:n_out]
@@ -366,7 +383,7 @@ class _SparseEncoderBase(nn.Module):
                   (D.IO_RES_PAIR if (res is not None and identity_pair) else 0))
             out = torch.empty((b["n"], m.out_channels), dtype=torch.float32, device=dev)
             self._conv(m, feats, b["nbr"], b["K"], step, res, out, b["n"], st,
-                       tmask=b.get("tmask"), trng=b.get("trng"), io=io, items=b.get("items"))
+                       tmask=b.get("tmask"), trng=b.get("trng"), io=io, items=b.get("items"), plan=b.get("plan"))
             feats, pair = out, out_pair
             ci += 1
         assert not pair

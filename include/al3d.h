@@ -249,6 +249,15 @@ int64_t al3d_sp_down_sites_workspace_bytes(int B, int OD, int OH, int OW);
 int al3d_sp_down_sites(const int* coords_in, int n_in, const int* ksize, const int* stride,
                        const int* pad, int B, int OD, int OH, int OW, int* grid_out,
                        int* coords_out, int* counter, int cap, void* workspace, void* stream);
+/* The same enumeration with the sites numbered COLUMN BY COLUMN: 8 x 8 (y, x) columns over all z, in (b, y/8, x/8,
+ * z, y%8, x%8) order -- the order of a level's rows is free inside the encoder (spconv's own order, indice.cu's atomics,
+ * is arbitrary), and this one makes R consecutive rows a compact patch whose z neighbours lie inside it, which is what
+ * al3d_sp_conv_blk_f16x3 stages.  Same outputs otherwise (grid_out in the plain (b, z, y, x) layout);
+ * workspace >= al3d_sp_down_sites_blocked_workspace_bytes().  Reference: spconv_ops.h:51-120 (getIndicePair). */
+int64_t al3d_sp_down_sites_blocked_workspace_bytes(int B, int OD, int OH, int OW);
+int al3d_sp_down_sites_blocked(const int* coords_in, int n_in, const int* ksize, const int* stride,
+                               const int* pad, int B, int OD, int OH, int OW, int* grid_out,
+                               int* coords_out, int* counter, int cap, void* workspace, void* stream);
 /* ... then its rulebook from the input level's grid */
 int al3d_sp_down_table(const int* coords_out, int n_out, const int* ksize, const int* stride,
                        const int* pad, int B, int ID, int IH, int IW, const int* grid_in, int* nbr,
@@ -326,6 +335,23 @@ int al3d_sp_conv_rng_f16x3(const float* fin, const int* nbr, int nbr_pitch, cons
                            const int* tile_rng, int K, const void* wgt_image, int cin, int cout, const float* scale,
                            const float* shift, const float* residual, int relu, float* fout, int n_out, int io,
                            void* stream);
+
+/* Block-staged form of the same layer (27-tap submanifold, Cin = Cout in {32, 64, 128}; csrc/spconv_blk.hip): a
+ * workgroup owns R consecutive output rows and stages the UNION of their 27-tap neighbourhoods once into LDS; the taps
+ * read it through 16-bit local indices.  al3d_sp_block_shape gives (R, CAP) of the kernel built for a channel pair;
+ * al3d_sp_block_plan builds, from the level's tiled table, per chunk of R rows: hdr [chunks][2] = (staged rows U,
+ * flag), rows [chunks][CAP] = the staged row ids (ascending within id windows), loc [chunks][27][R] uint16 = staged
+ * position of (tap, row) or 0xffff.  A chunk whose union does not fit (flag 1: no locality in the row order) is
+ * gathered tap by tap inside the same kernel.  One plan per table, shared by the level's layers.  Same weight image
+ * and contract as al3d_sp_conv_glds_f16x3_io; BIT-IDENTICAL to al3d_sp_conv_wave2_f16x3 in any row order.
+ * Replaces spconv's indice_conv for these layers (spconv_ops.h:260-361; call sites det3d/models/backbones/scn.py:349-369). */
+int al3d_sp_block_shape(int cin, int cout, int* rows_per_chunk, int* staged_cap);
+int al3d_sp_block_plan(const int* nbr, int64_t nbr_pitch, int K, int n_out, int rows_per_chunk, int staged_cap,
+                       int* out_hdr, int* out_rows, void* out_loc, void* stream);
+int al3d_sp_conv_blk_f16x3(const float* fin, const int* nbr, int nbr_pitch, const unsigned* tile_mask,
+                           const int* plan_hdr, const int* plan_rows, const void* plan_loc, int K,
+                           const void* wgt_image, int cin, int cout, const float* scale, const float* shift,
+                           const float* residual, int relu, float* fout, int n_out, int io, void* stream);
 
 /* Level-0 layers (16 input channels) on RASTER-ordered rows (csrc/spconv_l0.hip; the layers are
  * det3d/models/backbones/scn.py:331-347, rulebook semantics geometry.h:248-298).  The voxelizer's rows arrive in
