@@ -135,7 +135,7 @@ __global__ __launch_bounds__(R) void sp_block_plan_kernel(const int* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
-template <int CIN, int COUT, int R, int CAP, int SU>
+template <int CIN, int COUT, int R, int CAP, int SU, int NB>
 struct BlkCfg {
     static constexpr int KG = CIN / 16;                   // 16-channel units per tap
     static constexpr int TN = COUT / 32;
@@ -147,7 +147,7 @@ struct BlkCfg {
     static constexpr int NSLAB = NU / SU;
     static constexpr int SLAB_BYTES = SU * UNIT_BYTES;
     static constexpr int SLAB_PIECES = SLAB_BYTES / 1024;
-    static constexpr int W_BYTES = 2 * SLAB_BYTES;
+    static constexpr int W_BYTES = NB * SLAB_BYTES;       // ring of NB slabs: the producer runs NB - 1 slabs ahead
     static constexpr int ROWB = CIN * 4;
     static constexpr int A_BYTES = CAP * ROWB;
     static constexpr int LOC_BYTES = 27 * R * 2;
@@ -156,12 +156,15 @@ struct BlkCfg {
     static constexpr int LPR = CIN / 8;                   // lanes per staged row: one 8-channel group (32 bytes) each
     static constexpr int RPI = 64 / LPR;                  // rows per wave and staging iteration
     static constexpr int EP_PITCH = 40;
+    static constexpr int TPS = SU >= KG ? SU / KG : 1;    // whole taps per slab ...
+    static constexpr int SPT = SU >= KG ? 1 : KG / SU;    // ... or slabs per tap
     static_assert(CIN % 32 == 0 && COUT % 32 == 0 && R % 32 == 0 && NU % SU == 0, "shape");
-    static_assert(SLAB_PIECES <= 63, "vmcnt is a 6-bit counter");
+    static_assert(SU >= KG ? SU % KG == 0 : KG % SU == 0, "a slab is whole taps or a whole fraction of one");
+    static_assert(NB >= 2 && (NB - 1) * SLAB_PIECES <= 63, "vmcnt is a 6-bit counter");
     static_assert(A_BYTES >= NWC * 32 * EP_PITCH * 4, "the epilogue transposes through the staged rows' storage");
     static_assert(A_BYTES >= NWC * 32 * ROWB, "the per-tap path stages 32 rows per wave");
     static_assert(W_BYTES + NROWS * 32 + 3072 < 65536, "ds_read immediate offsets are 16 bits");
-    static_assert(LOC_BYTES % 16 == 0 && SMEM_BYTES <= 80 * 1024, "two workgroups per CU");
+    static_assert(LOC_BYTES % 16 == 0 && SMEM_BYTES <= 160 * 1024, "LDS budget");
     static_assert(CAP < 0xffff, "16-bit local indices");
 };
 
@@ -178,7 +181,45 @@ __device__ __forceinline__ void blk_lds_read_u16(unsigned& d, unsigned addr)
     asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d) : "v"(addr) : "memory");
 }
 
-template <int CIN, int COUT, int R, int CAP, int SU>
+// One pipelined unit (as spconv_rng.hip): the ds_reads of the NEXT unit's A / B fragments interleaved with the MFMAs
+// of the current unit, closed by the lgkmcnt wait -- one asm block, so no register is visible to hipcc in flight.
+template <int TN, int OFF, int PL>
+__device__ __forceinline__ void blk_read_next_mfma(gl_f32x4& nlo, gl_f32x4& nhi, f16x8 (&nwh)[TN], f16x8 (&nwl)[TN],
+                                                   f32x16 (&acc)[TN], const f16x8& al, const f16x8& ah,
+                                                   const f16x8 (&wd)[TN], const f16x8 (&wl)[TN], const f16x8 (&wh)[TN],
+                                                   unsigned a0, unsigned a1, unsigned b)
+{
+    static_assert(TN == 1 || TN == 2, "tile counts of the pipelined channel pairs");
+    if constexpr (TN == 1)
+        asm volatile("s_nop 1\n\t"
+                     "ds_read_b128 %0, %10\n\tds_read_b128 %1, %11\n\t"
+                     "v_mfma_f32_32x32x16_f16 %4, %5, %7, %4\n\t"
+                     "ds_read_b128 %2, %12 offset:%13\n\tds_read_b128 %3, %12 offset:%14\n\t"
+                     "v_mfma_f32_32x32x16_f16 %4, %6, %8, %4\n\t"
+                     "v_mfma_f32_32x32x16_f16 %4, %6, %9, %4\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(nlo), "=&v"(nhi), "=&v"(nwh[0]), "=&v"(nwl[0]), "+v"(acc[0])
+                     : "v"(al), "v"(ah), "v"(wd[0]), "v"(wl[0]), "v"(wh[0]), "v"(a0), "v"(a1), "v"(b), "n"(OFF), "n"(OFF + PL)
+                     : "memory");
+    else
+        asm volatile("s_nop 1\n\t"
+                     "ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\t"
+                     "v_mfma_f32_32x32x16_f16 %6, %8, %10, %6\n\t"
+                     "v_mfma_f32_32x32x16_f16 %7, %8, %13, %7\n\t"
+                     "ds_read_b128 %2, %18 offset:%19\n\tds_read_b128 %3, %18 offset:%20\n\t"
+                     "v_mfma_f32_32x32x16_f16 %6, %9, %11, %6\n\t"
+                     "v_mfma_f32_32x32x16_f16 %7, %9, %14, %7\n\t"
+                     "ds_read_b128 %4, %18 offset:%21\n\tds_read_b128 %5, %18 offset:%22\n\t"
+                     "v_mfma_f32_32x32x16_f16 %6, %9, %12, %6\n\t"
+                     "v_mfma_f32_32x32x16_f16 %7, %9, %15, %7\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(nlo), "=&v"(nhi), "=&v"(nwh[0]), "=&v"(nwl[0]), "=&v"(nwh[1]), "=&v"(nwl[1]), "+v"(acc[0]), "+v"(acc[1])
+                     : "v"(al), "v"(ah), "v"(wd[0]), "v"(wl[0]), "v"(wh[0]), "v"(wd[1]), "v"(wl[1]), "v"(wh[1]),
+                       "v"(a0), "v"(a1), "v"(b), "n"(OFF), "n"(OFF + PL), "n"(OFF + 1024), "n"(OFF + PL + 1024)
+                     : "memory");
+}
+
+template <int CIN, int COUT, int R, int CAP, int SU, int NB>
 __global__ __launch_bounds__(64 * (R / 32 + 1)) void sp_conv_blk_kernel(const float* __restrict__ fin,
                                                                        const int* __restrict__ nbr, int pitch,
                                                                        const unsigned* __restrict__ tmask, int ntiles,
@@ -189,11 +230,12 @@ __global__ __launch_bounds__(64 * (R / 32 + 1)) void sp_conv_blk_kernel(const fl
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ shift,
                                                                        const float* __restrict__ residual, int relu,
-                                                                       float* __restrict__ fout, int n_out, int io)
+                                                                       float* __restrict__ fout, int n_out, int io, int abl)
 {
-    using C = BlkCfg<CIN, COUT, R, CAP, SU>;
+    using C = BlkCfg<CIN, COUT, R, CAP, SU, NB>;
     constexpr int KG = C::KG, TN = C::TN, NROWS = C::NROWS, UNIT_BYTES = C::UNIT_BYTES, NWC = C::NWC, NWT = C::NWT;
-    constexpr int ROWB = C::ROWB, LPR = C::LPR, RPI = C::RPI, NSLAB = C::NSLAB;
+    constexpr int ROWB = C::ROWB, LPR = C::LPR, RPI = C::RPI, NSLAB = C::NSLAB, TPS = C::TPS, SPT = C::SPT;
+    constexpr bool PIPE = TN <= 2;                                           // software-pipelined units (asm for TN 1, 2)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -210,59 +252,80 @@ __global__ __launch_bounds__(64 * (R / 32 + 1)) void sp_conv_blk_kernel(const fl
     const unsigned zero_base = smem_base + C::ZERO_OFF;
 
     const int2 h = hdr[chunk];
-    const int U = __builtin_amdgcn_readfirstlane(h.x);
+    const int U = (abl & 2) ? 0 : __builtin_amdgcn_readfirstlane(h.x);
     const bool pertap = __builtin_amdgcn_readfirstlane(h.y) != 0;
 
-    // the producer's first slab goes out before anything else
-    auto issue_slab = [&](int s, int buf) {
-        const unsigned char* src = wpk + (size_t)s * C::SLAB_BYTES + lane * 16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + buf * C::SLAB_BYTES);
+    // the producer's first NB - 1 slabs go out before anything else (a slab past the end re-fetches an earlier one
+    // into a free buffer: the count of requests per slab is what the counted waits rely on)
+    auto issue_slab = [&](int s) {
+        const int sc = s < NSLAB ? s : s - NSLAB;
+        const unsigned char* src = wpk + (size_t)sc * C::SLAB_BYTES + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + (s % NB) * C::SLAB_BYTES);
         gl_static_for<C::SLAB_PIECES>([&](auto PC) {
             constexpr int pc = decltype(PC)::value;
             __builtin_amdgcn_global_load_lds((gbl_void*)(src + pc * 1024), (lds_void*)(size_t)(dst + pc * 1024), 16, 0, 0);
         });
     };
-    if (!consumer) issue_slab(0, 0);
+    if (!consumer) {
+#pragma unroll
+        for (int s = 0; s < NB - 1; ++s) issue_slab(s);
+    }
 
     if (tid < 16) reinterpret_cast<float*>(smem + C::ZERO_OFF)[tid] = 0.f;
-    if (!pertap) {
+    if (!pertap && consumer) {
         // ---- local indices of the chunk: 27 x R x 2 bytes, contiguous in the plan
         const uint4* src = reinterpret_cast<const uint4*>(ploc + (int64_t)chunk * 27 * R);
-        for (int i = tid; i < C::LOC_BYTES / 16; i += 64 * NWT)
+        for (int i = tid; i < C::LOC_BYTES / 16; i += 64 * NWC)
             *reinterpret_cast<uint4*>(smem + C::W_BYTES + C::A_BYTES + i * 16) = src[i];
         // ---- the staged rows: lane group g of LPR lanes fetches row j's eight-channel group (32 bytes), splits it
-        // (f32 rows) and stores its two 16-byte planes at the swizzled positions of staged row j
+        // (f32 rows) and stores its two 16-byte planes at the swizzled positions of staged row j.  Two iterations'
+        // loads are requested before the first one's stores.
         const int g = lane % LPR, jr = lane / LPR;
         const int* ids = prow + (int64_t)chunk * CAP;
-        for (int j0 = wave * RPI; j0 < U; j0 += NWT * RPI) {
-            const int j = j0 + jr;
-            if (j < U) {
-                const int id = ids[j];
-                const float* p = fin + (int64_t)id * CIN + g * 8;
-                const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
-                uint4 hi = a, lo = b;
-                if (!(io & SP_IO_IN_PAIR)) {
-                    const float v[8] = {__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y), __builtin_bit_cast(float, a.z),
-                                        __builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y),
-                                        __builtin_bit_cast(float, b.z), __builtin_bit_cast(float, b.w)};
-                    sp_split8(v, hi, lo);
-                }
-                const unsigned sw = blk_swz<ROWB>((unsigned)j);
-                unsigned char* rowp = smem + C::W_BYTES + j * ROWB;
-                *reinterpret_cast<uint4*>(rowp + (((2 * g) ^ sw) << 4)) = hi;
-                *reinterpret_cast<uint4*>(rowp + (((2 * g + 1) ^ sw) << 4)) = lo;
+        auto put = [&](int j, const uint4& a, const uint4& b) {
+            uint4 hi = a, lo = b;
+            if (!(io & SP_IO_IN_PAIR)) {
+                const float v[8] = {__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y), __builtin_bit_cast(float, a.z),
+                                    __builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y),
+                                    __builtin_bit_cast(float, b.z), __builtin_bit_cast(float, b.w)};
+                sp_split8(v, hi, lo);
+            }
+            const unsigned sw = blk_swz<ROWB>((unsigned)j);
+            unsigned char* rowp = smem + C::W_BYTES + j * ROWB;
+            *reinterpret_cast<uint4*>(rowp + (((2 * g) ^ sw) << 4)) = hi;
+            *reinterpret_cast<uint4*>(rowp + (((2 * g + 1) ^ sw) << 4)) = lo;
+        };
+        constexpr int UNR = 4;
+        for (int j0 = wave * RPI; j0 < U; j0 += UNR * NWC * RPI) {
+            int id[UNR];
+            uint4 a[UNR], b[UNR];
+#pragma unroll
+            for (int t = 0; t < UNR; ++t) {
+                const int j = j0 + t * NWC * RPI + jr;
+                id[t] = ids[j < U ? j : U - 1];
+            }
+#pragma unroll
+            for (int t = 0; t < UNR; ++t) {
+                const float* p = fin + (int64_t)id[t] * CIN + g * 8;
+                a[t] = *reinterpret_cast<const uint4*>(p);
+                b[t] = *reinterpret_cast<const uint4*>(p + 4);
+            }
+#pragma unroll
+            for (int t = 0; t < UNR; ++t) {
+                const int j = j0 + t * NWC * RPI + jr;
+                if (j < U) put(j, a[t], b[t]);
             }
         }
     }
 
     if (!consumer) {
-        // ================= producer wave: slab s+1 goes out while the consumers work on slab s
+        // ================= producer wave: NB - 1 slabs ahead of the consumers
         for (int s = 0; s < NSLAB; ++s) {
-            __builtin_amdgcn_s_waitcnt(0);                                   // slab s landed; its staging stores are done
-            __builtin_amdgcn_s_barrier();                                    // ... and slab s-1's buffer is free
-            if (s + 1 < NSLAB) issue_slab(s + 1, (s + 1) & 1);
+            gl_wait_vm<(NB - 2) * C::SLAB_PIECES>();                         // slab s has landed
+            if (!(abl & 1) || s == 0) __builtin_amdgcn_s_barrier();          // ... and slab s-1's buffer is free
+            issue_slab(s + NB - 1);
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        gl_wait_vm<0>();
         __builtin_amdgcn_s_barrier();                                        // the consumers' hand-over to their epilogue
         return;
     }
@@ -278,84 +341,115 @@ __global__ __launch_bounds__(64 * (R / 32 + 1)) void sp_conv_blk_kernel(const fl
     const unsigned offB = smem_base + (2 * fr + (fh ^ ((fr >> 3) & 1))) * 16;  // the weight image's swizzle
     const unsigned priv = a_base + wave * (32 * ROWB);                       // per-tap path: this wave's 32 rows
     const unsigned loc_lane = loc_base + (wave * 32 + fr) * 2;
-    unsigned rowa = zero_base, sw = 0u;
-    bool ok = false;
     __builtin_amdgcn_s_waitcnt(0);                                           // this wave's staging stores
 
-    // slab bookkeeping: SU >= KG: a slab holds TPS whole taps (one barrier per TPS taps); SU < KG: a tap spans KG / SU
-    // slabs, an even number, so the ring buffer of unit kg is (kg / SU) & 1
-    constexpr int TPS = SU >= KG ? SU / KG : 1;
-    static_assert(SU >= KG ? SU % KG == 0 : (KG % SU == 0 && (KG / SU) % 2 == 0), "slab / tap alignment");
-    for (int k = 0; k < 27; ++k) {
-        const bool live = (wmask >> k) & 1u;                                 // wave-uniform
-        unsigned bslab = offB;
-        if constexpr (SU >= KG) {
-            if (k % TPS == 0) __builtin_amdgcn_s_barrier();
-            bslab += ((k / TPS) & 1) * C::SLAB_BYTES + (k % TPS) * (KG * UNIT_BYTES);
-        }
-        if (live) {
-            if (!pertap) {
-                unsigned lid;
-                blk_lds_read_u16(lid, loc_lane + k * (R * 2));
-                ok = lid != BLK_NONE;
-                rowa = a_base + lid * ROWB;
-                sw = blk_swz<ROWB>(lid);
-            } else {
-                // gather the tap's 32 neighbour rows into the wave's private rows (the previous tap's fragment
-                // reads have all been waited for)
-                const int g = lane % LPR, jr = lane / LPR;
+    // the per-tap path's gather of one tap's 32 neighbour rows into the wave's private rows
+    auto gather_tap = [&](int k, unsigned& rowa, unsigned& sw, bool& ok) {
+        const int g = lane % LPR, jr = lane / LPR;
 #pragma unroll
-                for (int j0 = 0; j0 < 32; j0 += RPI) {
-                    const int j = j0 + jr;
-                    const int id = nbr[(int64_t)k * pitch + (int64_t)tile * 32 + j];
-                    if (id >= 0) {
-                        const float* p = fin + (int64_t)id * CIN + g * 8;
-                        const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
-                        uint4 hi = a, lo = b;
-                        if (!(io & SP_IO_IN_PAIR)) {
-                            const float v[8] = {__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y),
-                                                __builtin_bit_cast(float, a.z), __builtin_bit_cast(float, a.w),
-                                                __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y),
-                                                __builtin_bit_cast(float, b.z), __builtin_bit_cast(float, b.w)};
-                            sp_split8(v, hi, lo);
-                        }
-                        const unsigned swj = blk_swz<ROWB>((unsigned)j);
-                        unsigned char* rowp = smem + C::W_BYTES + wave * (32 * ROWB) + j * ROWB;
-                        *reinterpret_cast<uint4*>(rowp + (((2 * g) ^ swj) << 4)) = hi;
-                        *reinterpret_cast<uint4*>(rowp + (((2 * g + 1) ^ swj) << 4)) = lo;
-                    }
+        for (int j0 = 0; j0 < 32; j0 += RPI) {
+            const int j = j0 + jr;
+            const int id = nbr[(int64_t)k * pitch + (int64_t)tile * 32 + j];
+            if (id >= 0) {
+                const float* p = fin + (int64_t)id * CIN + g * 8;
+                const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+                uint4 hi = a, lo = b;
+                if (!(io & SP_IO_IN_PAIR)) {
+                    const float v[8] = {__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y),
+                                        __builtin_bit_cast(float, a.z), __builtin_bit_cast(float, a.w),
+                                        __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y),
+                                        __builtin_bit_cast(float, b.z), __builtin_bit_cast(float, b.w)};
+                    sp_split8(v, hi, lo);
                 }
-                const int idf = nbr[(int64_t)k * pitch + (int64_t)tile * 32 + fr];
-                __builtin_amdgcn_s_waitcnt(0);
-                __builtin_amdgcn_wave_barrier();
-                ok = idf >= 0;
-                rowa = priv + fr * ROWB;
-                sw = blk_swz<ROWB>((unsigned)fr);
+                const unsigned swj = blk_swz<ROWB>((unsigned)j);
+                unsigned char* rowp = smem + C::W_BYTES + wave * (32 * ROWB) + j * ROWB;
+                *reinterpret_cast<uint4*>(rowp + (((2 * g) ^ swj) << 4)) = hi;
+                *reinterpret_cast<uint4*>(rowp + (((2 * g + 1) ^ swj) << 4)) = lo;
             }
         }
-        gl_static_for<KG>([&](auto G) {
-            constexpr int kg = decltype(G)::value;
-            constexpr int boff = SU >= KG ? kg * UNIT_BYTES : ((kg / SU) & 1) * C::SLAB_BYTES + (kg % SU) * UNIT_BYTES;
-            if constexpr (SU < KG) {
-                if constexpr (kg % SU == 0) __builtin_amdgcn_s_barrier();
+        const int idf = nbr[(int64_t)k * pitch + (int64_t)tile * 32 + fr];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        ok = idf >= 0;
+        rowa = priv + fr * ROWB;
+        sw = blk_swz<ROWB>((unsigned)fr);
+    };
+    auto mfma3 = [&](const f16x8& ah, const f16x8& al, const f16x8 (&wh)[TN], const f16x8 (&wl)[TN]) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const f16x8 wd = gl_lift_down(wh[jn]);
+            acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wd, acc[jn], 0, 0, 0);              // smallest first
+            acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[jn], acc[jn], 0, 0, 0);
+            acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[jn], acc[jn], 0, 0, 0);
+        }
+    };
+
+    // staged rows of the current tap(s): row address, swizzle term, presence -- per tap of the slab
+    unsigned rowa[TPS], sw[TPS];
+    bool ok[TPS];
+#pragma unroll
+    for (int t = 0; t < TPS; ++t) { rowa[t] = zero_base; sw[t] = 0u; ok[t] = false; }
+
+    for (int s = 0; s < NSLAB; ++s) {
+        const int k0 = SU >= KG ? s * TPS : s / SPT;                         // first (or only) tap of the slab
+        const int kgb = SU >= KG ? 0 : (s % SPT) * SU;                       // its first unit within the tap
+        unsigned live = 0u;
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) live |= ((wmask >> (k0 + t)) & 1u) << t;
+        if (!pertap && (SU >= KG || kgb == 0)) {
+            // the slab's local indices (static data: read before the barrier)
+#pragma unroll
+            for (int t = 0; t < TPS; ++t) {
+                unsigned lid;
+                blk_lds_read_u16(lid, loc_lane + (k0 + t) * (R * 2));
+                ok[t] = lid != BLK_NONE;
+                rowa[t] = a_base + lid * ROWB;
+                sw[t] = blk_swz<ROWB>(lid);
             }
-            if (live) {
-                const unsigned a0 = ok ? rowa + (((unsigned)(4 * kg + 2 * fh) ^ sw) << 4) : zero_base;
-                const unsigned a1 = ok ? rowa + (((unsigned)(4 * kg + 2 * fh + 1) ^ sw) << 4) : zero_base;
+        }
+        if (!(abl & 1) || s == 0) __builtin_amdgcn_s_barrier();
+        if (!live || (abl & 4)) continue;                                    // wave-uniform: no neighbour under these taps
+        const unsigned bslab = offB + (s % NB) * C::SLAB_BYTES;
+        auto a_addr = [&](int t, int kg, int hl) -> unsigned {
+            return ok[t] ? rowa[t] + (((unsigned)(4 * kg + 2 * fh + hl) ^ sw[t]) << 4) : zero_base;
+        };
+        if (pertap || !PIPE) {
+            gl_static_for<SU>([&](auto UU) {
+                constexpr int u = decltype(UU)::value;
+                constexpr int t = SU >= KG ? u / KG : 0;
+                const int kg = SU >= KG ? u % KG : kgb + u;
+                if (!((live >> t) & 1u)) return;
+                if (pertap && kg == 0) gather_tap(k0 + t, rowa[t], sw[t], ok[t]);
                 gl_f32x4 vh, vl;
                 f16x8 wh[TN], wl[TN];
-                gl_lds_read_ab<TN, boff, NROWS * 32>(vh, vl, wh, wl, a0, a1, bslab);
-                const f16x8 ah = __builtin_bit_cast(f16x8, vh), al = __builtin_bit_cast(f16x8, vl);
+                gl_lds_read_ab<TN, u * UNIT_BYTES, NROWS * 32>(vh, vl, wh, wl, a_addr(t, kg, 0), a_addr(t, kg, 1), bslab);
+                mfma3(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), wh, wl);
+                if (pertap && kg == KG - 1) __builtin_amdgcn_wave_barrier();
+            });
+        } else if constexpr (PIPE) {
+            // all SU units of the slab, unit u + 1's fragments read while unit u's products run (a tap without a
+            // neighbour in this tile reads the zero row: +0 products)
+            gl_f32x4 vh[2], vl[2];
+            f16x8 wh[2][TN], wl[2][TN];
+            gl_lds_read_ab<TN, 0, NROWS * 32>(vh[0], vl[0], wh[0], wl[0], a_addr(0, kgb, 0), a_addr(0, kgb, 1), bslab);
+            gl_static_for<SU>([&](auto UU) {
+                constexpr int u = decltype(UU)::value;
+                constexpr int cur = u & 1, nxt = cur ^ 1;
+                const f16x8 ah = __builtin_bit_cast(f16x8, vh[cur]), al = __builtin_bit_cast(f16x8, vl[cur]);
+                if constexpr (u + 1 < SU) {
+                    constexpr int tn = SU >= KG ? (u + 1) / KG : 0;
+                    const int kgn = SU >= KG ? (u + 1) % KG : kgb + u + 1;
+                    f16x8 wd[TN];
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) {
-                    const f16x8 wd = gl_lift_down(wh[jn]);
-                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wd, acc[jn], 0, 0, 0);      // smallest first
-                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[jn], acc[jn], 0, 0, 0);
-                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[jn], acc[jn], 0, 0, 0);
+                    for (int jn = 0; jn < TN; ++jn) wd[jn] = gl_lift_down(wh[cur][jn]);
+                    blk_read_next_mfma<TN, (u + 1) * UNIT_BYTES, NROWS * 32>(vh[nxt], vl[nxt], wh[nxt], wl[nxt], acc, al, ah, wd,
+                                                                             wl[cur], wh[cur], a_addr(tn, kgn, 0),
+                                                                             a_addr(tn, kgn, 1), bslab);
+                } else {
+                    mfma3(ah, al, wh[cur], wl[cur]);
                 }
-            }
-        });
-        if (pertap) __builtin_amdgcn_wave_barrier();
+            });
+        }
     }
     __builtin_amdgcn_s_barrier();                                            // every wave is done with the staged rows
 
@@ -380,7 +474,7 @@ __global__ __launch_bounds__(64 * (R / 32 + 1)) void sp_conv_blk_kernel(const fl
 // the shapes the conv kernel is built for: R rows per chunk, CAP staged rows (two workgroups per CU)
 static bool blk_shape(int cin, int cout, int* R, int* cap)
 {
-    if (cin == 32 && cout == 32) { *R = 128; *cap = 320; return true; }
+    if (cin == 32 && cout == 32) { *R = 128; *cap = 288; return true; }
     if (cin == 64 && cout == 64) { *R = 128; *cap = 208; return true; }
     if (cin == 128 && cout == 128) { *R = 64; *cap = 104; return true; }
     return false;
@@ -417,13 +511,13 @@ extern "C" int al3d_sp_block_plan(const int* nbr, int64_t nbr_pitch, int K, int 
     return AL3D_OK;
 }
 
-#define BLK_DISPATCH(CI, CO, RR, CAPV, SUV)                                                                     \
+#define BLK_DISPATCH(CI, CO, RR, CAPV, SUV, NBV)                                                                     \
     if (cin == CI && cout == CO) {                                                                              \
         const int nchunks = (int)al3d_cdiv(n_out, RR);                                                          \
-        hipLaunchKernelGGL((sp_conv_blk_kernel<CI, CO, RR, CAPV, SUV>), dim3((unsigned)nchunks),               \
+        hipLaunchKernelGGL((sp_conv_blk_kernel<CI, CO, RR, CAPV, SUV, NBV>), dim3((unsigned)nchunks),               \
                            dim3(64 * (RR / 32 + 1)), 0, s, fin, nbr, nbr_pitch, tile_mask, ntiles, (const int2*)plan_hdr, \
                            plan_rows, (const unsigned short*)plan_loc, (const unsigned char*)wgt_image, scale, shift, \
-                           residual, relu, fout, n_out, io);                                                    \
+                           residual, relu, fout, n_out, io, abl);                                               \
         AL3D_CHECK_LAUNCH("sp_conv_blk_kernel");                                                                \
         return AL3D_OK;                                                                                         \
     }
@@ -442,8 +536,12 @@ extern "C" int al3d_sp_conv_blk_f16x3(const float* fin, const int* nbr, int nbr_
     AL3D_REQUIRE(nbr_pitch >= n_out && nbr_pitch % 256 == 0, "al3d_sp_conv_blk_f16x3: nbr_pitch must be al3d_sp_table_pitch(n_out)");
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (int)al3d_cdiv(n_out, 32);
-    BLK_DISPATCH(32, 32, 128, 320, 6)
-    BLK_DISPATCH(64, 64, 128, 208, 2)
-    BLK_DISPATCH(128, 128, 64, 104, 1)
+    int abl = 0;
+#ifdef AL3D_BLK_ABLATE
+    if (const char* e = getenv("AL3D_BLK_ABL")) abl = atoi(e);              // tuning build only (make EXTRA=-DAL3D_BLK_ABLATE)
+#endif
+    BLK_DISPATCH(32, 32, 128, 288, 6, 3)
+    BLK_DISPATCH(64, 64, 128, 208, 2, 2)
+    BLK_DISPATCH(128, 128, 64, 104, 1, 2)
     return al3d_fail(AL3D_EINVAL, "al3d_sp_conv_blk_f16x3: no kernel for Cin=%d Cout=%d", cin, cout);
 }

@@ -259,16 +259,27 @@ def sparse_rng(cin, cout):
 
 # Block-staged kernel (csrc/spconv_blk.hip): 27-tap submanifold layers of these channel pairs stage the union of a
 # 128-row chunk's neighbourhoods once; the encoder then numbers the level's rows column by column
-# (al3d_sp_down_sites_blocked).  AL3D_BLK_PAIRS: dev override, e.g. "32x32,64x64,128x128" or "" for none
+# (al3d_sp_down_sites_blocked).  Built, bit-identical, and MEASURED SLOWER than the range / per-tap kernels on lidar
+# data (round 5, DESIGN 5.3: fragment reads through arbitrary local indices are LDS-bank-conflict bound, and column order
+# makes 91 % instead of 72 % of the (tile, tap) pairs live), so no pair takes it by default.
+# AL3D_BLK_PAIRS: opt-in, e.g. "32x32,64x64,128x128"
 BLK_BUILT = {(32, 32), (64, 64), (128, 128)}
-BLK_PAIRS = {(32, 32), (64, 64), (128, 128)}
+BLK_PAIRS = set()
 if _os.environ.get("AL3D_BLK_PAIRS") is not None:
     BLK_PAIRS = {tuple(int(v) for v in t.split("x")) for t in _os.environ["AL3D_BLK_PAIRS"].split(",") if t}
 
 
+BLK_ORDER_ONLY = _os.environ.get("AL3D_BLK_ORDER_ONLY", "0") == "1"   # dev: column order for these pairs' levels, old kernels
+
+
+def sparse_blk_order(cin, cout, K=27):
+    """True when the level whose 27-tap submanifold layers are cin -> cout is numbered column by column."""
+    return MATH == "f16x3" and SPCONV == "auto" and K == 27 and (cin, cout) in (BLK_PAIRS & BLK_BUILT)
+
+
 def sparse_blk(cin, cout, K=27):
     """True when the 27-tap submanifold f16x3 layer cin -> cout runs on the block-staged kernel."""
-    return MATH == "f16x3" and SPCONV == "auto" and K == 27 and (cin, cout) in (BLK_PAIRS & BLK_BUILT)
+    return sparse_blk_order(cin, cout, K) and not BLK_ORDER_ONLY
 
 
 class BlkPlan:

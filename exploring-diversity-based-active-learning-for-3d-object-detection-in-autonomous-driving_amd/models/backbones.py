@@ -302,8 +302,8 @@ class _SparseEncoderBase(nn.Module):
                 # the order of the new level's rows: column by column when its layers run on the block-staged kernel
                 # (csrc/spconv_blk.hip), raster otherwise
                 nxt = next((s_ for s_ in self._plan[pi + 1:] if s_["kind"] != "stage_end"), None)
-                blocked = nxt is not None and nxt["kind"] == "subm" and isinstance(nxt["w"], D.GldsPacked) and \
-                    D.sparse_blk(self._pad_cin(nxt["mod"]), nxt["mod"].out_channels, int(np.prod(nxt["mod"].kernel_size)))
+                blocked = nxt is not None and nxt["kind"] == "subm" and \
+                    D.sparse_blk_order(self._pad_cin(nxt["mod"]), nxt["mod"].out_channels, int(np.prod(nxt["mod"].kernel_size)))
                 sites = "al3d_sp_down_sites_blocked" if blocked else "al3d_sp_down_sites"
                 ws = torch.empty(getattr(lib.load(), sites + "_workspace_bytes")(batch_size, olv.D, olv.H, olv.W),
                                  dtype=torch.uint8, device=dev)
