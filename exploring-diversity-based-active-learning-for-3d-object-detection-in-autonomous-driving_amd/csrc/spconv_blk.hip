@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * (R / 32 + 1)) void sp_conv_blk_kernel(const fl
                                                                        float* __restrict__ fout, int n_out, int io, int abl)
 {
     using C = BlkCfg<CIN, COUT, R, CAP, SU, NB>;
-    constexpr int KG = C::KG, TN = C::TN, NROWS = C::NROWS, UNIT_BYTES = C::UNIT_BYTES, NWC = C::NWC, NWT = C::NWT;
+    constexpr int KG = C::KG, TN = C::TN, NROWS = C::NROWS, UNIT_BYTES = C::UNIT_BYTES, NWC = C::NWC;
     constexpr int ROWB = C::ROWB, LPR = C::LPR, RPI = C::RPI, NSLAB = C::NSLAB, TPS = C::TPS, SPT = C::SPT;
     constexpr bool PIPE = TN <= 2;                                           // software-pipelined units (asm for TN 1, 2)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[C::SMEM_BYTES];

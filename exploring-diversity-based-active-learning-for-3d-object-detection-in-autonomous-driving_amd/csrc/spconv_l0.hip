@@ -116,10 +116,24 @@ __global__ __launch_bounds__(256) void l0_rank_kernel(const int* __restrict__ cn
 #define L0F_MAXLINES 43008
 #define L0F_CHUNK 512
 #define L0F_K 4
+// The caller's promise (rows frame-sorted, at most 65,535 per frame) is CHECKED, not trusted: this pass sets
+// status bit 0 when coords[:, 0] is not ascending within [0, B); the sort kernel then writes the identity permutation
+// (every row exactly once, valid coordinates -- correct, unsorted) instead of walking 16-bit counters that would wrap, and a
+// frame beyond the 16-bit limit does the same for its own rows and sets bit 1.  The host raises on a non-zero status.
+__global__ __launch_bounds__(256) void l0_check_frames_kernel(const int* __restrict__ coords, int n, int B, int* __restrict__ status)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = coords[4 * (int64_t)i];
+    const int bn = i + 1 < n ? coords[4 * (int64_t)(i + 1)] : b;
+    if (b < 0 || b >= B || bn < b) atomicOr(status, 1);
+}
+
 __global__ __launch_bounds__(L0F_NT) void l0_frame_sort_kernel(const int* __restrict__ coords, int n, L0Dims g,
                                                                unsigned short* __restrict__ slot_ws,
                                                                unsigned* __restrict__ bkey, int* __restrict__ bid,
-                                                               int* __restrict__ perm, int* __restrict__ coords_r)
+                                                               int* __restrict__ perm, int* __restrict__ coords_r,
+                                                               int* __restrict__ status)
 {
     __shared__ unsigned cw[L0F_MAXLINES / 2 + 2];              // packed 16-bit line counters, then exclusive prefixes
     __shared__ unsigned bits[L0F_CHUNK * 32];                  // x bit masks of one chunk of lines
@@ -138,8 +152,25 @@ __global__ __launch_bounds__(L0F_NT) void l0_frame_sort_kernel(const int* __rest
     }
     for (int i = tid; i < L0F_MAXLINES / 2 + 2; i += L0F_NT) cw[i] = 0u;
     __syncthreads();
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) {
+        // not frame-sorted: the frame ranges mean nothing.  Identity over an equal slice of the rows per workgroup.
+        const int64_t i0 = (int64_t)n * b / g.B, i1 = (int64_t)n * (b + 1) / g.B;
+        for (int64_t i = i0 + tid; i < i1; i += L0F_NT) {
+            perm[i] = (int)i;
+            *reinterpret_cast<int4*>(coords_r + 4 * i) = *reinterpret_cast<const int4*>(coords + 4 * i);
+        }
+        return;
+    }
     const int lo = s_lo, cnt_f = s_hi - s_lo;
     if (cnt_f <= 0) return;                                    // uniform
+    if (cnt_f > 65535) {                                       // beyond the 16-bit counters: identity for this frame's rows
+        if (tid == 0) atomicOr(status, 2);
+        for (int i = tid; i < cnt_f; i += L0F_NT) {
+            perm[lo + i] = lo + i;
+            *reinterpret_cast<int4*>(coords_r + 4 * (int64_t)(lo + i)) = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)(lo + i));
+        }
+        return;
+    }
     // A: arrival slot of every row in its line
     for (int i = tid; i < cnt_f; i += L0F_NT) {
         const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)(lo + i));
@@ -262,7 +293,7 @@ static inline int64_t l0_lines(int B, int D, int H) { return (int64_t)B * D * H;
 extern "C" int64_t al3d_sp_raster_perm_workspace_bytes(int n, int B, int D, int H)
 {
     const int64_t L = l0_lines(B, D, H);
-    return 2 * al3d_align(L * 4, 256) + al3d_scan_workspace_bytes(L) + al3d_align((int64_t)n * 4, 256) * 3 +
+    return 256 + 2 * al3d_align(L * 4, 256) + al3d_scan_workspace_bytes(L) + al3d_align((int64_t)n * 4, 256) * 3 +
            al3d_align((int64_t)n * 2, 256);
 }
 
@@ -276,6 +307,8 @@ extern "C" int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H
     hipStream_t s = (hipStream_t)stream;
     const int64_t L = l0_lines(B, D, H);
     char* w = (char*)workspace;
+    int* status = (int*)w; w += 256;                           // workspace[0]: 0 = ok, else the violated promise (see header)
+    if (hipMemsetAsync(status, 0, 4, s) != hipSuccess) return al3d_fail(AL3D_ELAUNCH, "al3d_sp_raster_perm: memset failed");
     int* cnt = (int*)w; w += al3d_align(L * 4, 256);
     int* base = (int*)w; w += al3d_align(L * 4, 256);
     void* scan_ws = w; w += al3d_scan_workspace_bytes(L);
@@ -287,8 +320,9 @@ extern "C" int al3d_sp_raster_perm(const int* coords, int n, int B, int D, int H
     if (frame_rows_max > 0 && frame_rows_max <= 65535 && D * H <= L0F_MAXLINES && W <= 1024) {
         // frame-sorted input (coords[:, 0] ascending, at most frame_rows_max rows per frame): one workgroup per frame
         unsigned short* slot16 = (unsigned short*)slot;
+        hipLaunchKernelGGL(l0_check_frames_kernel, dim3((unsigned)al3d_cdiv(n, 256)), dim3(256), 0, s, coords, n, B, status);
         hipLaunchKernelGGL(l0_frame_sort_kernel, dim3((unsigned)B), dim3(L0F_NT), 0, s, coords, n, g, slot16, (unsigned*)bl, bid, perm,
-                           coords_raster);
+                           coords_raster, status);
         AL3D_CHECK_LAUNCH("l0_frame_sort_kernel");
         return AL3D_OK;
     }
@@ -872,7 +906,13 @@ extern "C" int al3d_sp_conv_r16_f16x3(const float* fin, const int* nbr, int nbr_
     // it until that drains -- the first level-0 layer of a batch ran 2.0 ms beside the previous batch's decode + NMS against
     // 1.0 ms now (serial: 625 -> 587 us per layer; bench +0.8 %, tools/ab_r16_shape.sh).
     static const int shape = getenv("AL3D_R16_SHAPE") ? atoi(getenv("AL3D_R16_SHAPE")) : 4;
+#ifdef AL3D_R16_ABLATE
+    // tuning build only (make EXTRA=-DAL3D_R16_ABLATE, tools/ablate_l0.sh): runtime ablations that drop rows / indices /
+    // products / stores -- never reachable from a stray environment variable in the shipped library
     static const int abl = getenv("AL3D_R16_ABL") ? atoi(getenv("AL3D_R16_ABL")) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     {
         if (cout == 16) {
             if (residual) {

@@ -96,6 +96,30 @@ extern "C" int al3d_merge_sweeps_f32(const float* raw, const int64_t* file_off, 
 // launch set per batch instead of per frame.  is_key[f] marks the key-frame file of a frame (no
 // remove_close, time 0); frame_first_file[b] is the index of frame b's first file ([B+1] entries).
 // out_frame_off[b] = first output point of frame b ([B+1] int64, computed here from the scan).
+// optional range filter of the merged cloud (BEVFusion's PointsRangeFilter, transforms_3d.py:503-525 on
+// base_points.py:208-232): a point stays when lo < p < hi STRICTLY on x, y, z of the TRANSFORMED float32 point
+struct SweepRange { float lo[3], hi[3]; int on; };
+
+// sweep -> key frame under rule 0 / 1 (see al3d_merge_sweeps_batch_rule_f32)
+__device__ __forceinline__ void sweep_apply_xform(const double* __restrict__ t, int rule, float& x, float& y, float& z)
+{
+    const double xd = x, yd = y, zd = z;
+    if (rule == 0) {
+        const float nx = (float)(((t[0] * xd + t[1] * yd) + t[2] * zd) + t[3]);
+        const float ny = (float)(((t[4] * xd + t[5] * yd) + t[6] * zd) + t[7]);
+        const float nz = (float)(((t[8] * xd + t[9] * yd) + t[10] * zd) + t[11]);
+        x = nx; y = ny; z = nz;
+    } else {
+        // BEVFusion (bevfusion/mmdet3d/datasets/pipelines/loading.py:222-226): `p[:, :3] = p[:, :3] @ R.T` stores the
+        // float64 product back into the float32 array, then `p[:, :3] += t` adds the float64 translation to the
+        // ROUNDED value and rounds again
+        const float rx = (float)((t[0] * xd + t[1] * yd) + t[2] * zd);
+        const float ry = (float)((t[4] * xd + t[5] * yd) + t[6] * zd);
+        const float rz = (float)((t[8] * xd + t[9] * yd) + t[10] * zd);
+        x = (float)((double)rx + t[3]); y = (float)((double)ry + t[7]); z = (float)((double)rz + t[11]);
+    }
+}
+
 __device__ __forceinline__ int sweep_file_of_bs(const int64_t* __restrict__ off, int nfiles, int64_t i)
 {
     int lo = 0, hi = nfiles - 1;                  // largest f with off[f] <= i
@@ -108,14 +132,21 @@ __device__ __forceinline__ int sweep_file_of_bs(const int64_t* __restrict__ off,
 
 __global__ void sweep_flag_batch_kernel(const float* __restrict__ raw, const int64_t* __restrict__ off, int nfiles,
                                         int64_t total, const unsigned char* __restrict__ is_key, float min_distance,
-                                        int* __restrict__ flags)
+                                        const double* __restrict__ xform, const unsigned char* __restrict__ has_xform,
+                                        int rule, SweepRange rg, int* __restrict__ flags)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int f = sweep_file_of_bs(off, nfiles, i);
-    const float x = raw[5 * i], y = raw[5 * i + 1];
+    float x = raw[5 * i], y = raw[5 * i + 1];
     const bool close = fabsf(x) < min_distance && fabsf(y) < min_distance;
-    flags[i] = (is_key[f] || !close) ? 1 : 0;
+    bool keep = is_key[f] || !close;
+    if (keep && rg.on) {
+        float z = raw[5 * i + 2];
+        if (!is_key[f] && has_xform[f]) sweep_apply_xform(xform + 12 * f, rule, x, y, z);
+        keep = x > rg.lo[0] && y > rg.lo[1] && z > rg.lo[2] && x < rg.hi[0] && y < rg.hi[1] && z < rg.hi[2];
+    }
+    flags[i] = keep ? 1 : 0;
 }
 
 __global__ void sweep_emit_batch_kernel(const float* __restrict__ raw, const int64_t* __restrict__ off, int nfiles,
@@ -131,24 +162,7 @@ __global__ void sweep_emit_batch_kernel(const float* __restrict__ raw, const int
     float x = raw[5 * i], y = raw[5 * i + 1], z = raw[5 * i + 2];
     const float w = raw[5 * i + 3];
     const bool key = is_key[f] != 0;
-    if (!key && has_xform[f]) {
-        const double* t = xform + 12 * f;
-        const double xd = x, yd = y, zd = z;
-        if (rule == 0) {
-            const float nx = (float)(((t[0] * xd + t[1] * yd) + t[2] * zd) + t[3]);
-            const float ny = (float)(((t[4] * xd + t[5] * yd) + t[6] * zd) + t[7]);
-            const float nz = (float)(((t[8] * xd + t[9] * yd) + t[10] * zd) + t[11]);
-            x = nx; y = ny; z = nz;
-        } else {
-            // BEVFusion (bevfusion/mmdet3d/datasets/pipelines/loading.py:222-226): `p[:, :3] = p[:, :3] @ R.T` stores the
-            // float64 product back into the float32 array, then `p[:, :3] += t` adds the float64 translation to the
-            // ROUNDED value and rounds again
-            const float rx = (float)((t[0] * xd + t[1] * yd) + t[2] * zd);
-            const float ry = (float)((t[4] * xd + t[5] * yd) + t[6] * zd);
-            const float rz = (float)((t[8] * xd + t[9] * yd) + t[10] * zd);
-            x = (float)((double)rx + t[3]); y = (float)((double)ry + t[7]); z = (float)((double)rz + t[11]);
-        }
-    }
+    if (!key && has_xform[f]) sweep_apply_xform(xform + 12 * f, rule, x, y, z);
     float* o = out + 5 * (int64_t)pos[i];
     o[0] = x; o[1] = y; o[2] = z; o[3] = w;
     o[4] = key ? 0.0f : (float)time_lag[f];
@@ -165,11 +179,12 @@ __global__ void sweep_frame_off_kernel(const int64_t* __restrict__ off, const in
     out_frame_off[b] = r < total ? (int64_t)pos[r] : end;
 }
 
-extern "C" int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
-                                                const double* xform, const unsigned char* has_xform,
-                                                const double* time_lag, const unsigned char* is_key,
-                                                const int* frame_first_file, int n_frames, float min_distance, int rule,
-                                                float* out, int64_t* out_frame_off, void* workspace, void* stream);
+extern "C" int al3d_merge_sweeps_batch_range_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                                                 const double* xform, const unsigned char* has_xform,
+                                                 const double* time_lag, const unsigned char* is_key,
+                                                 const int* frame_first_file, int n_frames, float min_distance, int rule,
+                                                 const float* point_range, float* out, int64_t* out_frame_off,
+                                                 void* workspace, void* stream);
 
 extern "C" int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
                                            const double* xform, const unsigned char* has_xform,
@@ -177,8 +192,9 @@ extern "C" int al3d_merge_sweeps_batch_f32(const float* raw, const int64_t* file
                                            const int* frame_first_file, int n_frames, float min_distance,
                                            float* out, int64_t* out_frame_off, void* workspace, void* stream)
 {
-    return al3d_merge_sweeps_batch_rule_f32(raw, file_off, nfiles, total_rows, xform, has_xform, time_lag, is_key,
-                                            frame_first_file, n_frames, min_distance, 0, out, out_frame_off, workspace, stream);
+    return al3d_merge_sweeps_batch_range_f32(raw, file_off, nfiles, total_rows, xform, has_xform, time_lag, is_key,
+                                             frame_first_file, n_frames, min_distance, 0, nullptr, out, out_frame_off, workspace,
+                                             stream);
 }
 
 // rule 0: det3d's loader (one float64 4x4 product, rounded once); rule 1: BEVFusion's LoadPointsFromMultiSweeps (float64
@@ -190,6 +206,25 @@ extern "C" int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t*
                                                 const int* frame_first_file, int n_frames, float min_distance, int rule,
                                                 float* out, int64_t* out_frame_off, void* workspace, void* stream)
 {
+    return al3d_merge_sweeps_batch_range_f32(raw, file_off, nfiles, total_rows, xform, has_xform, time_lag, is_key,
+                                             frame_first_file, n_frames, min_distance, rule, nullptr, out, out_frame_off,
+                                             workspace, stream);
+}
+
+// ... followed by the pipeline's PointsRangeFilter (bevfusion/configs/nuscenes/default.yaml:233-235): point_range = HOST
+// float[6] (x_min, y_min, z_min, x_max, y_max, z_max) or NULL (no filter); a merged point stays when it lies STRICTLY inside
+extern "C" int al3d_merge_sweeps_batch_range_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                                                 const double* xform, const unsigned char* has_xform,
+                                                 const double* time_lag, const unsigned char* is_key,
+                                                 const int* frame_first_file, int n_frames, float min_distance, int rule,
+                                                 const float* point_range, float* out, int64_t* out_frame_off,
+                                                 void* workspace, void* stream)
+{
+    SweepRange rg = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0};
+    if (point_range) {
+        for (int d = 0; d < 3; ++d) { rg.lo[d] = point_range[d]; rg.hi[d] = point_range[3 + d]; }
+        rg.on = 1;
+    }
     AL3D_REQUIRE(rule == 0 || rule == 1, "al3d_merge_sweeps_batch_rule_f32: rule 0 (det3d) or 1 (BEVFusion)");
     AL3D_REQUIRE(nfiles >= 1 && n_frames >= 1 && total_rows >= 0 && total_rows < (1LL << 31),
                  "al3d_merge_sweeps_batch_f32: bad sizes");
@@ -207,7 +242,7 @@ extern "C" int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t*
     void* scan_ws = (unsigned char*)workspace + 2 * al3d_align(total_rows * 4, 256);
     const unsigned blocks = (unsigned)al3d_cdiv(total_rows, 256);
     hipLaunchKernelGGL(sweep_flag_batch_kernel, dim3(blocks), dim3(256), 0, s, raw, file_off, nfiles, total_rows,
-                       is_key, min_distance, flags);
+                       is_key, min_distance, xform, has_xform, rule, rg, flags);
     int rc = al3d_exclusive_scan_i32(flags, pos, total_rows, scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(sweep_emit_batch_kernel, dim3(blocks), dim3(256), 0, s, raw, file_off, nfiles, total_rows,

@@ -2,7 +2,9 @@
 
 The test branch of the reference's pipeline (bevfusion/configs/nuscenes/default.yaml:186-243):
 ``LoadMultiViewImageFromFiles`` (loading.py:19-83) -> ``LoadPointsFromFile`` / ``LoadPointsFromMultiSweeps``
-(loading.py:84-237; sweeps_num 9, pad_empty_sweeps, remove_close) -> ``ImageAug3D`` (transforms_3d.py:26-122, is_train
+(loading.py:84-237; sweeps_num 9, pad_empty_sweeps, remove_close) -> ``PointsRangeFilter`` (transforms_3d.py:503-525:
+merged points strictly inside ``point_cloud_range``; it is what keeps far / high returns out of the view transform's
+lidar depth image, base.py:213-262) -> ``ImageAug3D`` (transforms_3d.py:26-122, is_train
 False: resize 0.48, bottom crop to 256 x 704, the ``img_aug_matrix`` it emits) -> ``GlobalRotScaleTrans`` (identity in test
 mode: ``lidar_aug_matrix`` = I) -> ``ImageNormalize`` (transforms_3d.py:903-920), with the calibration matrices of
 ``NuScenesDataset.get_data_info`` (nuscenes_dataset.py:233-275).
@@ -124,10 +126,17 @@ class CameraLidarFileLoader(FileSweepLoader):
     def __init__(self, infos, voxel_cfg, anchors, batch_size=4, device="cuda", sweeps_num=9, root=None, threads=8,
                  indices=None, depth=2, min_distance=1.0, image_size=(256, 704), resize_lim=(0.48, 0.48),
                  bot_pct_lim=(0.0, 0.0), mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), decode_threads=None,
-                 pad_empty_sweeps=True):
+                 pad_empty_sweeps=True, point_cloud_range="voxel"):
         super().__init__(infos, voxel_cfg, anchors, batch_size=batch_size, device=device, nsweeps=sweeps_num + 1, root=root,
                          threads=threads, indices=indices, depth=depth, min_distance=min_distance)
         self.sweeps_num, self.pad_empty_sweeps = int(sweeps_num), bool(pad_empty_sweeps)
+        # PointsRangeFilter: the pipeline's ${point_cloud_range} is the voxelizer's range in every shipped config
+        # (default.yaml:233-235 / voxelnet_0p075: [-54, -54, -5, 54, 54, 3]); None switches the filter off
+        if isinstance(point_cloud_range, str):
+            point_cloud_range = list(voxel_cfg["range"] if isinstance(voxel_cfg, dict) else voxel_cfg.range)
+        self.point_range = None if point_cloud_range is None else [float(v) for v in point_cloud_range]
+        if self.point_range is not None and len(self.point_range) != 6:
+            raise lib.Al3dError("CameraLidarFileLoader: point_cloud_range = [x_min, y_min, z_min, x_max, y_max, z_max]")
         self.image_size, self._aug_cfg = tuple(image_size), (tuple(resize_lim), tuple(bot_pct_lim), tuple(mean), tuple(std))
         self._aug = {}
         from .file_loader import usable_cores

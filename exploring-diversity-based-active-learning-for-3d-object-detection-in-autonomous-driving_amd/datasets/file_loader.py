@@ -205,8 +205,10 @@ class FileSweepLoader:
         frame_off = torch.empty((st.B + 1,), dtype=torch.int64, device=dev)
         ws = torch.empty(lib.load().al3d_merge_sweeps_workspace_bytes(st.total), dtype=torch.uint8, device=dev)
         base = buf.data_ptr()
-        lib.call("al3d_merge_sweeps_batch_rule_f32", base, base + st.o_off, st.nf, st.total, base + st.o_xf, base + st.o_has,
-                 base + st.o_tl, base + st.o_key, base + st.o_ff, st.B, self.min_distance, int(self.rule), out.data_ptr(),
+        rg = getattr(self, "point_range", None)              # PointsRangeFilter of the BEVFusion test pipeline (else None)
+        rg = None if rg is None else (ctypes.c_float * 6)(*[float(np.float32(v)) for v in rg])
+        lib.call("al3d_merge_sweeps_batch_range_f32", base, base + st.o_off, st.nf, st.total, base + st.o_xf, base + st.o_has,
+                 base + st.o_tl, base + st.o_key, base + st.o_ff, st.B, self.min_distance, int(self.rule), rg, out.data_ptr(),
                  frame_off.data_ptr(), ws.data_ptr(), stream.cuda_stream)
         v = self.voxelizer(out, frame_off)
         gs = self.voxelizer.grid_size

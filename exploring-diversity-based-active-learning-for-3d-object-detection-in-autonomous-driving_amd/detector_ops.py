@@ -369,7 +369,18 @@ def raster_perm(coords, batch, shape, frame_rows_max=0):
                      device=coords.device)
     lib.call("al3d_sp_raster_perm", _ptr(coords), n, batch, D_, H_, W_, int(frame_rows_max), _ptr(ws), _ptr(perm), _ptr(out),
              _stream())
+    raster_perm.last_status = ws[:4].view(torch.int32)       # device status word: see check_raster_status
     return perm, out
+
+
+def check_raster_status(status):
+    """Raise when al3d_sp_raster_perm found its frame_rows_max promise broken (one small D2H: call it where the
+    stream is synchronised anyway)."""
+    v = int(status.item()) if status is not None else 0
+    if v:
+        raise lib.Al3dError("sparse encoder: frame_rows_max was promised (example['voxel_cap']) but "
+                            + ("the voxel rows are not frame-sorted" if v & 1 else "a frame holds more than 65,535 voxels")
+                            + "; pass frame_rows_max=0 for rows in any order")
 
 
 def rows_gather_pad(rows, perm, channels_out, to_pair=False):

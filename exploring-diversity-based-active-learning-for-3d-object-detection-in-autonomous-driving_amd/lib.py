@@ -163,6 +163,8 @@ SIGNATURES = {
                                             c_p, c_p, c_p, c_p]),
     "al3d_merge_sweeps_batch_rule_f32": (c_int, [c_p, c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_p, c_int, ctypes.c_float,
                                                  c_int, c_p, c_p, c_p, c_p]),
+    "al3d_merge_sweeps_batch_range_f32": (c_int, [c_p, c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_p, c_int, ctypes.c_float,
+                                                  c_int, c_p, c_p, c_p, c_p, c_p]),
     "al3d_tf_proposals_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "al3d_tf_proposals_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_int, c_p, c_int, c_p, c_p, c_p,
                                       c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

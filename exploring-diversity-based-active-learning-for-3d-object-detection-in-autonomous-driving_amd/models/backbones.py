@@ -244,13 +244,14 @@ class _SparseEncoderBase(nn.Module):
         coords = coords.to(torch.int32).contiguous()
         shape = [int(s) for s in spatial_shape]
         n = coords.shape[0]
-        perm = None
+        perm, raster_status = None, None
         if D.sparse_raster() and any(isinstance(s_.get("w"), D.R16Packed) for s_ in self._plan):
             # the input level's rows renumbered in raster order (b, z, y, x): the order of a level's rows is free inside
             # the encoder (example["coordinates"] keeps the reference's first-appearance order), and raster order makes
             # the neighbour sets of consecutive rows contiguous index ranges (csrc/spconv_l0.hip)
             # (frame_rows_max > 0: the caller promises frame-sorted rows with at most that many rows per frame)
             perm, coords = D.raster_perm(coords, batch_size, shape, frame_rows_max)
+            raster_status = D.raster_perm.last_status if frame_rows_max > 0 else None
         lv = self._level(shape, batch_size, dev)
         lib.call("al3d_sp_scatter_index", _ptr(coords), n, batch_size, lv.D, lv.H, lv.W, _ptr(lv.grid),
                  1, st)
@@ -310,6 +311,9 @@ class _SparseEncoderBase(nn.Module):
                 lib.call(sites, _ptr(coords), n, ks, ss, ps, batch_size, olv.D, olv.H,
                          olv.W, _ptr(olv.grid), _ptr(ocoords), _ptr(counter), cap, _ptr(ws), st)
                 n_out = int(counter.item())      # one small D2H per stage
+                if raster_status is not None:    # the level-0 order's promise, checked where the stream is synchronised anyway
+                    D.check_raster_status(raster_status)
+                    raster_status = None
                 ocoords = ocoords[:n_out]
                 used.append((olv, ocoords, n_out))
                 if tiled:
@@ -326,6 +330,8 @@ class _SparseEncoderBase(nn.Module):
                                   items=D.tile_items(dnbr, n_out, dmask) if isinstance(step["w"], D.R16Packed) else None))
                 coords, n, shape, lv = ocoords, n_out, oshape, olv
                 nbr_key = None
+        if raster_status is not None:
+            D.check_raster_status(raster_status)
         for g, c, cnt in used:      # leave every level grid clean for the next call
             lib.call("al3d_sp_scatter_index", _ptr(c), cnt, batch_size, g.D, g.H, g.W, _ptr(g.grid), 0, st)
         # the zero-filled dense BEV buffer the last stage scatters into (537 MB at batch 32): also

@@ -362,6 +362,10 @@ int al3d_sp_conv_blk_f16x3(const float* fin, const int* nbr, int nbr_pitch, cons
  *     line.  workspace >= al3d_sp_raster_perm_workspace_bytes(n, B, D, H).  frame_rows_max > 0 promises frame-sorted
  *     rows (coords[:, 0] ascending) with at most that many rows per frame: up to 65,535 rows, D H <= 43,008 lines and
  *     W <= 1024 the whole sort then runs in LDS, one workgroup per frame; 0: no promise, the general path.
+ *     The promise is checked on the device: the first int32 of `workspace` is a STATUS word the caller reads after the
+ *     call's stream work (0 = kept; bit 0 = rows not frame-sorted, bit 1 = a frame beyond 65,535 rows).  On a violation
+ *     perm / coords_raster still hold a valid permutation (the identity, for the offending rows) -- never an
+ *     uninitialised index -- but the rows are not in raster order: treat a non-zero status as an error.
  *   al3d_sp_rows_gather_pad_f32: out[r] = rows[perm[r]] (perm NULL: identity) zero-padded from channels_in to
  *     channels_out (% 8 == 0) channels, as f32 rows or pair rows.
  * In raster order the neighbours of 32 consecutive output rows under the three kx taps of a (kz, ky) group lie in one
@@ -630,6 +634,15 @@ int al3d_merge_sweeps_batch_rule_f32(const float* raw, const int64_t* file_off, 
                                      const unsigned char* is_key, const int* frame_first_file, int n_frames,
                                      float min_distance, int rule, float* out, int64_t* out_frame_off, void* workspace,
                                      void* stream);
+/* ... followed by the test pipeline's PointsRangeFilter (bevfusion/mmdet3d/datasets/pipelines/transforms_3d.py:503-525 on
+ * core/points/base_points.py:208-232; bevfusion/configs/nuscenes/default.yaml:233-235): point_range = HOST float[6]
+ * (x_min, y_min, z_min, x_max, y_max, z_max) or NULL; a merged (transformed, float32) point stays when it lies STRICTLY
+ * inside the range on x, y and z. */
+int al3d_merge_sweeps_batch_range_f32(const float* raw, const int64_t* file_off, int nfiles, int64_t total_rows,
+                                      const double* xform, const unsigned char* has_xform, const double* time_lag,
+                                      const unsigned char* is_key, const int* frame_first_file, int n_frames,
+                                      float min_distance, int rule, const float* point_range, float* out,
+                                      int64_t* out_frame_off, void* workspace, void* stream);
 
 /* TransFusion query initialisation (csrc/proposals.hip; bevfusion/mmdet3d/models/heads/bbox/transfusion.py:236-275):
  * heat_logits [B][H][W][C] channels-last (the heat-map head's output) -> the P best (class, cell) pairs among the k x k

@@ -158,6 +158,14 @@ def merge_sweeps(key_points, sweeps, ts, sweeps_num=9, pad_empty_sweeps=True, re
     return np.concatenate(out, 0)
 
 
+def points_range_filter(points, point_cloud_range):
+    """PointsRangeFilter (transforms_3d.py:503-525 on base_points.py:208-232): rows STRICTLY inside the float32 range."""
+    r = np.asarray(point_cloud_range, dtype=np.float32)
+    p = points
+    keep = (p[:, 0] > r[0]) & (p[:, 1] > r[1]) & (p[:, 2] > r[2]) & (p[:, 0] < r[3]) & (p[:, 1] < r[4]) & (p[:, 2] < r[5])
+    return p[keep]
+
+
 def camera_matrices(cam):
     """One camera's (lidar2image, camera_intrinsics, camera2lidar) 4 x 4 float32 as get_data_info builds them."""
     l2c_r = np.linalg.inv(cam["sensor2lidar_rotation"])

@@ -122,6 +122,29 @@ def test_camera_lidar_file_loader_end_to_end(tmp_path):
     assert seen == 3 and loader.images_decoded == 6
 
 
+@pytest.mark.parametrize("case", ["five", "eleven", "none"])
+def test_camera_lidar_file_loader_applies_the_points_range_filter(tmp_path, case):
+    """the test pipeline's PointsRangeFilter (default.yaml:233-235) sits between the sweep merge and everything
+    that reads ``points`` (the voxelizer AND the view transform's lidar depth image).  The loader's merged, filtered cloud
+    == the reference's LoadPointsFromMultiSweeps -> PointsRangeFilter output bit for bit (golden from the reference classes;
+    the range's x_max is exactly one merged point's x: strict bound); with the filter off the unfiltered golden comes back."""
+    from al3d.datasets import CameraLidarFileLoader
+    g = np.load(os.path.join(G, "bevfusion_sweeps.npz"))
+    infos, want, _ = _write_pool_from_golden(tmp_path, [case])
+    rg = g[f"{case}.range"]
+    vox = dict(range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], voxel_size=[0.075, 0.075, 0.2], max_points_in_voxel=10,
+               max_voxel_num=120000)
+    for pr, ref in ((rg.tolist(), g[f"{case}.out_range"]), (None, want[0])):
+        loader = CameraLidarFileLoader(infos, vox, None, batch_size=1, device=DEV, root=str(tmp_path), image_size=(64, 176),
+                                       threads=2, decode_threads=2, point_cloud_range=pr)
+        ex = next(iter(loader))
+        got = ex["points"][0].cpu().numpy()
+        assert got.shape == ref.shape and np.array_equal(got.view(np.int32), ref.view(np.int32)), (case, pr)
+    # default: the voxelizer's range
+    assert CameraLidarFileLoader(infos, vox, None, batch_size=1, device=DEV, root=str(tmp_path), image_size=(64, 176),
+                                 threads=2, decode_threads=2).point_range == vox["range"]
+
+
 def test_cli_sweeps_a_camera_lidar_pool_from_files(tmp_path):
     """tools/active_select.py on BASELINE configs[4] WITHOUT --synthetic-scenes: an mmdet3d-format pool on disk (lidar .bin
     files, six JPEG cameras per sample, infos pkl) -> CameraLidarFileLoader -> the registered BEVFusion detector ->

@@ -63,6 +63,18 @@ def test_sweep_merge_oracle_matches_the_reference_class(case):
     assert got.shape == want.shape and np.array_equal(got.view(np.int32), want.view(np.int32))
 
 
+@pytest.mark.parametrize("case", ["five", "eleven", "none"])
+def test_points_range_filter_oracle_matches_the_reference_class(case):
+    """oracle.points_range_filter == the reference's PointsRangeFilter on the merged cloud (strict bounds: the range's
+    x_max is exactly one point's x, and that point goes): same rows, same order, bit for bit."""
+    g = np.load(os.path.join(G, "bevfusion_sweeps.npz"))
+    key, sweeps, ts, merged = _golden_sweeps(case)
+    rg, want = g[f"{case}.range"], g[f"{case}.out_range"]
+    assert (merged[:, 0] == rg[3]).any()
+    got = BL.points_range_filter(BL.merge_sweeps(key, sweeps, ts), rg)
+    assert got.shape == want.shape and np.array_equal(got.view(np.int32), want.view(np.int32))
+
+
 def test_library_filter_tables_equal_the_oracle():
     """al3d_image_resample_coeffs (a host function of the library: no GPU needed) == the numpy restatement."""
     from al3d import lib

@@ -90,8 +90,37 @@ def test_raster_perm_frame_sorted_fast_path(case):
     want = np.argsort(_raster_key(coords, shape), kind="stable")
     assert np.array_equal(perm.cpu().numpy(), want.astype(np.int32))
     assert np.array_equal(cr.cpu().numpy(), coords[want])
+    assert int(D.raster_perm.last_status.item()) == 0                       # the promise was kept
     slow_perm, slow_cr = D.raster_perm(_t(coords), batch, shape)            # the general path gives the same answer
     assert torch.equal(slow_perm, perm) and torch.equal(slow_cr, cr)
+
+
+@pytest.mark.parametrize("case", ["unsorted", "too_many"])
+def test_raster_perm_checks_its_promise(case):
+    """frame_rows_max is a promise the device CHECKS.  Rows that are not frame-sorted, or a frame with more
+    than 65,535 rows: the status word is set, perm is still a permutation of all rows and coords_raster the matching
+    coordinates (nothing uninitialised reaches a gather), and the encoder's check raises."""
+    from al3d import detector_ops as D, lib
+    rng = np.random.default_rng(11)
+    shape = [41, 96, 1024]
+    counts = [3000, 2000, 1000] if case == "unsorted" else [65536 + 500, 100]
+    rows = []
+    for b, c in enumerate(counts):
+        cells = rng.choice(shape[0] * shape[1] * shape[2], size=c, replace=False)
+        x, y, z = cells % shape[2], (cells // shape[2]) % shape[1], cells // (shape[2] * shape[1])
+        rows.append(np.stack([np.full_like(x, b), z, y, x], 1))
+    coords = np.concatenate(rows).astype(np.int32)
+    if case == "unsorted":
+        coords = coords[rng.permutation(len(coords))]
+    perm, cr = D.raster_perm(_t(coords), len(counts), shape, frame_rows_max=60000)
+    status = D.raster_perm.last_status
+    torch.cuda.synchronize()
+    assert int(status.item()) == (1 if case == "unsorted" else 2)
+    p = perm.cpu().numpy()
+    assert np.array_equal(np.sort(p), np.arange(len(coords)))
+    assert np.array_equal(cr.cpu().numpy(), coords[p])
+    with pytest.raises(lib.Al3dError):
+        D.check_raster_status(status)
 
 
 def test_rows_gather_pad():

@@ -1,5 +1,6 @@
 # dev: runtime ablations of the level-0 item-stream kernel (AL3D_R16_ABL bits: 1 rows from the zero row, 2 no indices,
 # 4 no products, 8 no fragment reads, 16 no stores, 32 no residual requests)
+# needs the tuning build: make -C exploring-*_amd/csrc EXTRA=-DAL3D_R16_ABLATE (the shipped library ignores AL3D_R16_ABL)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 : > $O/l0_abl.log
