@@ -141,7 +141,7 @@ class CameraLidarFileLoader(FileSweepLoader):
         self._aug = {}
         from .file_loader import usable_cores
         self._pool = ThreadPoolExecutor(max_workers=int(decode_threads or max(2, usable_cores() - 2)))
-        self._img_jobs, self._img_pinned = {}, {}
+        self._img_pinned = {}
         self.images_decoded = 0
 
     # ---- lidar side: LoadPointsFromFile + LoadPointsFromMultiSweeps (test branch)
@@ -172,12 +172,19 @@ class CameraLidarFileLoader(FileSweepLoader):
         for i in ids:
             cams = self.infos[i]["cams"]
             jobs.append([self._pool.submit(_decode_rgb, self._path(c["data_path"])) for c in cams.values()])
-        self._img_jobs[id(st)] = jobs
+        st.extra = jobs                                      # on the staged batch itself (not keyed by id())
         return st
+
+    def _abandon(self, st):
+        """Iteration ended before this batch was finished: cancel the decode jobs that have not started, drop the rest."""
+        for cam_jobs in getattr(st, "extra", None) or []:
+            for f in cam_jobs:
+                f.cancel()
+        st.extra = None
 
     def _finish(self, st):
         ex = super()._finish(st)
-        jobs = self._img_jobs.pop(id(st))
+        jobs, st.extra = st.extra, None
         frames = [[f.result() for f in cam_jobs] for cam_jobs in jobs]
         B, N = len(frames), len(frames[0])
         if any(len(fr) != N for fr in frames):
@@ -218,6 +225,14 @@ class CameraLidarFileLoader(FileSweepLoader):
             return torch.from_numpy(np.ascontiguousarray(np.stack(a), dtype=np.float32)).to(self.device)
         ex["img"] = img.view(B, N, *img.shape[1:])
         ex["lidar2image"], ex["camera_intrinsics"], ex["camera2lidar"] = dev(l2i), dev(K), dev(c2l)
+        # digest of the host bytes every calibration tensor of this batch was uploaded from (the view transform's plan cache
+        # compares it on the host: models/bevfusion_camera.py)
+        import hashlib
+        hk = hashlib.sha1()
+        for a in (l2i, K, c2l):
+            hk.update(np.ascontiguousarray(np.stack(a), dtype=np.float32).tobytes())
+        hk.update(aug.matrix.tobytes() + bytes([B, N]))
+        ex["calib_key"] = hk.digest()
         ex["img_aug_matrix"] = torch.from_numpy(aug.matrix).to(self.device).expand(B, N, 4, 4).contiguous()
         ex["lidar_aug_matrix"] = torch.eye(4, device=self.device).expand(B, 4, 4).contiguous()
         off = ex["point_offsets"].cpu().tolist()             # per-sample clouds for the view transform's depth image

@@ -84,7 +84,7 @@ class SweepFileReader:
 class _Staged:
     """One batch in flight on the host side: its pinned buffer, layout and read job."""
     __slots__ = ("pinned", "job", "total", "nf", "B", "o_off", "o_xf", "o_tl", "o_has", "o_key", "o_ff", "nbytes",
-                 "ids", "slot")
+                 "ids", "slot", "extra")                     # extra: a subclass's own per-batch state (camera decode jobs)
 
 
 class FileSweepLoader:
@@ -241,4 +241,8 @@ class FileSweepLoader:
                     self.reader.wait(st.job)
                 except Exception:
                     pass
+                self._abandon(st)
             staged.clear()
+
+    def _abandon(self, st):
+        """Hook: a staged batch that will never be finished (subclasses drop what they attached to it)."""

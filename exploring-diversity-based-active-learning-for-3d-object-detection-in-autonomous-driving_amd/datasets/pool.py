@@ -137,7 +137,13 @@ class CameraLidarSweepLoader(DeviceSweepLoader):
             K, cam2lidar, lidar2image, img_aug, lidar_aug, _ = synthetic.camera_setup(1, self.num_cameras, seed + 9, self.image_size)
             calib = dict(camera_intrinsics=K, camera2lidar=cam2lidar, lidar2image=lidar2image, img_aug_matrix=img_aug,
                          lidar_aug_matrix=lidar_aug)
-        self.calib = {k: v.to(self.device, dtype=torch.float32) for k, v in calib.items()}
+        # digests of the host copies, per calibration row: a batch's ``calib_key`` lets the view transform decide on the
+        # host whether its cached pooling plan still applies (no device comparison, no stream synchronisation)
+        import hashlib
+        host = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in calib.items()}
+        self._calib_digest = {k: [hashlib.sha1(v[r].numpy().tobytes()).digest() for r in range(v.shape[0])]
+                              for k, v in host.items()}
+        self.calib = {k: v.to(self.device) for k, v in host.items()}
 
     def __iter__(self):
         M = self.images.shape[0]
@@ -146,7 +152,10 @@ class CameraLidarSweepLoader(DeviceSweepLoader):
             sel = torch.as_tensor([i % M for i in ids], device=self.device)
             ex["img"] = self.images[sel]
             ex["points"] = [self.pool.frames[i] for i in ids]
+            key = []
             for k, v in self.calib.items():
                 rows = torch.as_tensor([i % v.shape[0] for i in ids], device=self.device)
                 ex[k] = v[rows]
+                key.append(b"".join(self._calib_digest[k][i % v.shape[0]] for i in ids))
+            ex["calib_key"] = b"|".join(key)
             yield ex

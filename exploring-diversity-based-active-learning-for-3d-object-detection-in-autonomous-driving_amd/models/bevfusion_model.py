@@ -80,7 +80,7 @@ class BEVFusionCameraLidar(nn.Module):
         fpn = self.camera_neck(list(feats))[0]
         mark("camera neck (LSS-FPN)")
         cam = self.vtransform(fpn.view(B, N, *fpn.shape[1:]), points, lidar2image, cam_intrinsic, camera2lidar,
-                              img_aug_matrix, lidar_aug_matrix)
+                              img_aug_matrix, lidar_aug_matrix, calib_key=example.get("calib_key") if isinstance(example, dict) else None)
         cam = cam.permute(0, 2, 1, 3).contiguous()                   # [x, y] -> this build's [H=y, W=x]
         mark("view transform (depth LSS)")
         if lidar_bev is None:

@@ -246,3 +246,15 @@ def test_pooling_plan_is_cached_per_calibration_and_equals_the_one_shot_call():
     r3 = rows(moved)
     out3 = vt.pool_lss(d2, c2, r3, B, N)
     assert vt.plan_builds == 2 and torch.equal(out3, one_shot(d2, c2, r3)) and not torch.equal(out3, one_shot(d2, c2, r1))
+    # with a host-side calibration digest the decision needs no device comparison: same key -> reuse, other
+    # key -> rebuild, and a plan used from another stream waits for the event recorded at its build
+    out4 = vt.pool_lss(d2, c2, r3, B, N, calib_key=b"rig-a")
+    assert vt.plan_builds == 3 and torch.equal(out4, out3)             # the held plan carried no key: rebuilt once, keyed
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out5 = vt.pool_lss(d2, c2, r3, B, N, calib_key=b"rig-a")
+    torch.cuda.current_stream().wait_stream(side)
+    assert vt.plan_builds == 3 and torch.equal(out5, out3)
+    out6 = vt.pool_lss(d1, c1, r1, B, N, calib_key=b"rig-b")
+    assert vt.plan_builds == 4 and torch.equal(out6, one_shot(d1, c1, r1))
