@@ -519,11 +519,14 @@ extern "C" int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW
 }
 
 // ------------------------------------------------------------------ top-down step of the LSS-FPN
-// generalized_lss.py:88-101: x = cat([laterals[i], interpolate(laterals[i + 1], size = laterals[i].shape, mode = bilinear,
-// align_corners = True)], channel).  One kernel writes the concatenated channels-last map: a thread owns four channels of one
-// output pixel -- the first C1 are copied from `lat`, the other C2 are the four-tap blend of `src` with torch's weights
-// (source position = o * (in - 1) / (out - 1) in float, the upper neighbour clamped at the border; blend as
+// generalized_lss.py:88-101: x = cat([laterals[i], interpolate(laterals[i + 1], size = laterals[i].shape, **upsample_cfg)],
+// channel), upsample_cfg = {mode: bilinear, align_corners: ...} (the class defaults to True, the shipped swint configs set
+// false: configs/nuscenes/det/transfusion/secfpn/camera+lidar/default.yaml:16-18).  One kernel writes the concatenated
+// channels-last map: a thread owns four channels of one output pixel -- the first C1 are copied from `lat`, the other C2 are
+// the four-tap blend of `src` with torch's weights (source position in float: align_corners: o (in - 1) / (out - 1);
+// otherwise max(0, (o + 0.5) in / out - 0.5); the upper neighbour clamped at the border; blend as
 // h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11)).
+template <bool ALIGN>
 __global__ __launch_bounds__(256) void lss_upsample_cat_kernel(const float* __restrict__ lat, const float* __restrict__ src, int64_t total,
                                                                int H, int W, int C1, int h, int w, int C2, float sh, float sw,
                                                                float* __restrict__ out)
@@ -540,7 +543,13 @@ __global__ __launch_bounds__(256) void lss_upsample_cat_kernel(const float* __re
     } else {
         const int x = (int)(px % W), y = (int)((px / W) % H);
         const int64_t n = px / ((int64_t)W * H);
-        const float yr = sh * (float)y, xr = sw * (float)x;
+        float yr, xr;
+        if constexpr (ALIGN) {
+            yr = sh * (float)y; xr = sw * (float)x;
+        } else {                                                    // torch's area_pixel_compute_source_index, cubic = false
+            yr = sh * ((float)y + 0.5f) - 0.5f; xr = sw * ((float)x + 0.5f) - 0.5f;
+            yr = yr < 0.f ? 0.f : yr; xr = xr < 0.f ? 0.f : xr;
+        }
         const int y0 = (int)yr, x0 = (int)xr;
         const int yp = y0 < h - 1 ? 1 : 0, xp = x0 < w - 1 ? 1 : 0;
         const float ly = yr - (float)y0, lx = xr - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
@@ -556,8 +565,17 @@ __global__ __launch_bounds__(256) void lss_upsample_cat_kernel(const float* __re
     *reinterpret_cast<float4*>(out + px * (C1 + C2) + c) = v;
 }
 
+extern "C" int al3d_lss_upsample_cat_mode_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2,
+                                              int align_corners, float* out, void* stream);
+
 extern "C" int al3d_lss_upsample_cat_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2,
                                          float* out, void* stream)
+{
+    return al3d_lss_upsample_cat_mode_f32(lat, src, N, H, W, C1, h, w, C2, 1, out, stream);
+}
+
+extern "C" int al3d_lss_upsample_cat_mode_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2,
+                                              int align_corners, float* out, void* stream)
 {
     AL3D_REQUIRE(lat && src && out, "al3d_lss_upsample_cat_f32: null pointer");
     AL3D_REQUIRE(N >= 0 && H >= 1 && W >= 1 && h >= 1 && w >= 1 && C1 >= 4 && C2 >= 4 && C1 % 4 == 0 && C2 % 4 == 0,
@@ -565,9 +583,15 @@ extern "C" int al3d_lss_upsample_cat_f32(const float* lat, const float* src, int
     AL3D_REQUIRE((((uintptr_t)lat | (uintptr_t)src | (uintptr_t)out) & 15) == 0, "al3d_lss_upsample_cat_f32: 16-byte aligned maps");
     const int64_t total = (int64_t)N * H * W * ((C1 + C2) / 4);
     if (total == 0) return AL3D_OK;
-    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    hipLaunchKernelGGL(lss_upsample_cat_kernel, dim3((unsigned)al3d_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, lat, src,
-                       total, H, W, C1, h, w, C2, sh, sw, out);
+    if (align_corners) {
+        const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+        hipLaunchKernelGGL(lss_upsample_cat_kernel<true>, dim3((unsigned)al3d_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           lat, src, total, H, W, C1, h, w, C2, sh, sw, out);
+    } else {
+        const float sh = (float)h / (float)H, sw = (float)w / (float)W;        // area_pixel_compute_scale without scale factors
+        hipLaunchKernelGGL(lss_upsample_cat_kernel<false>, dim3((unsigned)al3d_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           lat, src, total, H, W, C1, h, w, C2, sh, sw, out);
+    }
     AL3D_CHECK_LAUNCH("lss_upsample_cat_kernel");
     return AL3D_OK;
 }

@@ -318,8 +318,14 @@ class GeneralizedLSSFPN(nn.Module):
     [BN, H_l, W_l, C_l] in, tuple of the ``used_backbone_levels`` outputs out.  Upsample + concatenation are one kernel
     (``al3d_lss_upsample_cat_f32``), the convolutions run on the dense conv kernels."""
 
-    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, upsample_cfg=None, **kwargs):
         super().__init__()
+        # upsample_cfg: the class default is align_corners=True (generalized_lss.py:25); the shipped swint configs pass
+        # {mode: bilinear, align_corners: false} (configs/.../camera+lidar/default.yaml:16-18) -- found by the round-5 golden
+        upsample_cfg = dict(mode="bilinear", align_corners=True) if upsample_cfg is None else dict(upsample_cfg)
+        if upsample_cfg.get("mode", "bilinear") != "bilinear":
+            raise lib.Al3dError("GeneralizedLSSFPN: only bilinear upsampling is built")
+        self.align_corners = bool(upsample_cfg.get("align_corners", False))
         self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
         self.num_ins = len(in_channels)
         self.backbone_end_level = self.num_ins - 1 if end_level == -1 else end_level
@@ -345,9 +351,9 @@ class GeneralizedLSSFPN(nn.Module):
                 raise lib.Al3dError(f"GeneralizedLSSFPN: level channel counts {lat.shape[-1]} / {src.shape[-1]} must be "
                                     "multiples of 4 (al3d_lss_upsample_cat_f32)")
             x = torch.empty((*lat.shape[:3], lat.shape[-1] + src.shape[-1]), dtype=torch.float32, device=lat.device)
-            lib.call("al3d_lss_upsample_cat_f32", _ptr(_dev(lat, torch.float32, "lateral")), _ptr(_dev(src, torch.float32, "coarser level")),
+            lib.call("al3d_lss_upsample_cat_mode_f32", _ptr(_dev(lat, torch.float32, "lateral")), _ptr(_dev(src, torch.float32, "coarser level")),
                      lat.shape[0], lat.shape[1], lat.shape[2], lat.shape[3], src.shape[1], src.shape[2], src.shape[3],
-                     _ptr(x), _stream())
+                     1 if self.align_corners else 0, _ptr(x), _stream())
             laterals[i] = self.fpn_convs[i](self.lateral_convs[i](x))
         return tuple(laterals[i] for i in range(used))
 

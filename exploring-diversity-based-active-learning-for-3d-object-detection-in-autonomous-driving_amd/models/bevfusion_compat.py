@@ -67,17 +67,37 @@ def convert_lidar_state_dict(sd, lidar_prefix="encoders.lidar.backbone.", decode
                 bn(f"{src}.bn{c}", f"{dst}.bn{c}")
     out["backbone.middle_conv3.2.weight"] = _sp(sd[e + "conv_out.0.weight"])
     bn(e + "conv_out.1", "backbone.middle_conv3.3")
+    out.update(convert_decoder_state_dict(sd, decoder_prefix))
+    return out
+
+
+def convert_decoder_state_dict(sd, decoder_prefix="decoder.", neck_prefix="neck."):
+    """The decoder half alone: BEVFusion's ``SECOND`` + ``SECONDFPN`` parameters (``<decoder_prefix>backbone.blocks.b.k.*``,
+    ``<decoder_prefix>neck.deblocks.b.k.*``; second.py:42-70, necks/second.py:46-75) -> this build's ``RPN``
+    (``<neck_prefix>blocks.b.k.*`` with the ZeroPad2d slot, ``<neck_prefix>deblocks.b.k.*``), 2-D kernels transposed for the
+    [H = y, W = x] maps.  Pinned by tests/test_bevfusion_second_golden_gpu.py against the reference classes' own output."""
+    out = {}
+
+    def bn(src, dst):
+        for k in _BN:
+            if src + "." + k in sd:
+                out[dst + "." + k] = sd[src + "." + k]
+            elif k != "num_batches_tracked":
+                raise KeyError(src + "." + k)
+
     d = decoder_prefix
-    for b in range(2):
+    b = 0
+    while f"{d}backbone.blocks.{b}.0.weight" in sd:
         i = 0
         while f"{d}backbone.blocks.{b}.{3 * i}.weight" in sd:     # there: conv, bn, relu; here: pad, conv, bn, relu, ...
-            out[f"neck.blocks.{b}.{3 * i + 1}.weight"] = _t2(sd[f"{d}backbone.blocks.{b}.{3 * i}.weight"])
-            bn(f"{d}backbone.blocks.{b}.{3 * i + 1}", f"neck.blocks.{b}.{3 * i + 2}")
+            out[f"{neck_prefix}blocks.{b}.{3 * i + 1}.weight"] = _t2(sd[f"{d}backbone.blocks.{b}.{3 * i}.weight"])
+            bn(f"{d}backbone.blocks.{b}.{3 * i + 1}", f"{neck_prefix}blocks.{b}.{3 * i + 2}")
             i += 1
-        if i == 0:
-            raise KeyError(f"{d}backbone.blocks.{b}.0.weight")
-        out[f"neck.deblocks.{b}.0.weight"] = _t2(sd[f"{d}neck.deblocks.{b}.0.weight"])
-        bn(f"{d}neck.deblocks.{b}.1", f"neck.deblocks.{b}.1")
+        out[f"{neck_prefix}deblocks.{b}.0.weight"] = _t2(sd[f"{d}neck.deblocks.{b}.0.weight"])
+        bn(f"{d}neck.deblocks.{b}.1", f"{neck_prefix}deblocks.{b}.1")
+        b += 1
+    if b == 0:
+        raise KeyError(f"{d}backbone.blocks.0.0.weight")
     return out
 
 

@@ -29,7 +29,8 @@ class BEVFusionCameraLidar(nn.Module):
         self.lidar = lidar_detector                                   # sparse encoder + SECOND / SECONDFPN ("neck")
         self.camera_backbone = SwinTransformer(embed_dims=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7,
                                                mlp_ratio=4, qkv_bias=True, patch_norm=True, out_indices=[1, 2, 3])
-        self.camera_neck = GeneralizedLSSFPN([192, 384, 768], 256, 3)
+        # upsample_cfg of the swint configs (configs/nuscenes/det/transfusion/secfpn/camera+lidar/default.yaml:16-18)
+        self.camera_neck = GeneralizedLSSFPN([192, 384, 768], 256, 3, upsample_cfg=dict(mode="bilinear", align_corners=False))
         self.vtransform = DepthLSSTransform(256, camera_channels, image_size, feature_size, list(xbound), list(ybound),
                                             list(zbound), list(dbound), downsample=2)
         self.fuser = ConvFuser([camera_channels, lidar_channels], lidar_channels)

@@ -577,6 +577,11 @@ int al3d_lss_depth_softmax_f32(const float* y, int BN, int fH, int fW, int D, in
  * cat(lat [N][H][W][C1], bilinear upsample (align_corners = True, torch's weights) of src [N][h][w][C2]); C1, C2 % 4 == 0. */
 int al3d_lss_upsample_cat_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2, float* out,
                               void* stream);
+/* ... with upsample_cfg's align_corners as a parameter (the class default is True; the shipped swint configs set false:
+ * bevfusion/configs/nuscenes/det/transfusion/secfpn/camera+lidar/default.yaml:16-18): 0 = torch's half-pixel source
+ * positions max(0, (o + 0.5) in / out - 0.5). */
+int al3d_lss_upsample_cat_mode_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2,
+                                   int align_corners, float* out, void* stream);
 /* depth_lss.py:38-44, the first two layers of `dtransform` as one kernel: Conv2d(1, 8, 1) + BN + ReLU -> Conv2d(8, 32, 5,
  * stride 4, padding 2) + BN + ReLU on the depth image [BN][iH][iW] -> out [BN][oH][oW][32] (channels-last, oH =
  * (iH - 1) / 4 + 1).  p0 = [w0[8] | scale0[8] | shift0[8]] with layer 0 = relu((w0 d) scale0 + shift0) (bias and BN folded:

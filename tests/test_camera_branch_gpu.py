@@ -185,8 +185,9 @@ def test_fused_dtransform_head_matches_float64(size):
     assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("shape", [((2, 32, 88, 192), (16, 44, 384)), ((1, 7, 5, 8), (3, 2, 12)), ((1, 4, 4, 4), (1, 1, 4))])
-def test_upsample_cat_kernel_matches_torch(shape):
+def test_upsample_cat_kernel_matches_torch(shape, align):
     """``al3d_lss_upsample_cat_f32`` (generalized_lss.py:88-101: bilinear upsample with align_corners=True of the coarser
     level + channel concatenation, one kernel on channels-last maps) against ``F.interpolate`` + ``torch.cat``: the
     copied half bit for bit, the interpolated half to fp32 rounding of a four-tap blend against torch's float32 result;
@@ -199,9 +200,10 @@ def test_upsample_cat_kernel_matches_torch(shape):
     src = torch.randn(N, h, w, C2, generator=g).to(DEV)
     out = torch.empty(N, H, W, C1 + C2, device=DEV)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    lib.call("al3d_lss_upsample_cat_f32", p(lat), p(src), N, H, W, C1, h, w, C2, p(out), torch.cuda.current_stream().cuda_stream)
-    up64 = F.interpolate(src.permute(0, 3, 1, 2).double(), size=(H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
-    up32 = F.interpolate(src.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    lib.call("al3d_lss_upsample_cat_mode_f32", p(lat), p(src), N, H, W, C1, h, w, C2, 1 if align else 0, p(out),
+             torch.cuda.current_stream().cuda_stream)
+    up64 = F.interpolate(src.permute(0, 3, 1, 2).double(), size=(H, W), mode="bilinear", align_corners=align).permute(0, 2, 3, 1)
+    up32 = F.interpolate(src.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=align).permute(0, 2, 3, 1)
     scale = float(src.abs().max())
     assert torch.equal(out[..., :C1], lat)
     # the source position o * (in - 1) / (out - 1) is a float32 product in torch and here: against torch's own float32 result
