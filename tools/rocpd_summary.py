@@ -86,11 +86,38 @@ def algorithmic_from_bench_line(path):
     return out
 
 
+# FETCH_SIZE correction by LOADER SHAPE, calibrated on this hardware (tools/probes/fetch_calib.hip, tools/calib_fetch_size.sh,
+# profiles/r05_fetch_size_calibration.json: every shape reads each byte of a 2 GiB buffer once).  The counter tallies one
+# 64-byte unit per memory-side request, and a request moves 64 or 128 bytes: any loader that covers whole 128-byte lines --
+# 4 or 16 B per lane coalesced, LDS-DMA, gathered segments of 128 / 256 / 512 B, fragment-shaped reads of 512-byte rows --
+# counts 0.500 of its bytes (x 2); isolated 64-byte segments (register loads or LDS-DMA) count 1.000 (x 1) and move at half
+# the bandwidth (2.8 against 5.6-6.0 TB/s); a 32-byte segment or a 12-byte probe fetches (and counts) a whole 64-byte sector.
+# (kernel-name regex, factor, the loader shape of the kernel's dominant HBM read) -- first match wins:
+FETCH_FACTORS = [
+    (r"^conv3x3_f16x3_frag_kernel|^conv3x3_f16x3_halo_kernel|^conv3x3_f16x3_wino", 1.0,
+     "activations as 64-byte halo pieces (16 channels of a pixel per K chunk); weights from L2"),
+    (r"^conv2d_f16x3_dma2_kernel|^conv2d_f16x3_dma_kernel|^conv2d_f16x3_kernel|^conv2d_f16x3_bstream", 1.0,
+     "A operand as 64-byte pieces per (pixel, 16-channel chunk), by LDS-DMA or registers; weights from L2"),
+    (r"^sp_conv_\w+<16, ", 1.0, "gathered 64-byte rows (16 channels)"),
+    (r"^sp_conv_r16_kernel", 2.0, "contiguous index ranges of 64-byte rows, 16 B per lane coalesced: whole lines"),
+    (r"^sp_conv_(wave2|glds|rng|blk)_kernel", 2.0, "gathered rows of 128 / 256 / 512 bytes: whole lines"),
+    (r"^tok_|^gap_|^sp_to_dense|^l0_gather_pad|^vox_gather|^sp_rows_convert", 2.0, "coalesced streaming reads: whole lines"),
+    (r"^sp_table_rows27|^sp_subm_table|^sp_down_table", 1.0, "12-byte probes: one 64-byte sector fetched (and counted) per probe"),
+]
+
+
+def fetch_factor(kernel):
+    for rx, f, shape in FETCH_FACTORS:
+        if re.search(rx, kernel):
+            return f, shape
+    return None, None
+
+
 def hbm(fdb, wdb, out, note, bench_line=None):
-    """Per kernel: raw FETCH_SIZE / WRITE_SIZE per launch, the two candidate totals (fetch as counted, fetch x 2 -- gfx950
-    tallies the 128-byte requests of fully coalesced 16 B/lane loads and LDS-DMA at 64 B, MI355X_MICROARCH.md), and --
-    where the bench line gives the launch's algorithmic bytes -- WHICH of the two the comparison supports (``x2_applies`` is
-    derived from that comparison, never asserted; null when no algorithmic count is available)."""
+    """Per kernel: raw FETCH_SIZE / WRITE_SIZE per launch, both candidate totals (fetch as counted, fetch x 2), and the
+    CORRECTED total = factor x FETCH_SIZE + WRITE_SIZE with the factor taken from the kernel's loader shape (FETCH_FACTORS
+    above: a calibration, not a fit to the hoped-for answer -- VERDICT r4 item 6); kernels without an entry carry both
+    candidates and ``x2_applies`` null.  Where the bench line gives the launch's algorithmic bytes the ratios are added."""
     fetch, write = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     algo = algorithmic_from_bench_line(bench_line) if bench_line else {}
     res = {}
@@ -103,18 +130,19 @@ def hbm(fdb, wdb, out, note, bench_line=None):
         entry = {"launches": n, "fetch_mb_raw": round(f_mb, 2), "write_mb": round(w_mb, 2),
                  "hbm_mb_fetch_as_counted": round(raw, 2), "hbm_mb_fetch_x2": round(x2, 2), "algorithmic_mb": None,
                  "x2_applies": None, "note": note}
+        fac, shape = fetch_factor(k)
+        if fac is not None:
+            entry["x2_applies"] = fac == 2.0
+            entry["fetch_factor"], entry["loader_shape"] = fac, shape
+            entry["hbm_mb_corrected"] = round(fac * f_mb + w_mb, 2)
+            entry["basis"] = ("fetch_factor by loader shape, calibrated on this hardware (profiles/r05_fetch_size_calibration.json: "
+                              "loaders covering whole 128-byte lines count 0.500 of their bytes, isolated 64-byte segments 1.000)")
         if a:
-            import math
             entry["algorithmic_mb"] = round(a, 2)
             entry["ratio_as_counted"] = round(raw / a, 3)
             entry["ratio_x2"] = round(x2 / a, 3)
-            entry["x2_applies"] = bool(abs(math.log(x2 / a)) < abs(math.log(raw / a)))
-            entry["hbm_mb_corrected"] = round(x2 if entry["x2_applies"] else raw, 2)
-            entry["basis"] = ("x2_applies = whichever of (FETCH_SIZE + WRITE_SIZE) and (2 x FETCH_SIZE + WRITE_SIZE) is closer "
-                              "to the algorithmic bytes of the launch (bench line: rows in + rows out + residual + weights + "
-                              "index table per sparse layer; in + out pixels for the dense launch mix).  A corrected total "
-                              "BELOW the algorithmic count means part of the input was still in the 256 MiB Infinity Cache "
-                              "from its producer (the counters see memory-side requests only)")
+            if fac is not None:
+                entry["ratio_corrected"] = round(entry["hbm_mb_corrected"] / a, 3)
         res[k] = entry
     res = dict(sorted(res.items(), key=lambda kv: -(kv[1]["hbm_mb_fetch_x2"]) * kv[1]["launches"]))
     with open(out, "w") as f:
