@@ -227,7 +227,8 @@ class ConvTimer:
         else:
             out.update(kernel="conv2d_mfma_kernel", peak=MFMA_F32_PEAK_TFLOPS,
                        frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
-        for pmc in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for pmc in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json",
+                    "r01_pmc_hbm_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", pmc)
             if not os.path.exists(pmc):      # PMC passes are separate runs (rocprofv3 --pmc); see DESIGN.md
                 continue
@@ -238,7 +239,8 @@ class ConvTimer:
                     out["traffic_detail"] = {k: rec[k] for k in ("fetch_mb_raw", "fetch_mb_x2", "write_mb", "launches",
                                                                  "correction", "hbm_mb_fetch_as_counted", "hbm_mb_fetch_x2",
                                                                  "algorithmic_mb", "x2_applies", "ratio_as_counted",
-                                                                 "ratio_x2") if k in rec}
+                                                                 "ratio_x2", "fetch_factor", "loader_shape",
+                                                                 "ratio_corrected") if k in rec}
                     out["traffic_note"] = rec.get("note", "") + " (" + os.path.basename(pmc) + ")"
                     break
             except Exception:

@@ -98,8 +98,8 @@ FETCH_FACTORS = [
      "activations as 64-byte halo pieces (16 channels of a pixel per K chunk); weights from L2"),
     (r"^conv2d_f16x3_dma2_kernel|^conv2d_f16x3_dma_kernel|^conv2d_f16x3_kernel|^conv2d_f16x3_bstream", 1.0,
      "A operand as 64-byte pieces per (pixel, 16-channel chunk), by LDS-DMA or registers; weights from L2"),
-    (r"^sp_conv_\w+<16, ", 1.0, "gathered 64-byte rows (16 channels)"),
     (r"^sp_conv_r16_kernel", 2.0, "contiguous index ranges of 64-byte rows, 16 B per lane coalesced: whole lines"),
+    (r"^sp_conv_\w+<16, ", 1.0, "gathered 64-byte rows (16 channels)"),
     (r"^sp_conv_(wave2|glds|rng|blk)_kernel", 2.0, "gathered rows of 128 / 256 / 512 bytes: whole lines"),
     (r"^tok_|^gap_|^sp_to_dense|^l0_gather_pad|^vox_gather|^sp_rows_convert", 2.0, "coalesced streaming reads: whole lines"),
     (r"^sp_table_rows27|^sp_subm_table|^sp_down_table", 1.0, "12-byte probes: one 64-byte sector fetched (and counted) per probe"),
