@@ -596,6 +596,49 @@ extern "C" int al3d_lss_upsample_cat_mode_f32(const float* lat, const float* src
     return AL3D_OK;
 }
 
+// ------------------------------------------------------------------ channel concatenation of two channels-last maps
+// out [N][H][W][Ca + Cb] = cat(a, b) per pixel (depth_lss.py:84: cat([d, x], dim=1) before the depth net; fusers/conv.py:24:
+// cat(inputs, dim=1) before the fuser's convolution).  a_hw_swapped: `a` is stored [N][W][H][Ca] -- the view transform's BEV
+// map comes out as [x, y] and every other map of this build is [H = y, W = x]: the transposition rides on the copy instead of
+// being a pass of its own.  One thread per four channels of an output pixel.
+__global__ __launch_bounds__(256) void cat2_nhwc_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t total,
+                                                        int H, int W, int Ca, int Cb, int swapped, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int CQ = (Ca + Cb) >> 2;
+    const int c = (int)(t % CQ) * 4;
+    const int64_t px = t / CQ;
+    float4 v;
+    if (c < Ca) {
+        int64_t pa = px;
+        if (swapped) {
+            const int x = (int)(px % W), y = (int)((px / W) % H);
+            const int64_t n = px / ((int64_t)W * H);
+            pa = (n * W + x) * H + y;
+        }
+        v = *reinterpret_cast<const float4*>(a + pa * Ca + c);
+    } else {
+        v = *reinterpret_cast<const float4*>(b + px * Cb + (c - Ca));
+    }
+    *reinterpret_cast<float4*>(out + px * (Ca + Cb) + c) = v;
+}
+
+extern "C" int al3d_cat2_nhwc_f32(const float* a, const float* b, int N, int H, int W, int Ca, int Cb, int a_hw_swapped,
+                                  float* out, void* stream)
+{
+    AL3D_REQUIRE(a && b && out, "al3d_cat2_nhwc_f32: null pointer");
+    AL3D_REQUIRE(N >= 0 && H >= 1 && W >= 1 && Ca >= 4 && Cb >= 4 && Ca % 4 == 0 && Cb % 4 == 0,
+                 "al3d_cat2_nhwc_f32: channel counts must be multiples of 4");
+    AL3D_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "al3d_cat2_nhwc_f32: 16-byte aligned maps");
+    const int64_t total = (int64_t)N * H * W * ((Ca + Cb) / 4);
+    if (total == 0) return AL3D_OK;
+    hipLaunchKernelGGL(cat2_nhwc_kernel, dim3((unsigned)al3d_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a, b, total, H, W,
+                       Ca, Cb, a_hw_swapped ? 1 : 0, out);
+    AL3D_CHECK_LAUNCH("cat2_nhwc_kernel");
+    return AL3D_OK;
+}
+
 // ------------------------------------------------------------------ first two layers of the depth branch, fused
 // depth_lss.py:38-44: dtransform = Conv2d(1, 8, 1) + BN + ReLU -> Conv2d(8, 32, 5, stride 4, padding 2) + BN + ReLU on
 // the [BN, 1, iH, iW] lidar depth image.  As two convolutions that is a 554 MB eight-channel map per 16 samples written,

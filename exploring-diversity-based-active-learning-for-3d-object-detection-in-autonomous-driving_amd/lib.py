@@ -145,6 +145,7 @@ SIGNATURES = {
     "al3d_lss_geometry_f32": (c_int, [c_p, c_i64, c_p, c_int, c_p, c_p, c_p]),
     "al3d_lss_depth_softmax_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_lss_upsample_cat_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_cat2_nhwc_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_lss_upsample_cat_mode_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_lss_dtransform01_f32": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p]),
     "al3d_lss_depth_image_workspace_bytes": (c_i64, [c_int, c_int, c_int]),

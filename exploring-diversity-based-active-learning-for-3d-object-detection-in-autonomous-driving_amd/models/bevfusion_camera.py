@@ -246,6 +246,19 @@ class LSSViewTransform(nn.Module):
         return x
 
 
+def cat2_nhwc(a, b, a_hw_swapped=False):
+    """cat([a, b], channel) of two channels-last maps as ONE device kernel (``al3d_cat2_nhwc_f32``); a may be stored
+    [N, W, H, C] (``a_hw_swapped``)."""
+    a, b = _dev(a, torch.float32, "a").contiguous(), _dev(b, torch.float32, "b").contiguous()
+    N, H, W, Cb = b.shape
+    want = (N, W, H) if a_hw_swapped else (N, H, W)
+    if tuple(a.shape[:3]) != want:
+        raise lib.Al3dError(f"cat2_nhwc: map sizes {tuple(a.shape)} / {tuple(b.shape)} do not match")
+    out = torch.empty((N, H, W, a.shape[-1] + Cb), dtype=torch.float32, device=b.device)
+    lib.call("al3d_cat2_nhwc_f32", _ptr(a), _ptr(b), N, H, W, a.shape[-1], Cb, 1 if a_hw_swapped else 0, _ptr(out), _stream())
+    return out
+
+
 class ConvFuser(nn.Sequential):
     """fusers/conv.py:11-25: Conv2d(sum(in_channels), out_channels, 3, padding=1, bias=False) + BN + ReLU on the
     channel-concatenated BEV maps (channels-last here)."""
@@ -257,8 +270,14 @@ class ConvFuser(nn.Sequential):
         # kept OUT of the module tree: the state dict holds the reference's keys (0.weight, 1.*) and nothing else
         object.__setattr__(self, "_run", _ConvBNReLU(self[0], self[1]))
 
-    def forward(self, inputs):
+    def forward(self, inputs, first_hw_swapped=False):
+        """inputs: the channels-last BEV maps; ``first_hw_swapped``: the first one (the camera map) is still in the view
+        transform's [x, y] order and is transposed by the concatenation kernel (no pass of its own)."""
         assert [t.shape[-1] for t in inputs] == list(self.in_channels)
+        if len(inputs) == 2:
+            return self._run(cat2_nhwc(inputs[0], inputs[1], first_hw_swapped))
+        if first_hw_swapped:
+            inputs = [inputs[0].permute(0, 2, 1, 3)] + list(inputs[1:])
         return self._run(torch.cat(inputs, dim=-1).contiguous())
 
 
@@ -445,7 +464,7 @@ class DepthLSSTransform(LSSViewTransform):
             for layer in self._dt:
                 d = layer(d)
         assert d.shape[1:3] == (fH, fW), (d.shape, fH, fW)
-        y = torch.cat([d, x.reshape(B * N, fH, fW, Cin)], dim=-1).contiguous()
+        y = cat2_nhwc(d, x.reshape(B * N, fH, fW, Cin))
         for layer in self._dn:
             y = layer(y)
         y = y.contiguous()

@@ -82,14 +82,14 @@ class BEVFusionCameraLidar(nn.Module):
         mark("camera neck (LSS-FPN)")
         cam = self.vtransform(fpn.view(B, N, *fpn.shape[1:]), points, lidar2image, cam_intrinsic, camera2lidar,
                               img_aug_matrix, lidar_aug_matrix, calib_key=example.get("calib_key") if isinstance(example, dict) else None)
-        cam = cam.permute(0, 2, 1, 3).contiguous()                   # [x, y] -> this build's [H=y, W=x]
+        # cam is [x, y]; this build's maps are [H = y, W = x]: the fuser's concatenation kernel transposes it on the way
         mark("view transform (depth LSS)")
         if lidar_bev is None:
             lidar_bev, _ = self.lidar.sparse_stage(example, book=book)
         else:
             torch.cuda.current_stream(img.device).wait_stream(self._side_stream(img.device))
         mark("lidar encoder")
-        fused = self.fuser([cam, lidar_bev])
+        fused = self.fuser([cam, lidar_bev], first_hw_swapped=True)
         mark("fuser")
         dec = self.lidar.neck(fused)
         emb = getattr(self.lidar.neck, "embedding", None)

@@ -397,13 +397,21 @@ class TransFusionHead(nn.Module):
         the query's class; decode; optional per-group circle NMS (nuScenes: pedestrians and cones, radius 0.175)."""
         p = preds_dicts[0]
         P = self.num_proposals
-        score = p["heatmap"][..., -P:].sigmoid()
-        one_hot = F.one_hot(self.query_labels, num_classes=self.num_classes).permute(0, 2, 1)
-        score = score * p["query_heatmap_score"] * one_hot
-        vel = p["vel"][..., -P:] if "vel" in p else None
-        temp = self._decode(score, p["rot"][..., -P:], p["dim"][..., -P:], p["center"][..., -P:], p["height"][..., -P:], vel)
+        # Post-processing on the HOST (round 5): the query decoder's outputs for a batch are a few hundred KB; one D2H
+        # brings them over, the reference's arithmetic (sigmoid, exp, atan2: the same torch ops, on CPU tensors -- what the
+        # TransFusionBBoxCoder golden pins) and the per-sample filters / circle NMS run there, and the kept boxes return
+        # in one H2D -- instead of ~40 library launches and a dozen synchronisations per sample for boolean-mask indexing
+        # on 200 proposals (profiles/r04_bevfusion_camera_lidar_head_kernel_stats.csv: rocprim partition / index kernels).
+        dev = p["heatmap"].device
+        names = ["heatmap", "rot", "dim", "center", "height"] + (["vel"] if "vel" in p else [])
+        host = self._to_host({k: p[k][..., -P:] for k in names} | {"query_heatmap_score": p["query_heatmap_score"],
+                                                                   "query_labels": self.query_labels})
+        score = host["heatmap"].sigmoid()
+        one_hot = F.one_hot(host["query_labels"], num_classes=self.num_classes).permute(0, 2, 1)
+        score = score * host["query_heatmap_score"] * one_hot
+        temp = self._decode(score, host["rot"], host["dim"], host["center"], host["height"], host.get("vel"))
         if self.test_cfg.get("nms_type") is None:
-            return temp
+            return self._to_device(temp, dev)
         if self.test_cfg["nms_type"] != "circle":
             raise NotImplementedError("only nms_type null / circle are built")
         dataset = self.test_cfg.get("dataset", "nuScenes")
@@ -425,11 +433,46 @@ class TransFusionHead(nn.Module):
                 task_mask = task_mask.bool()
                 if task["radius"] > 0:
                     dets = torch.cat([boxes3d[task_mask][:, :2], scores[:, None][task_mask]], dim=1)
-                    keep = torch.tensor(circle_nms(dets.detach().cpu().numpy(), task["radius"]), dtype=torch.long)
+                    keep = torch.tensor(circle_nms(dets.detach().numpy(), task["radius"]), dtype=torch.long)
                 else:
                     keep = torch.arange(int(task_mask.sum()))
                 if keep.shape[0] != 0:
-                    keep_mask[torch.where(task_mask != 0)[0][keep.to(scores.device)]] = 1
+                    keep_mask[torch.where(task_mask != 0)[0][keep]] = 1
             keep_mask = keep_mask.bool()
             rets.append(dict(bboxes=boxes3d[keep_mask], scores=scores[keep_mask], labels=labels[keep_mask]))
-        return rets
+        return self._to_device(rets, dev)
+
+    def _to_host(self, tensors):
+        """{name: device tensor} -> {name: CPU tensor}: asynchronous copies into cached pinned buffers, ONE synchronisation."""
+        if not next(iter(tensors.values())).is_cuda:
+            return {k: v.detach() for k, v in tensors.items()}
+        cache = self.__dict__.setdefault("_pinned", {})
+        out = {}
+        for k, v in tensors.items():
+            v = v.detach()
+            if not v.is_contiguous():
+                v = v.contiguous()                               # only when the decoder has several layers (a slice of P)
+            buf = cache.get(k)
+            if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
+                buf = cache[k] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+            buf.copy_(v, non_blocking=True)
+            out[k] = buf
+        torch.cuda.current_stream(next(iter(tensors.values())).device).synchronize()
+        return {k: v.clone() for k, v in out.items()}            # the pinned buffers are reused by the next batch
+
+    @staticmethod
+    def _to_device(rets, dev):
+        """Per-sample dicts of CPU tensors -> the same dicts on ``dev`` through two uploads (floats, labels)."""
+        if torch.device(dev).type != "cuda" or not rets:
+            return rets
+        counts = [int(r["scores"].shape[0]) for r in rets]
+        width, total = rets[0]["bboxes"].shape[1], sum(counts)
+        # one float buffer [all boxes | all scores] (both halves contiguous per sample), one label buffer
+        fl = torch.cat([r["bboxes"].reshape(-1) for r in rets] + [r["scores"] for r in rets]).to(dev)
+        lb = torch.cat([r["labels"] for r in rets]).to(dev)
+        boxes, scores = fl[:total * width].view(total, width), fl[total * width:]
+        out, a = [], 0
+        for c in counts:
+            out.append(dict(bboxes=boxes[a:a + c], scores=scores[a:a + c], labels=lb[a:a + c]))
+            a += c
+        return out

@@ -582,6 +582,11 @@ int al3d_lss_upsample_cat_f32(const float* lat, const float* src, int N, int H, 
  * positions max(0, (o + 0.5) in / out - 0.5). */
 int al3d_lss_upsample_cat_mode_f32(const float* lat, const float* src, int N, int H, int W, int C1, int h, int w, int C2,
                                    int align_corners, float* out, void* stream);
+/* Channel concatenation of two channels-last maps, out [N][H][W][Ca + Cb] = cat(a, b) (vtransforms/depth_lss.py:84 before the
+ * depth net, fusers/conv.py:24 before the fuser); a_hw_swapped: a is stored [N][W][H][Ca] (the view transform's [x, y] map)
+ * and is transposed on the way.  Ca, Cb % 4 == 0. */
+int al3d_cat2_nhwc_f32(const float* a, const float* b, int N, int H, int W, int Ca, int Cb, int a_hw_swapped, float* out,
+                       void* stream);
 /* depth_lss.py:38-44, the first two layers of `dtransform` as one kernel: Conv2d(1, 8, 1) + BN + ReLU -> Conv2d(8, 32, 5,
  * stride 4, padding 2) + BN + ReLU on the depth image [BN][iH][iW] -> out [BN][oH][oW][32] (channels-last, oH =
  * (iH - 1) / 4 + 1).  p0 = [w0[8] | scale0[8] | shift0[8]] with layer 0 = relu((w0 d) scale0 + shift0) (bias and BN folded:

@@ -185,6 +185,20 @@ def test_fused_dtransform_head_matches_float64(size):
     assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("swapped", [False, True])
+def test_cat2_kernel_equals_torch_cat(swapped):
+    """``al3d_cat2_nhwc_f32``: the channel concatenation in front of the depth net and of the fuser (depth_lss.py:84,
+    fusers/conv.py:24) as one kernel, bit for bit == ``torch.cat`` -- with the camera map's [x, y] -> [y, x] transposition
+    riding on the copy."""
+    from al3d.models.bevfusion_camera import cat2_nhwc
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Ca, Cb = 2, 9, 14, 80, 256
+    a = torch.randn(N, W, H, Ca, generator=g).to(DEV) if swapped else torch.randn(N, H, W, Ca, generator=g).to(DEV)
+    b = torch.randn(N, H, W, Cb, generator=g).to(DEV)
+    want = torch.cat([a.permute(0, 2, 1, 3) if swapped else a, b], dim=-1)
+    assert torch.equal(cat2_nhwc(a, b, swapped), want)
+
+
 @pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("shape", [((2, 32, 88, 192), (16, 44, 384)), ((1, 7, 5, 8), (3, 2, 12)), ((1, 4, 4, 4), (1, 1, 4))])
 def test_upsample_cat_kernel_matches_torch(shape, align):
