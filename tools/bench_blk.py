@@ -17,7 +17,7 @@ modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["off", "on"]
 anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
 pool = PoolFrames.from_synthetic(bs, dev, num_base=8)
 ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=bs, device=dev)))
-saved = set(D.BLK_PAIRS)
+saved = set(D.BLK_PAIRS) or set(D.BLK_BUILT)        # "on" = every built pair unless AL3D_BLK_PAIRS names some
 res = {}
 for mode in modes:
     D.BLK_PAIRS = set() if mode == "off" else saved
