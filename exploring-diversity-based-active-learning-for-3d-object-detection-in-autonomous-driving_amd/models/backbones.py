@@ -364,6 +364,9 @@ class _SparseEncoderBase(nn.Module):
         for step, b in zip(self._plan, book["steps"]):
             if step["kind"] == "stage_end":
                 middle.append(SparseTensor(feats, b["coords"], b["shape"], batch_size, pair_rows=pair))
+                hook = getattr(self, "stage_hook", None)        # the sweep's pipeline: "stage k of the encoder is enqueued"
+                if hook is not None:
+                    hook(len(middle) - 1)
                 continue
             m = step["mod"]
             if perm is not None or feats.shape[-1] != self._pad_cin(m):

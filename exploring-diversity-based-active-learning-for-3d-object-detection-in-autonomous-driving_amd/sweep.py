@@ -84,6 +84,9 @@ _SIDE = {}
 # that suffer most from it).  +1.3 % frames/s at the round-3 kernels, but the contention then lands on the dense launches
 # (1,559 -> 1,774 us each), i.e. on the kernel whose live roofline the bench line reports: default off
 SIDE_AFTER_SPARSE = _os.environ.get("AL3D_SIDE_AFTER_SPARSE", "0") == "1"
+# AL3D_SIDE_AFTER_STAGE=k (round 5, dev knob): the side stream's work for batch i+1 is released when stage k of batch i's
+# sparse encoder (0 = the input level's six layers) has been executed -- between "at once" (default) and AFTER_SPARSE
+SIDE_AFTER_STAGE = int(_os.environ.get("AL3D_SIDE_AFTER_STAGE", "-1"))
 
 
 # AL3D_NMS_AFTER_SPARSE=1: batch i's decode + NMS launch is held back until batch i+1's sparse encoder is through
@@ -231,7 +234,19 @@ def sweep_embeddings(detector, dataloader, device, num_frames=None, with_entropy
                               nms_head.flush_deferred(sparse_done)
                           preds, middle = detector.dense_stage(example, x, middle, estimate=True)
                       elif mode == "ahead":
-                          preds, middle = detector(example, return_loss=False, estimate=True, book=ahead)
+                          bb = getattr(detector, "backbone", None)
+                          if SIDE_AFTER_STAGE >= 0 and bb is not None:
+                              def _hook(k, _side=side, _main=main):
+                                  if k == SIDE_AFTER_STAGE:
+                                      e_ = torch.cuda.Event()
+                                      e_.record(_main)
+                                      _side.wait_event(e_)
+                              bb.stage_hook = _hook
+                          try:
+                              preds, middle = detector(example, return_loss=False, estimate=True, book=ahead)
+                          finally:
+                              if bb is not None and SIDE_AFTER_STAGE >= 0:
+                                  bb.stage_hook = None
                       else:
                           x, middle = ahead
                           preds, middle = detector.dense_stage(example, x, middle, estimate=True)
