@@ -10,8 +10,12 @@ mode: ``lidar_aug_matrix`` = I) -> ``ImageNormalize`` (transforms_3d.py:903-920)
 ``NuScenesDataset.get_data_info`` (nuscenes_dataset.py:233-275).
 
 Here: the lidar side streams through the native reader pool and ``al3d_merge_sweeps_batch_rule_f32`` (rule 1: BEVFusion's
-two-step float64 -> float32 transform); the camera frames are decoded on host threads (PIL, imported lazily: the only
-decoder the image has), uploaded as 8-bit RGB and resized / cropped / normalised by ``al3d_image_aug_normalize_u8``
+two-step float64 -> float32 transform).  Camera frames (round 5): a baseline JPEG is SPLIT -- its Huffman entropy decoding
+runs on host threads (``al3d_jpeg_entropy_decode``, straight into a pinned buffer), the quantised coefficients are uploaded
+and the device does the inverse DCT, chroma upsampling and colour conversion (``al3d_jpeg_idct_rgb_u8``: the bytes Pillow's
+decoder gives, tests/test_jpeg_gpu.py); any other file (PNG, progressive JPEG, ...) and any batch that mixes geometries is
+decoded by Pillow on the same threads (imported lazily) and uploaded as 8-bit RGB.  Either way the frames are then resized /
+cropped / normalised by ``al3d_image_aug_normalize_u8``
 (PIL's bicubic resize restated as an integer kernel: the same bytes as ``Image.resize``) into the channels-last float32
 layout the token kernels read.  Sweep order = list order (the reference draws a random subset of nine when a sample lists
 more and test_mode is unset: not reproducible, like det3d's loader).
@@ -115,6 +119,29 @@ def _decode_rgb(path):
         return np.asarray(im.convert("RGB"))
 
 
+def jpeg_header(data):
+    """(info [32] int32, quant [3, 64] uint16) of a baseline JPEG in memory, or None when the split decoder does not take it."""
+    info = np.zeros(32, np.int32)
+    quant = np.zeros((3, 64), np.uint16)
+    rc = lib.load().al3d_jpeg_header(data.ctypes.data_as(ctypes.c_void_p), int(data.size), info.ctypes.data_as(ctypes.c_void_p),
+                                     quant.ctypes.data_as(ctypes.c_void_p))
+    return (info, quant) if rc == 0 else None
+
+
+def _decode_jpeg_into(path, want_info, coef_ptr, coef_blocks, quant_out):
+    """Worker-thread job: entropy-decode one camera frame into its slice of the batch's pinned coefficient buffer.
+    Returns True, or the decoded RGB array (Pillow) when the file is not a baseline JPEG of the batch's geometry."""
+    data = np.fromfile(path, dtype=np.uint8)
+    hdr = jpeg_header(data) if data.size > 4 and data[0] == 0xff and data[1] == 0xd8 else None
+    if hdr is not None and np.array_equal(hdr[0][:24], want_info[:24]):
+        rc = lib.load().al3d_jpeg_entropy_decode(data.ctypes.data_as(ctypes.c_void_p), int(data.size), ctypes.c_void_p(coef_ptr),
+                                                 int(coef_blocks))
+        if rc == 0:
+            quant_out[:] = hdr[1]
+            return True
+    return _decode_rgb(path)
+
+
 class CameraLidarFileLoader(FileSweepLoader):
     """Batches of BEVFusion ``example`` dicts (``al3d.models.bevfusion_model.CAMERA_KEYS`` + the lidar keys) from an
     mmdet3d-format pool: ``infos[i]`` carries ``lidar_path``, ``timestamp``, ``sweeps[k]{data_path, timestamp,
@@ -126,7 +153,7 @@ class CameraLidarFileLoader(FileSweepLoader):
     def __init__(self, infos, voxel_cfg, anchors, batch_size=4, device="cuda", sweeps_num=9, root=None, threads=8,
                  indices=None, depth=2, min_distance=1.0, image_size=(256, 704), resize_lim=(0.48, 0.48),
                  bot_pct_lim=(0.0, 0.0), mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), decode_threads=None,
-                 pad_empty_sweeps=True, point_cloud_range="voxel"):
+                 pad_empty_sweeps=True, point_cloud_range="voxel", jpeg="split"):
         super().__init__(infos, voxel_cfg, anchors, batch_size=batch_size, device=device, nsweeps=sweeps_num + 1, root=root,
                          threads=threads, indices=indices, depth=depth, min_distance=min_distance)
         self.sweeps_num, self.pad_empty_sweeps = int(sweeps_num), bool(pad_empty_sweeps)
@@ -143,6 +170,13 @@ class CameraLidarFileLoader(FileSweepLoader):
         self._pool = ThreadPoolExecutor(max_workers=int(decode_threads or max(2, usable_cores() - 2)))
         self._img_pinned = {}
         self.images_decoded = 0
+        # jpeg = "split": baseline JPEGs are entropy-decoded on the host and finished on the device; "pil": everything by Pillow
+        if jpeg not in ("split", "pil"):
+            raise lib.Al3dError("CameraLidarFileLoader: jpeg = 'split' or 'pil'")
+        self.jpeg = jpeg
+        self._jpeg_info = None                               # geometry of the pool's frames (from the first one that parses)
+        self._coef_pinned = {}
+        self.images_split = 0
 
     # ---- lidar side: LoadPointsFromFile + LoadPointsFromMultiSweeps (test branch)
     def _frame_files(self, info):
@@ -168,47 +202,101 @@ class CameraLidarFileLoader(FileSweepLoader):
     def _start(self, b):
         st = super()._start(b)
         ids = self.indices[b * self.batch_size:(b + 1) * self.batch_size]
-        jobs = []
-        for i in ids:
-            cams = self.infos[i]["cams"]
-            jobs.append([self._pool.submit(_decode_rgb, self._path(c["data_path"])) for c in cams.values()])
-        st.extra = jobs                                      # on the staged batch itself (not keyed by id())
+        paths = [[self._path(c["data_path"]) for c in self.infos[i]["cams"].values()] for i in ids]
+        nimg = sum(len(p) for p in paths)
+        info = None
+        if self.jpeg == "split" and nimg:
+            if self._jpeg_info is None:
+                first = paths[0][0]
+                if first.lower().endswith((".jpg", ".jpeg")):
+                    hdr = jpeg_header(np.fromfile(first, dtype=np.uint8))
+                    self._jpeg_info = hdr[0] if hdr is not None else False
+                else:
+                    self._jpeg_info = False
+            info = self._jpeg_info if self._jpeg_info is not False else None
+        if info is None:
+            st.extra = dict(mode="pil", jobs=[[self._pool.submit(_decode_rgb, p) for p in cams] for cams in paths])
+            return st
+        # split path: every job writes its coefficients into its slice of the slot's pinned buffer (free: the parent has
+        # just waited for the slot's previous upload, and ours is recorded on the same slot below)
+        nb = int(info[20])
+        held = self._coef_pinned.get(st.slot)
+        if held is not None and held[2] is not None:
+            held[2].synchronize()
+        if held is None or held[0].shape[0] < nimg or held[0].shape[1] != nb:
+            held = [torch.empty((nimg, nb, 64), dtype=torch.int16).pin_memory(),
+                    torch.empty((nimg, 3, 64), dtype=torch.int16).pin_memory(), None]
+            self._coef_pinned[st.slot] = held
+        coefs, quant = held[0], held[1]
+        qv = quant.numpy().view(np.uint16)
+        jobs, k = [], 0
+        for cams in paths:
+            row = []
+            for pth in cams:
+                row.append(self._pool.submit(_decode_jpeg_into, pth, info, coefs[k].data_ptr(), nb, qv[k]))
+                k += 1
+            jobs.append(row)
+        st.extra = dict(mode="split", jobs=jobs, info=info, nimg=nimg)
         return st
 
     def _abandon(self, st):
         """Iteration ended before this batch was finished: cancel the decode jobs that have not started, drop the rest."""
-        for cam_jobs in getattr(st, "extra", None) or []:
+        for cam_jobs in (getattr(st, "extra", None) or {}).get("jobs", []):
             for f in cam_jobs:
                 f.cancel()
         st.extra = None
 
     def _finish(self, st):
         ex = super()._finish(st)
-        jobs, st.extra = st.extra, None
-        frames = [[f.result() for f in cam_jobs] for cam_jobs in jobs]
-        B, N = len(frames), len(frames[0])
-        if any(len(fr) != N for fr in frames):
+        extra, st.extra = st.extra, None
+        jobs = extra["jobs"]
+        results = [[f.result() for f in cam_jobs] for cam_jobs in jobs]
+        B, N = len(results), len(results[0])
+        if any(len(fr) != N for fr in results):
             raise lib.Al3dError("CameraLidarFileLoader: every sample of a batch must list the same number of cameras")
-        H, W = frames[0][0].shape[:2]
-        # pinned staging, one buffer per in-flight slot of the parent's ring (refilled only after its upload has left)
-        need = B * N * H * W * 3
-        held = self._img_pinned.get(st.slot)
-        if held is not None and held[1] is not None:
-            held[1].synchronize()
-        if held is None or held[0].numel() < need:
-            held = [torch.empty(need, dtype=torch.uint8).pin_memory(), None]
-            self._img_pinned[st.slot] = held
-        host = held[0][:need].view(B * N, H, W, 3)
-        hv = host.numpy()
-        for bi, fr in enumerate(frames):
-            for ci, a in enumerate(fr):
-                if a.shape != (H, W, 3):
-                    raise lib.Al3dError(f"CameraLidarFileLoader: camera frames of one batch differ in size ({a.shape} vs {(H, W, 3)})")
-                hv[bi * N + ci] = a
+        split = extra["mode"] == "split" and all(r is True for fr in results for r in fr)
+        if split:
+            # coefficients -> device -> RGB bytes (al3d_jpeg_idct_rgb_u8: what Pillow's decoder gives)
+            from ..selector_ops import _ptr, _stream
+            info, nimg = extra["info"], extra["nimg"]
+            W, H = int(info[0]), int(info[1])
+            held = self._coef_pinned[st.slot]
+            dcoef = held[0][:nimg].to(self.device, non_blocking=True)
+            dquant = held[1][:nimg].to(self.device, non_blocking=True)
+            held[2] = torch.cuda.Event()
+            held[2].record(torch.cuda.current_stream(self.device))
+            L = lib.load()
+            ws = torch.empty(max(int(L.al3d_jpeg_workspace_bytes(info.ctypes.data_as(ctypes.c_void_p), nimg)), 16),
+                             dtype=torch.uint8, device=self.device)
+            dev_u8 = torch.empty((nimg, H, W, 3), dtype=torch.uint8, device=self.device)
+            lib.call("al3d_jpeg_idct_rgb_u8", _ptr(dcoef), _ptr(dquant), info.ctypes.data_as(ctypes.c_void_p), nimg, _ptr(dev_u8),
+                     _ptr(ws), _stream())
+            self.images_split += nimg
+        else:
+            # Pillow's pixels (a batch with any frame the split decoder did not take is finished by Pillow as a whole)
+            frames = []
+            for fr, cams in zip(results, [list(self.infos[i]["cams"].values()) for i in st.ids]):
+                frames.append([a if a is not True else _decode_rgb(self._path(c["data_path"])) for a, c in zip(fr, cams)])
+            H, W = frames[0][0].shape[:2]
+            # pinned staging, one buffer per in-flight slot of the parent's ring (refilled only after its upload has left)
+            need = B * N * H * W * 3
+            held = self._img_pinned.get(st.slot)
+            if held is not None and held[1] is not None:
+                held[1].synchronize()
+            if held is None or held[0].numel() < need:
+                held = [torch.empty(need, dtype=torch.uint8).pin_memory(), None]
+                self._img_pinned[st.slot] = held
+            host = held[0][:need].view(B * N, H, W, 3)
+            hv = host.numpy()
+            for bi, fr in enumerate(frames):
+                for ci, a in enumerate(fr):
+                    if a.shape != (H, W, 3):
+                        raise lib.Al3dError(f"CameraLidarFileLoader: camera frames of one batch differ in size ({a.shape} vs {(H, W, 3)})")
+                    hv[bi * N + ci] = a
+            dev_u8 = host.to(self.device, non_blocking=True)
+            held[1] = torch.cuda.Event()
+            held[1].record(torch.cuda.current_stream(self.device))
         self.images_decoded += B * N
-        dev_u8 = host.to(self.device, non_blocking=True)
-        held[1] = torch.cuda.Event()
-        held[1].record(torch.cuda.current_stream(self.device))
         aug = self._aug.get((W, H))
         if aug is None:
             rl, bp, mean, std = self._aug_cfg

@@ -145,6 +145,10 @@ SIGNATURES = {
     "al3d_lss_geometry_f32": (c_int, [c_p, c_i64, c_p, c_int, c_p, c_p, c_p]),
     "al3d_lss_depth_softmax_f32": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_lss_upsample_cat_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
+    "al3d_jpeg_header": (c_int, [c_p, c_i64, c_p, c_p]),
+    "al3d_jpeg_entropy_decode": (c_int, [c_p, c_i64, c_p, c_i64]),
+    "al3d_jpeg_workspace_bytes": (c_i64, [c_p, c_int]),
+    "al3d_jpeg_idct_rgb_u8": (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p]),
     "al3d_cat2_nhwc_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_lss_upsample_cat_mode_f32": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
     "al3d_lss_dtransform01_f32": (c_int, [c_p, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p]),

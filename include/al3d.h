@@ -654,6 +654,26 @@ int al3d_merge_sweeps_batch_range_f32(const float* raw, const int64_t* file_off,
                                       float min_distance, int rule, const float* point_range, float* out,
                                       int64_t* out_frame_off, void* workspace, void* stream);
 
+/* Split JPEG decoding for configs[4] from files (csrc/jpeg_host.cpp + csrc/jpeg.hip).  The reference decodes every camera
+ * frame with Pillow's Image.open in DataLoader workers (bevfusion/mmdet3d/datasets/pipelines/loading.py:19-58), i.e. with
+ * libjpeg-turbo at its defaults; here the Huffman entropy decoding stays on host threads and everything after it runs on the
+ * device, bit-identical to Pillow's RGB bytes (accurate integer IDCT, fancy chroma upsampling, 16-bit fixed-point YCbCr -> RGB).
+ *   al3d_jpeg_header: HOST.  Parse the markers of a baseline JPEG in memory -> info [AL3D_JPEG_INFO_INTS] = {width, height,
+ *     ncomp, h[3], v[3], mcus_x, mcus_y, blocks_w[3], blocks_h[3], block_offset[3], total_blocks, restart_interval, max_h,
+ *     max_v, 0...} and quant [3][64] uint16 (natural order, per component).  AL3D_EINVAL (with the reason in
+ *     al3d_last_error) for anything but 8-bit baseline Huffman, one interleaved scan, 1 or 3 components, sampling factors 1 / 2
+ *     with the luma at the maximum: the caller then uses another decoder for that file.
+ *   al3d_jpeg_entropy_decode: HOST, thread-safe.  -> coefs [total_blocks][64] int16: quantised coefficients in natural order,
+ *     component after component, each a plane of blocks_h x blocks_w blocks (whole MCUs).
+ *   al3d_jpeg_idct_rgb_u8: DEVICE.  nimg images of ONE geometry (info; coefs [nimg][total_blocks][64], quant [nimg][3][64])
+ *     -> out_rgb [nimg][height][width][3] uint8; workspace >= al3d_jpeg_workspace_bytes(info, nimg) (the component planes). */
+#define AL3D_JPEG_INFO_INTS 32
+int al3d_jpeg_header(const unsigned char* data, int64_t nbytes, int* info, unsigned short* quant);
+int al3d_jpeg_entropy_decode(const unsigned char* data, int64_t nbytes, short* coefs, int64_t coef_blocks);
+int64_t al3d_jpeg_workspace_bytes(const int* info, int nimg);
+int al3d_jpeg_idct_rgb_u8(const short* coefs, const unsigned short* quant, const int* info, int nimg,
+                          unsigned char* out_rgb, void* workspace, void* stream);
+
 /* TransFusion query initialisation (csrc/proposals.hip; bevfusion/mmdet3d/models/heads/bbox/transfusion.py:236-275):
  * heat_logits [B][H][W][C] channels-last (the heat-map head's output) -> the P best (class, cell) pairs among the k x k
  * local maxima of sigmoid(heat) (interior cells only; classes of free_class_mask keep every cell), ties broken by the
