@@ -438,8 +438,9 @@ def bevfusion_lidar_leg(dev, frames=96, batch=32):
 
 def bevfusion_camera_lidar_from_files(cfg, model, frames, batch, dev):
     """The same sweep fed from an mmdet3d-format pool on tmpfs (tools/write_synthetic_pool.py --cameras: ten .bin files and
-    six 1600 x 900 JPEGs per sample): reader pool + BEVFusion merge rule + voxelizer for the lidar side, host-thread JPEG
-    decode + device resize / crop / normalise (PIL's bicubic as an integer kernel) for the cameras."""
+    six 1600 x 900 JPEGs per sample): reader pool + BEVFusion merge rule + range filter + voxelizer for the lidar side; split
+    JPEG decoding (entropy decoding on host threads, the rest on the device) + device resize / crop / normalise (PIL's bicubic
+    as an integer kernel) for the cameras."""
     import shutil
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from write_synthetic_pool import write_camera_lidar_pool
@@ -462,8 +463,10 @@ def bevfusion_camera_lidar_from_files(cfg, model, frames, batch, dev):
         dt = time.perf_counter() - t0
         return {"frames_per_s": round(len(infos) / dt, 2), "frames": len(infos), "images_per_s": round(loader.images_decoded / dt, 1),
                 "decode_threads": loader._pool._max_workers, "finite": bool(torch.isfinite(emb).all()),
-                "what": "sweep only; per sample 10 lidar .bin files + 6 JPEG frames of 1600 x 900 on tmpfs; JPEG decoding "
-                        "(PIL, host threads) bounds it: the device side of the image path is two small kernels"}
+                "images_split_decoded": int(getattr(loader, "images_split", 0)),
+                "what": "sweep only; per sample 10 lidar .bin files + 6 JPEG frames of 1600 x 900 on tmpfs; split JPEG "
+                        "decoding: Huffman entropy decoding on host threads, IDCT / upsampling / colour conversion on the "
+                        "device (byte-identical to Pillow; 113 frames/s with Pillow decoding everything in round 4)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
