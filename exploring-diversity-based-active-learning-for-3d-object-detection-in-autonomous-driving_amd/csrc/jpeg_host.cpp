@@ -6,8 +6,8 @@
 // (bevfusion/mmdet3d/datasets/pipelines/loading.py:19-58), i.e. with libjpeg-turbo at its defaults: the accurate integer
 // inverse DCT (jidctint.c), "fancy" (triangle) chroma upsampling (jdsample.c) and the 16-bit fixed-point YCbCr -> RGB tables
 // (jdcolor.c).  The two halves here restate those published algorithms (libjpeg-turbo is a dependency of Pillow, not part
-// of /root/reference) and are held to the installed Pillow's bytes: tests/test_jpeg_host.py (CPU: this decoder + the numpy
-// restatement in oracle/jpeg_oracle.py == PIL), tests/test_jpeg_gpu.py (device == PIL).
+// of /root/reference) and are held to the installed Pillow's bytes: tests/test_jpeg_host.py (CPU: this decoder + a numpy
+// restatement of the device half == PIL), tests/test_jpeg_gpu.py (device == PIL).
 //
 // Scope: 8-bit baseline (SOF0) Huffman, one interleaved scan, 1 or 3 components (YCbCr / grayscale), sampling factors 1 or
 // 2 with the luma at the maximum, restart intervals.  Anything else (progressive, arithmetic, 12-bit, CMYK, RGB component
