@@ -507,13 +507,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_halo_kernel(ConvF3Params
 // previous chunk -- and one after its last store), and the four waves drift freely in between.
 // LDS traffic per step and CU: 83 KB -> 35 KB; L2 -> CU traffic doubles (both M-waves of a block
 // load the same weights: 32 KB per step and CU, ~40 % of the vector L1's 64 B/clk).
-template <int IO = 0>
+// SHAPE 1 (round 5): a wave owns all FOUR image rows of the tile x ONE 32-channel tile instead of two rows x two tiles, so
+// every weight fragment is loaded by exactly one wave of the workgroup (half the L2 -> CU weight traffic: 11.5 instead of
+// 23 TB/s chip-wide on the 256 -> 256 layers) at twice the LDS fragment reads; same MFMA sequence per accumulator.
+template <int IO = 0, int SHAPE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params p)
 {
+    constexpr int NI = SHAPE ? 4 : 2, NJ = SHAPE ? 1 : 2;      // M tiles (image rows) x N tiles (32 channels) per wave
     __shared__ __attribute__((aligned(16))) unsigned char Ah[2][2][G3_HP * F3_LDB];      // [chunk parity][plane] 39.2 KB
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = SHAPE ? 0 : (wave & 1), wn = wave >> 1;
+    const int row0 = SHAPE ? 0 : 2 * wm, ch0 = SHAPE ? wave * 32 : wn * 64;      // the wave's first image row / channel in the tile
     const int fr = lane & 31, fh = lane >> 5;
     int tile, nblk;
     if (!f3_tile_of_block(p, tile, nblk)) return;     // padding block of the last group (uniform)
@@ -554,20 +559,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
 
     // ---- this wave's weight stream: [plane][ntile][step][lane][8]; ntile = 32 output channels
     const int NT = p.Cout >> 5;
-    const int nt0 = (n0 >> 5) + wn * 2;
-    const _Float16* bsrc[2][2];                       // [plane][tile]
+    const int nt0 = (n0 + ch0) >> 5;
+    const _Float16* bsrc[2][NJ];                      // [plane][tile]
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
             bsrc[pl][j] = p.wgt + ((int64_t)(pl * NT + nt0 + j) * total) * 512 + lane * 8;
-    f16x8 fb0[2][2], fb1[2][2], fb2[2][2];            // ring of three register sets [plane][tile]
+    f16x8 fb0[2][NJ], fb1[2][NJ], fb2[2][NJ];         // ring of three register sets [plane][tile]
     auto load_b = [&](auto ring_, int sidx) {
         constexpr int ring = decltype(ring_)::value;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const f16x8 v = *reinterpret_cast<const f16x8*>(bsrc[pl][j] + (int64_t)sidx * 512);
                 if constexpr (ring == 0) fb0[pl][j] = v;
                 else if constexpr (ring == 1) fb1[pl][j] = v;
@@ -575,40 +580,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
             }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_off = ((2 * wm) * G3_HW + fr) * F3_LDB + 16 * fh;
-    f16x8 fa[2][2][2];                                // [set][plane][tile]
+    const int a_off = (row0 * G3_HW + fr) * F3_LDB + 16 * fh;
+    f16x8 fa[2][2][NI];                               // [set][plane][tile]
     auto read_a = [&](int set, int pl, int hbuf, int tap) {
         const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NI; ++t)
             fa[set][pl][t] = *reinterpret_cast<const f16x8*>(
                 &Ah[hbuf][pl][a_off + ((t + ky) * G3_HW + kx) * F3_LDB]);
     };
-    auto mfma_step = [&](int set, const f16x8 (&fb)[2][2], auto&& between0, auto&& between1) {
-        f16x8 wd[2];
+    auto mfma_step = [&](int set, const f16x8 (&fb)[2][NJ], auto&& between0, auto&& between1) {
+        f16x8 wd[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wd[j] = lift_down(fb[0][j]);
+        for (int j = 0; j < NJ; ++j) wd[j] = lift_down(fb[0][j]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = F3_MFMA(fa[set][1][i], wd[j], acc[i][j]);        // xl' * wd
+            for (int j = 0; j < NJ; ++j) acc[i][j] = F3_MFMA(fa[set][1][i], wd[j], acc[i][j]);       // xl' * wd
         between0();
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = F3_MFMA(fa[set][0][i], fb[1][j], acc[i][j]);     // xh * wl
+            for (int j = 0; j < NJ; ++j) acc[i][j] = F3_MFMA(fa[set][0][i], fb[1][j], acc[i][j]);    // xh * wl
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = F3_MFMA(fa[set][0][i], fb[0][j], acc[i][j]);     // xh * wh
+            for (int j = 0; j < NJ; ++j) acc[i][j] = F3_MFMA(fa[set][0][i], fb[0][j], acc[i][j]);    // xh * wh
         between1();
     };
 
@@ -667,11 +672,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
         float* scr = reinterpret_cast<float*>(&Ah[0][0][0]) + wave * (32 * SP);
         static_assert(4 * 32 * SP * 4 <= (int)sizeof(Ah), "scratch must fit the halo storage");
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int y = ty_ * G3_TH + 2 * wm + i;
+        for (int i = 0; i < NI; ++i) {
+            const int y = ty_ * G3_TH + row0 + i;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + fr;
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + ch0 + j * 32 + fr;
                 const float sc = p.scale[n];
                 const float sh = p.shift ? p.shift[n] : 0.0f;
 #pragma unroll
@@ -683,15 +688,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
+            constexpr int GPP = 4 * NJ;                // 8-channel groups per pixel of the wave's row
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = lane + 64 * q, pl = t >> 3, g = t & 7;
+            for (int q = 0; q < 2 * NJ; ++q) {
+                const int t = lane + 64 * q, pl = t / GPP, g = t % GPP;
                 const int x = tx_ * G3_TW + pl;
                 if (y >= p.OH || x >= p.OW) continue;
                 const float4 a = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8);
                 const float4 b4 = *reinterpret_cast<const float4*>(scr + pl * SP + g * 8 + 4);
                 const float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
-                float* o = p.out + (((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n0 + wn * 64 + g * 8;
+                float* o = p.out + (((int64_t)b * p.OH + y) * p.OW + x) * p.ldc + p.coff + n0 + ch0 + g * 8;
                 if constexpr ((IO & SP_IO_OUT_PAIR) != 0) {
                     uint4 hi, lo;
                     sp_split8(v, hi, lo);
@@ -707,13 +713,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + fr;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + ch0 + j * 32 + fr;
         const float sc = p.scale[n];
         const float sh = p.shift ? p.shift[n] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int y = ty_ * G3_TH + 2 * wm + i;
+        for (int i = 0; i < NI; ++i) {
+            const int y = ty_ * G3_TH + row0 + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int x = tx_ * G3_TW + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -1275,7 +1281,16 @@ static int conv3x3_frag_impl(const float* in, const void* wgt_frag, const float*
     static int direct = -1;                            // AL3D_FRAG_EPI=direct: the untransposed f32 epilogue, for A/B
     if (direct < 0) { const char* e = getenv("AL3D_FRAG_EPI"); direct = e && e[0] == 'd'; }
     const bool vec_ok = ldc % 4 == 0 && coff % 4 == 0 && ((uintptr_t)out & 15) == 0;
-    if (io & SP_IO_OUT_PAIR) hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel<2>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    // wave shape: 1 (default, round 5) = four image rows x ONE 32-channel tile per wave; 0 = round 1's two rows x two tiles
+    // (AL3D_FRAG_SHAPE=0 for A/B).  Same bits; the nine `<0>` launches of the neck 1,670 -> 1,600 us, bench +1.6 % same box
+    static int shape = -1;
+    if (shape < 0) { const char* e = getenv("AL3D_FRAG_SHAPE"); shape = e ? atoi(e) != 0 : 1; }
+    if (shape) {
+        if (io & SP_IO_OUT_PAIR) hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<2, 1>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+        else if (direct || !vec_ok) hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<1, 1>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<0, 1>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    }
+    else if (io & SP_IO_OUT_PAIR) hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel<2>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     else if (direct || !vec_ok) hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel<1>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv3x3_f16x3_frag_kernel<0>, dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     AL3D_CHECK_LAUNCH("conv3x3_f16x3_frag_kernel");
