@@ -142,17 +142,17 @@ class ConvTimer:
         neck_fwd, head_fwd = model.neck.forward, model.bbox_head.forward
         timer = self
 
-        def neck(x):
+        def neck(x, out_pair=False):                   # the detector looks for `out_pair` in this signature (pair pixels to the head)
             if not timer.enabled:
-                return neck_fwd(x)
+                return neck_fwd(x, out_pair=out_pair)
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = neck_fwd(x)
+            y = neck_fwd(x, out_pair=out_pair)
             timer._e0, timer._b = e0, x.shape[0]
             return y
 
-        def head(x, finetune=False):
-            r = head_fwd(x, finetune=finetune)
+        def head(x, finetune=False, **kw):
+            r = head_fwd(x, finetune=finetune, **kw)
             if timer.enabled:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()

@@ -160,7 +160,10 @@ class MultiGroupHead(nn.Module):
     def accepts_pair(self, device):
         """True when the fused head convolution runs on the LDS-DMA kernel and can read pair pixels."""
         self._prepare(device)
-        return D.MATH == "f16x3" and D.DPIX == "pair" and getattr(self._w, "kind", None) == "dma"
+        import os
+        # AL3D_HEAD_PAIR=0 (A/B): the head reads f32 pixels although the neck could hand it pair pixels
+        return D.MATH == "f16x3" and D.DPIX == "pair" and getattr(self._w, "kind", None) == "dma" and \
+            os.environ.get("AL3D_HEAD_PAIR", "1") != "0"
 
     def forward(self, x, finetune=False, in_pair=False):
         """x NHWC [B,H,W,512] -> list of per-task dicts with NHWC views
