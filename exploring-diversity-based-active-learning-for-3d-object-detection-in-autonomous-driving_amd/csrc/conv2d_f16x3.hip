@@ -514,7 +514,10 @@ template <int IO = 0, int SHAPE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params p)
 {
     constexpr int NI = SHAPE ? 4 : 2, NJ = SHAPE ? 1 : 2;      // M tiles (image rows) x N tiles (32 channels) per wave
-    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][2][G3_HP * F3_LDB];      // [chunk parity][plane] 39.2 KB
+    constexpr bool HALO_FAR = SHAPE == 2;
+    constexpr int NHB = 2;                                    // halo buffers (a third one, dropping the tap-1 barrier, measured a tie)
+    static_assert(SHAPE >= 0 && SHAPE <= 2, "wave shapes 0 / 1; 2 = 1 with the far halo prefetch");
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[NHB][2][G3_HP * F3_LDB];    // [chunk % NHB][plane] 39.2 KB (58.8)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = SHAPE ? 0 : (wave & 1), wn = wave >> 1;
@@ -531,7 +534,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
     const int total = 9 * nchunks;
     const float* zero = reinterpret_cast<const float*>(&g_f3_zero16);
 
-    float4 rh[2];                                    // the halo travels in two halves (8 VGPRs, not 16)
+    // the next chunk's halo travels in two halves; HALO_FAR (round 5): each half has its own registers and waits FOUR steps
+    // between its request and its store (two before: a step apart is ~1.5k cycles of wall time at two waves per SIMD, less than
+    // an HBM round trip under load, and vmcnt retires in order, so the wait also held the weight stream back)
+    float4 rh[HALO_FAR ? 4 : 2];
     auto load_halo = [&](int chunk, int half) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
             const int iy = y0 + hp / G3_HW, ix = x0 + hp % G3_HW;
             const bool ok = hp < G3_HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const float* src = p.in + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + chunk * F3_BK + 4 * q;
-            rh[k] = *reinterpret_cast<const float4*>(ok ? src : zero);
+            rh[(HALO_FAR ? 2 * half : 0) + k] = *reinterpret_cast<const float4*>(ok ? src : zero);
         }
     };
     auto store_halo = [&](int buf, int half) {
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
             const int hp = piece >> 2, q = piece & 3;
             if (hp >= G3_HP) continue;
             f16x4 h, l;
-            split_act4(rh[k], h, l);
+            split_act4(rh[(HALO_FAR ? 2 * half : 0) + k], h, l);
             const int off = hp * F3_LDB + 8 * q;
             *reinterpret_cast<f16x4*>(&Ah[buf][0][off]) = h;
             *reinterpret_cast<f16x4*>(&Ah[buf][1][off]) = l;
@@ -629,32 +635,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_frag_kernel(ConvF3Params
     read_a(0, 1, 0, 0);
     read_a(0, 0, 0, 0);
 
-    auto step = [&](auto cp_, auto tap_, int chunk, int cn) {
+    auto step = [&](auto cp_, auto tap_, int chunk, int cn, int hb, int hbn) {
         constexpr int cp = decltype(cp_)::value, tap = decltype(tap_)::value;
         constexpr int q = (cp + tap) & 1;             // A fragment set of this step
         constexpr int ring = (cp * 9 + tap) % 3;      // B register set of this step (18 % 3 == 0)
         const int s2 = chunk * 9 + tap + 2;           // B(s+2) -> the set used at step s-1
         load_b(F3_IC((ring + 2) % 3), s2 < total ? s2 : total - 1);
-        if (tap == 0) load_halo(cn, 0);               // next chunk's halo, first half: stored at tap 2
-        if (tap == 3) load_halo(cn, 1);               // second half: stored at tap 5, first read at tap 8
+        if (tap == 0) load_halo(cn, 0);               // next chunk's halo, first half: stored at tap 2 (HALO_FAR: 4)
+        if (tap == (HALO_FAR ? 1 : 3)) load_halo(cn, 1);     // second half: stored at tap 5, first read at tap 8
         __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top of the step
-        constexpr int nh = tap < 8 ? cp : cp ^ 1, nt = tap < 8 ? tap + 1 : 0;
+        constexpr int nt = tap < 8 ? tap + 1 : 0;
+        const int nh = tap < 8 ? hb : hbn;
         auto b0 = [&]() { read_a(q ^ 1, 1, nh, nt); };
         auto b1 = [&]() { read_a(q ^ 1, 0, nh, nt); };
         if constexpr (ring == 0) mfma_step(q, fb0, b0, b1);
         else if constexpr (ring == 1) mfma_step(q, fb1, b0, b1);
         else mfma_step(q, fb2, b0, b1);
-        if (tap == 2) store_halo(cp ^ 1, 0);
-        if (tap == 5) store_halo(cp ^ 1, 1);
+        if (tap == (HALO_FAR ? 4 : 2)) store_halo(hbn, 0);
+        if (tap == 5) store_halo(hbn, 1);
         // tap 1: every wave is past the previous chunk's tap 7, the last reader of halo buffer cp^1,
         // before anyone overwrites it at tap 2; tap 6: both halves stored before the reads of tap 8
-        if (tap == 1 || tap == 6) __syncthreads();
+        // (three halo buffers: the one being filled was last read two chunks ago, and the tap-6 barrier bounds the drift
+        // of the waves to less than a chunk: the tap-1 barrier is not needed)
+        if ((tap == 1 && NHB == 2) || tap == 6) __syncthreads();
     };
     auto chunk_body = [&](auto cp_, int chunk) {
         const int cn = chunk < last ? chunk + 1 : chunk;         // clamped: the last chunk re-reads itself
-        step(cp_, F3_IC(0), chunk, cn); step(cp_, F3_IC(1), chunk, cn); step(cp_, F3_IC(2), chunk, cn);
-        step(cp_, F3_IC(3), chunk, cn); step(cp_, F3_IC(4), chunk, cn); step(cp_, F3_IC(5), chunk, cn);
-        step(cp_, F3_IC(6), chunk, cn); step(cp_, F3_IC(7), chunk, cn); step(cp_, F3_IC(8), chunk, cn);
+        const int hb = chunk % NHB, hbn = (chunk + 1) % NHB;
+        step(cp_, F3_IC(0), chunk, cn, hb, hbn); step(cp_, F3_IC(1), chunk, cn, hb, hbn); step(cp_, F3_IC(2), chunk, cn, hb, hbn);
+        step(cp_, F3_IC(3), chunk, cn, hb, hbn); step(cp_, F3_IC(4), chunk, cn, hb, hbn); step(cp_, F3_IC(5), chunk, cn, hb, hbn);
+        step(cp_, F3_IC(6), chunk, cn, hb, hbn); step(cp_, F3_IC(7), chunk, cn, hb, hbn); step(cp_, F3_IC(8), chunk, cn, hb, hbn);
     };
     for (int chunk0 = 0; chunk0 < nchunks; chunk0 += 2) {       // nchunks is even (checked by the launcher)
         chunk_body(F3_IC(0), chunk0);
@@ -1281,11 +1291,18 @@ static int conv3x3_frag_impl(const float* in, const void* wgt_frag, const float*
     static int direct = -1;                            // AL3D_FRAG_EPI=direct: the untransposed f32 epilogue, for A/B
     if (direct < 0) { const char* e = getenv("AL3D_FRAG_EPI"); direct = e && e[0] == 'd'; }
     const bool vec_ok = ldc % 4 == 0 && coff % 4 == 0 && ((uintptr_t)out & 15) == 0;
-    // wave shape: 1 (default, round 5) = four image rows x ONE 32-channel tile per wave; 0 = round 1's two rows x two tiles
-    // (AL3D_FRAG_SHAPE=0 for A/B).  Same bits; the nine `<0>` launches of the neck 1,670 -> 1,600 us, bench +1.6 % same box
+    // wave shape: 2 (default, round 5) = four image rows x ONE 32-channel tile per wave, the next chunk's halo halves in their
+    // own registers (requested at taps 0 / 1, stored at taps 4 / 5); 1 = the same wave shape with the halves sharing two registers
+    // (requested at 0 / 3, stored at 2 / 5); 0 = round 1's two rows x two tiles (AL3D_FRAG_SHAPE=0|1 for A/B).  Same bits; the
+    // nine `<0>` launches of the neck: 1,670 (shape 0) -> 1,607 (1) -> 1,597 us (2) on one box
     static int shape = -1;
-    if (shape < 0) { const char* e = getenv("AL3D_FRAG_SHAPE"); shape = e ? atoi(e) != 0 : 1; }
-    if (shape) {
+    if (shape < 0) { const char* e = getenv("AL3D_FRAG_SHAPE"); shape = e ? atoi(e) : 2; }
+    if (shape == 2) {
+        if (io & SP_IO_OUT_PAIR) hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<2, 2>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+        else if (direct || !vec_ok) hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<1, 2>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<0, 2>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    }
+    else if (shape) {
         if (io & SP_IO_OUT_PAIR) hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<2, 1>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
         else if (direct || !vec_ok) hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<1, 1>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((conv3x3_f16x3_frag_kernel<0, 1>), dim3(f3_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
