@@ -10,6 +10,7 @@
 //                        kernels' halo pieces; 128 / 256 / 512 B: whole rows of 32 / 64 / 128 channels)
 //   frag32               lane (r, h) reads 32 B of its own 512-byte row per step (sp_conv_wave2's fragment-shaped gather)
 //   dma<0> / dma<64> / dma<128> / dma<256>   global_load_lds_dwordx4 (LDS-DMA): coalesced 1 KiB pieces; 4 / 8 / 16 lanes per segment
+//   walk64<1> / <0>      the dense kernels' K loop: 64-byte pieces of 2 KiB pixel records, chunk after chunk (LDS-DMA / registers)
 //   x3_sector            one 12-byte dwordx3 probe per 64-byte sector (sp_table_rows27's lookups): 12 of 64 bytes used
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -99,6 +100,35 @@ __global__ __launch_bounds__(256) void dma(const char* __restrict__ buf, int64_t
     if (slot[wave][lane] == 77) out[0] = 1.f;
 }
 
+// The dense kernels' K loop: a wave owns 16 consecutive 2 KiB pixel records and walks them 64 bytes (one 16-channel chunk) per
+// step, 4 lanes per piece, with the step time of a real launch between two chunks (s_sleep): both halves of every 128-byte
+// line ARE fetched, a step apart.  DMA = 1: global_load_lds (conv2d_f16x3_dma2_kernel), 0: registers (the 3x3 halo loads).
+template <int DMA>
+__global__ __launch_bounds__(256) void walk64(const char* __restrict__ buf, int64_t bytes, float* out)
+{
+    __shared__ __attribute__((aligned(1024))) char slot[4][4096];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ngroups = bytes / (16 * 2048), nw = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
+    float4 acc = make_float4(0, 0, 0, 0);
+    int q = 0;
+    for (int64_t g = w0; g < ngroups; g += nw) {
+        const char* row = buf + (g * 16 + (lane >> 2)) * 2048 + (lane & 3) * 16;
+        for (int c = 0; c < 32; ++c) {
+            if (DMA) {
+                __builtin_amdgcn_global_load_lds((gbl_void*)(row + c * 64), (lds_void*)(slot[wave] + (q & 3) * 1024), 16, 0, 0);
+                ++q;
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(row + c * 64);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            __builtin_amdgcn_s_sleep(30);                     // ~2k cycles: a step of the real kernels
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DMA) { if (slot[wave][lane] == 77) out[0] = 1.f; }
+    else sink(acc, out);
+}
+
 typedef int i32x3 __attribute__((ext_vector_type(3)));
 __global__ __launch_bounds__(256) void x3_sector(const char* __restrict__ buf, int64_t nsect, int64_t mult, float* out)
 {
@@ -136,6 +166,8 @@ int main()
         hipLaunchKernelGGL(dma<64>, dim3(grid), dim3(256), 0, 0, (const char*)buf, bytes, mult, out);
         hipLaunchKernelGGL(dma<128>, dim3(grid), dim3(256), 0, 0, (const char*)buf, bytes, mult, out);
         hipLaunchKernelGGL(dma<256>, dim3(grid), dim3(256), 0, 0, (const char*)buf, bytes, mult, out);
+        hipLaunchKernelGGL(walk64<1>, dim3(grid), dim3(256), 0, 0, (const char*)buf, bytes, out);
+        hipLaunchKernelGGL(walk64<0>, dim3(grid), dim3(256), 0, 0, (const char*)buf, bytes, out);
         hipLaunchKernelGGL(x3_sector, dim3(grid), dim3(256), 0, 0, (const char*)buf, bytes / 64, mult, out);
         CHECK(hipDeviceSynchronize());
     }

@@ -94,10 +94,14 @@ def algorithmic_from_bench_line(path):
 # the bandwidth (2.8 against 5.6-6.0 TB/s); a 32-byte segment or a 12-byte probe fetches (and counts) a whole 64-byte sector.
 # (kernel-name regex, factor, the loader shape of the kernel's dominant HBM read) -- first match wins:
 FETCH_FACTORS = [
-    (r"^conv3x3_f16x3_frag_kernel|^conv3x3_f16x3_halo_kernel|^conv3x3_f16x3_wino", 1.0,
-     "activations as 64-byte halo pieces (16 channels of a pixel per K chunk); weights from L2"),
-    (r"^conv2d_f16x3_dma2_kernel|^conv2d_f16x3_dma_kernel|^conv2d_f16x3_kernel|^conv2d_f16x3_bstream", 1.0,
-     "A operand as 64-byte pieces per (pixel, 16-channel chunk), by LDS-DMA or registers; weights from L2"),
+    # walk64 in the calibration: 64-byte pieces of a pixel record fetched chunk after chunk -- both halves of every 128-byte line
+    # ARE fetched, a step apart, and the counter then reads 0.51 of the bytes, like any whole-line loader (only segments whose
+    # other half is never touched count 1.0).  An earlier version of this table took the dense kernels for "isolated 64-byte
+    # segments" (factor 1); the fused head's A operand alone (4.3 GB mandatory against 2.4 GB counted) shows that was wrong
+    (r"^conv3x3_f16x3_frag_kernel|^conv3x3_f16x3_halo_kernel|^conv3x3_f16x3_wino", 2.0,
+     "activations as 64-byte halo pieces walking whole pixel records chunk by chunk (walk64): whole lines; weights from L2"),
+    (r"^conv2d_f16x3_dma2_kernel|^conv2d_f16x3_dma_kernel|^conv2d_f16x3_kernel|^conv2d_f16x3_bstream", 2.0,
+     "A operand as 64-byte pieces walking whole pixel records chunk by chunk (walk64), by LDS-DMA or registers: whole lines"),
     (r"^sp_conv_r16_kernel", 2.0, "contiguous index ranges of 64-byte rows, 16 B per lane coalesced: whole lines"),
     (r"^sp_conv_\w+<16, ", 1.0, "gathered 64-byte rows (16 channels)"),
     (r"^sp_conv_(wave2|glds|rng|blk)_kernel", 2.0, "gathered rows of 128 / 256 / 512 bytes: whole lines"),
@@ -136,7 +140,8 @@ def hbm(fdb, wdb, out, note, bench_line=None):
             entry["fetch_factor"], entry["loader_shape"] = fac, shape
             entry["hbm_mb_corrected"] = round(fac * f_mb + w_mb, 2)
             entry["basis"] = ("fetch_factor by loader shape, calibrated on this hardware (profiles/r05_fetch_size_calibration.json: "
-                              "loaders covering whole 128-byte lines count 0.500 of their bytes, isolated 64-byte segments 1.000)")
+                              "loaders that end up covering whole 128-byte lines -- at once or chunk after chunk -- count 0.50-0.51 of their bytes, "
+                              "64-byte segments whose other half is never touched 1.000)")
         if a:
             entry["algorithmic_mb"] = round(a, 2)
             entry["ratio_as_counted"] = round(raw / a, 3)
