@@ -233,7 +233,9 @@ class ConvTimer:
             if not os.path.exists(pmc):      # PMC passes are separate runs (rocprofv3 --pmc); see DESIGN.md
                 continue
             try:
-                rec = json.load(open(pmc)).get(out["kernel"])
+                recs = json.load(open(pmc))
+                # the counter file names the instantiation ("...<0, 2>"); the line names the family member ("...<0>")
+                rec = recs.get(out["kernel"]) or next((v for k, v in recs.items() if k.startswith(out["kernel"][:-1] + ",")), None)
                 if rec:
                     out["traffic"] = round(rec["hbm_mb_corrected"] * 1e6)
                     out["traffic_detail"] = {k: rec[k] for k in ("fetch_mb_raw", "fetch_mb_x2", "write_mb", "launches",

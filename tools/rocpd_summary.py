@@ -82,7 +82,7 @@ def algorithmic_from_bench_line(path):
         # SECOND neck at 128 x 128 / 64 x 64 (rpn.py:66-113), f32 pixels: in + out bytes of the nine f32-writing 3x3 launches
         px1, px2 = 128 * 128 * 4.0 * frames / 1e6, 64 * 64 * 4.0 * frames / 1e6
         mix = [px1 * (256 + 128)] + [px1 * (128 + 128)] * 4 + [px2 * (256 + 256)] * 4
-        out["conv3x3_f16x3_frag_kernel<0>"] = sum(mix) / len(mix)
+        out["conv3x3_f16x3_frag_kernel<0"] = sum(mix) / len(mix)      # <0> / <0, SHAPE>: the f32-writing launches
     return out
 
 
