@@ -52,6 +52,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// AL3D_F3_MAP=band (default) | rr: see f3_tile_of_block
+static inline int f3_map_default()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AL3D_F3_MAP"); v = !(e && e[0] == 'r'); }
+    return v;
+}
+
 struct ConvF3Params {
     const float* in;        // [B, H, W, Cin] f32
     const _Float16* wgt;    // [2][Cout][taps][Cin] f16 planes (wh, wl)
@@ -65,6 +73,7 @@ struct ConvF3Params {
     int64_t plane;          // elements per weight plane = Cout * taps * Cin
     float* gap;             // optional [B][gap_parts][ldc]: per-workgroup channel sums of the stored values (fused GAP)
     int gap_parts;
+    int xmap = f3_map_default();   // workgroup -> (pixel tile, column block) order, see f3_tile_of_block
     int io = 0;             // row formats of in / out (sp_rows.h: bit 0 = in pair pixels, bit 1 = write pair pixels); DMA kernel only
 };
 
@@ -72,8 +81,20 @@ struct ConvF3Params {
 // so the column blocks of one pixel tile get ids that differ by 8: they run on the same XCD at
 // about the same time and the second one finds the tile's activations in L2 instead of HBM (the
 // 1x1 layers are bandwidth-bound: 42 flop per byte).  Grid = ceil(ntiles / 8) * 8 * nblocks.
+// xmap = 1 ("band", round 5): each XCD (blockIdx % 8) walks ONE contiguous band of pixel tiles in raster order, the column
+// blocks of a tile back to back -- so that the tiles resident on an XCD at any moment are spatial neighbours (the 3x3 kernels'
+// 6 x 34 halos overlap: rows shared with the tile above / below are L2 hits instead of second HBM reads) and the second column
+// block still finds its activations in L2.  xmap = 0 ("rr"): tiles dealt round-robin over the XCDs (rounds 1-4).
 __device__ __forceinline__ bool f3_tile_of_block(const ConvF3Params& p, int& tile, int& nblk)
 {
+    if (p.xmap) {
+        const int k = blockIdx.x & 7, t = blockIdx.x >> 3;
+        const int j = t / p.nblocks;
+        nblk = t - j * p.nblocks;
+        const int q8 = p.ntiles >> 3, r8 = p.ntiles & 7;
+        tile = k * q8 + (k < r8 ? k : r8) + j;
+        return j < q8 + (k < r8 ? 1 : 0);
+    }
     const int id = blockIdx.x, span = 8 * p.nblocks;
     const int grp = id / span, rem = id - grp * span;
     nblk = rem >> 3;
