@@ -315,6 +315,13 @@ class _SparseEncoderBase(nn.Module):
                     D.check_raster_status(raster_status)
                     raster_status = None
                 ocoords = ocoords[:n_out]
+                if not blocked and n_out > 0 and nxt is not None and nxt["kind"] == "subm" and \
+                        int(np.prod(nxt["mod"].kernel_size)) == 27 and nxt["mod"].out_channels in D.MASK_SORT:
+                    # rows of the new level grouped by tap mask inside windows of raster rows: more whole-tile tap skips
+                    sorted_coords = torch.empty_like(ocoords)
+                    lib.call("al3d_sp_mask_window_sort", _ptr(ocoords), n_out, batch_size, olv.D, olv.H, olv.W, _ptr(olv.grid),
+                             D.MASK_SORT_WINDOW, _ptr(sorted_coords), st)
+                    ocoords = sorted_coords
                 used.append((olv, ocoords, n_out))
                 if tiled:
                     pitch = lib.load().al3d_sp_table_pitch(n_out)

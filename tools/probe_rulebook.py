@@ -59,3 +59,13 @@ for name, coords, shape in levels:
     for tag, key in (("mask-sort", mask), ("face6 bkt", fkey), ("popcount", pop), ("pop,mask", pop * (1 << 27) + mask)):
         perm = torch.argsort(key, stable=True)
         stats(nbr[:, perm], tag)
+
+    # the same mask sort inside WINDOWS of consecutive raster rows (keeps a tile's rows spatial neighbours): executed fraction by window size
+    nbr_r = table(c[torch.argsort(((c[:, 0].long() * D + c[:, 1]) * H + c[:, 2]) * W + c[:, 3])].contiguous())
+    valid_r = (nbr_r >= 0)
+    mask_r = (valid_r.long() * w).sum(0)
+    for win in (64, 128, 256, 512, 1024, 4096):
+        idx = torch.arange(n, device=dev)
+        key = (idx // win) * (1 << 28) + mask_r
+        stats(nbr_r[:, torch.argsort(key, stable=True)], f"mask/w{win}")
+        # cheaper key: popcount of the mask's three kz groups + ky groups (what makes whole (kz,ky) groups live)
