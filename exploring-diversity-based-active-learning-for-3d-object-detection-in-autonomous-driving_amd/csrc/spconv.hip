@@ -382,55 +382,73 @@ __global__ void sp_down_table_tiles_kernel(const int* __restrict__ coords_out, i
 // plane, i.e. still spatial neighbours for the L2) are re-ordered by their own 27-bit neighbour mask: rows that lack the same
 // taps end up in the same tiles, and whole-tile tap skips fire more often (level 3, measured on the bench's frames: 0.765 ->
 // 0.687 executed at W = 256, 0.669 at W = 1024; the unreachable optimum, a sort over the whole batch, is 0.601).
-// One workgroup per window: masks by the nine 3-cell probes of sp_table_rows27_kernel, a bitonic sort of (mask, position)
-// keys in LDS (stable, deterministic), then coords_out[base + j] = coords_in[base + key_j.position] and the level's index grid
-// is renumbered in place (concurrent windows only test grid cells for >= 0, which renumbering keeps true).
-template <int W>
-__global__ __launch_bounds__(256) void sp_mask_window_sort_kernel(const int* __restrict__ coords, int n, SpDims g,
-                                                                  int* __restrict__ grid, int* __restrict__ coords_out)
+// Two passes: the masks, one thread per row (the nine 3-cell probes of sp_table_rows27_kernel); then one workgroup per window: a
+// bitonic sort of (mask, position) keys in LDS (stable, deterministic), coords_out[base + j] = coords_in[base + key_j.position]
+// and the level's index grid renumbered in place.  (A first form did both in one 256-thread workgroup per window: 0.74 ms per
+// level at W = 8192 -- the probes of 32 rows per thread in sequence; split: the probes run at full occupancy.)
+// pass 1: one thread per row, its 27-bit neighbour mask (the probes of the table kernels, without the tables)
+__global__ __launch_bounds__(256) void sp_row_masks_kernel(const int* __restrict__ coords, int n, SpDims g,
+                                                           const int* __restrict__ grid, unsigned* __restrict__ masks)
 {
-    constexpr int R = W / 256;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)i);
+    const int xc = c.w - 1 < 0 ? 0 : (c.w - 1 > g.W - 3 ? g.W - 3 : c.w - 1);      // three cells at a clamped position
+    const int shift = c.w - 1 - xc;                                                // (W >= 3 is checked by the entry)
+    int v[9][3];
+    bool ok[9];
+#pragma unroll
+    for (int kzy = 0; kzy < 9; ++kzy) {
+        const int z = c.y + kzy / 3 - 1, y = c.z + kzy % 3 - 1;
+        ok[kzy] = z >= 0 && z < g.D && y >= 0 && y < g.H;
+        const int* p = grid + (ok[kzy] ? sp_cell(g, c.x, z, y, xc) : 0);           // unconditional loads: nine independent probes
+        v[kzy][0] = p[0]; v[kzy][1] = p[1]; v[kzy][2] = p[2];
+    }
+    unsigned mask = 0u;
+#pragma unroll
+    for (int kzy = 0; kzy < 9; ++kzy)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int x = c.w + kx - 1, idx = kx + shift;
+            const int val = idx <= 0 ? v[kzy][0] : (idx == 1 ? v[kzy][1] : v[kzy][2]);
+            if (ok[kzy] && x >= 0 && x < g.W && val >= 0) mask |= 1u << (kzy * 3 + kx);
+        }
+    masks[i] = mask;
+}
+
+// pass 2: one 1024-thread workgroup per window: bitonic sort of (mask, position) keys in LDS, then the permuted coords and the
+// renumbered grid cells
+template <int W>
+__global__ __launch_bounds__(1024) void sp_mask_window_sort_kernel(const int* __restrict__ coords, int n, SpDims g,
+                                                                   const unsigned* __restrict__ masks,
+                                                                   int* __restrict__ grid, int* __restrict__ coords_out)
+{
+    constexpr int R = W / 1024;
     __shared__ unsigned long long key[W];
     const int base = blockIdx.x * W;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int loc = threadIdx.x + 256 * r, i = base + loc;
-        unsigned long long kv = ~0ull;                                  // rows past n: stay at the window's end
-        if (i < n) {
-            const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)i);
-            unsigned mask = 0u;
-#pragma unroll
-            for (int kzy = 0; kzy < 9; ++kzy) {
-                const int z = c.y + kzy / 3 - 1, y = c.z + kzy % 3 - 1;
-                if (z < 0 || z >= g.D || y < 0 || y >= g.H) continue;
-                const int64_t line = sp_cell(g, c.x, z, y, 0);
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int x = c.w + kx - 1;
-                    if (x >= 0 && x < g.W && grid[line + x] >= 0) mask |= 1u << (kzy * 3 + kx);
-                }
-            }
-            kv = ((unsigned long long)mask << 16) | (unsigned)loc;
-        }
-        key[loc] = kv;
+        const int loc = threadIdx.x + 1024 * r, i = base + loc;
+        key[loc] = i < n ? (((unsigned long long)masks[i] << 16) | (unsigned)loc) : ~0ull;      // rows past n: stay at the end
     }
     __syncthreads();
+    // W / 2 compare-exchanges per step, W / 2048 per thread, every lane busy: pair p -> (t, t + j) with t = 2 j (p / j) + p % j
     for (int k = 2; k <= W; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int t = threadIdx.x + 256 * r, o = t ^ j;
-                if (o > t) {
-                    const unsigned long long a = key[t], b2 = key[o];
-                    const bool up = (t & k) == 0;
-                    if ((a > b2) == up) { key[t] = b2; key[o] = a; }
-                }
+            for (int r = 0; r < (R > 1 ? R / 2 : 1); ++r) {
+                const int p = threadIdx.x + 1024 * r;
+                if (R == 1 && p >= W / 2) break;
+                const int t = ((p & ~(j - 1)) << 1) | (p & (j - 1)), o = t + j;
+                const unsigned long long a = key[t], b2 = key[o];
+                const bool up = (t & k) == 0;
+                if ((a > b2) == up) { key[t] = b2; key[o] = a; }
             }
             __syncthreads();
         }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int loc = threadIdx.x + 256 * r, i = base + loc;
+        const int loc = threadIdx.x + 1024 * r, i = base + loc;
         if (i >= n) continue;
         const int src = base + (int)(key[loc] & 0xffffu);
         const int4 c = *reinterpret_cast<const int4*>(coords + 4 * (int64_t)src);
@@ -439,22 +457,33 @@ __global__ __launch_bounds__(256) void sp_mask_window_sort_kernel(const int* __r
     }
 }
 
-extern "C" int al3d_sp_mask_window_sort(const int* coords, int n, int B, int D, int H, int W, int* grid, int window,
-                                        int* coords_out, void* stream)
+extern "C" int64_t al3d_sp_mask_window_sort_workspace_bytes(int n)
 {
-    AL3D_REQUIRE(n >= 0 && B >= 1 && D >= 1 && H >= 1 && W >= 1, "al3d_sp_mask_window_sort: bad shape");
-    AL3D_REQUIRE(window == 256 || window == 1024 || window == 4096 || window == 8192 || window == 16384, "al3d_sp_mask_window_sort: window must be 256, 1024, 4096, 8192 or 16384 (got %d)", window);
+    return al3d_align((int64_t)(n > 0 ? n : 1) * 4, 256);
+}
+
+extern "C" int al3d_sp_mask_window_sort(const int* coords, int n, int B, int D, int H, int W, int* grid, int window,
+                                        int* coords_out, void* workspace, void* stream)
+{
+    AL3D_REQUIRE(n >= 0 && B >= 1 && D >= 1 && H >= 1 && W >= 3, "al3d_sp_mask_window_sort: bad shape (W >= 3)");
+    AL3D_REQUIRE(window == 1024 || window == 4096 || window == 8192 || window == 16384,
+                 "al3d_sp_mask_window_sort: window must be 1024, 4096, 8192 or 16384 (got %d)", window);
     if (n == 0) return AL3D_OK;
-    AL3D_REQUIRE(coords && grid && coords_out && coords != coords_out, "al3d_sp_mask_window_sort: null pointer / in-place call");
+    AL3D_REQUIRE(coords && grid && coords_out && workspace && coords != coords_out,
+                 "al3d_sp_mask_window_sort: null pointer / in-place call");
     AL3D_REQUIRE(((uintptr_t)coords & 15) == 0 && ((uintptr_t)coords_out & 15) == 0,
                  "al3d_sp_mask_window_sort: coords must be 16-byte aligned");
     SpDims g = {B, D, H, W};
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* masks = (unsigned*)workspace;
+    hipLaunchKernelGGL(sp_row_masks_kernel, dim3((unsigned)al3d_cdiv(n, 256)), dim3(256), 0, s, coords, n, g, grid, masks);
     const unsigned blocks = (unsigned)al3d_cdiv(n, window);
-    if (window == 256) hipLaunchKernelGGL(sp_mask_window_sort_kernel<256>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, coords, n, g, grid, coords_out);
-    else if (window == 1024) hipLaunchKernelGGL(sp_mask_window_sort_kernel<1024>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, coords, n, g, grid, coords_out);
-    else if (window == 4096) hipLaunchKernelGGL(sp_mask_window_sort_kernel<4096>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, coords, n, g, grid, coords_out);
-    else if (window == 8192) hipLaunchKernelGGL(sp_mask_window_sort_kernel<8192>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, coords, n, g, grid, coords_out);
-    else hipLaunchKernelGGL(sp_mask_window_sort_kernel<16384>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, coords, n, g, grid, coords_out);
+#define MS_LAUNCH(WV) hipLaunchKernelGGL(sp_mask_window_sort_kernel<WV>, dim3(blocks), dim3(1024), 0, s, coords, n, g, masks, grid, coords_out)
+    if (window == 1024) MS_LAUNCH(1024);
+    else if (window == 4096) MS_LAUNCH(4096);
+    else if (window == 8192) MS_LAUNCH(8192);
+    else MS_LAUNCH(16384);
+#undef MS_LAUNCH
     AL3D_CHECK_LAUNCH("sp_mask_window_sort_kernel");
     return AL3D_OK;
 }

@@ -271,13 +271,13 @@ if _os.environ.get("AL3D_BLK_PAIRS") is not None:
 
 # Tap-mask row order (al3d_sp_mask_window_sort): levels whose 27-tap submanifold layers have these output widths get their rows
 # re-numbered by neighbour mask inside windows of MASK_SORT_WINDOW raster rows, so that the rows of a 32-row tile lack the same
-# taps (the per-tap gather kernels of the 64- and 128-channel levels execute 8-12 % fewer (tile, tap) pairs: 64 -> 64 layers
-# -11 %, 128 -> 128 -5 %, bench +1.0..1.4 % at windows of 4096-8192; level 1's range-gather kernel needs raster order: +9 % slower
-# there).  AL3D_MASK_SORT: e.g. "64,128" / "" for none; AL3D_MASK_SORT_WINDOW: 256 | 1024 | 4096 | 8192 | 16384
+# taps (the per-tap gather kernels of the 64- and 128-channel levels execute 10-15 % fewer (tile, tap) pairs: 64 -> 64 layers
+# -11 %, 128 -> 128 -10 %, bench +2.3 % at windows of 16384; level 1's range-gather kernel needs raster order: +9 % slower
+# there).  AL3D_MASK_SORT: e.g. "64,128" / "" for none; AL3D_MASK_SORT_WINDOW: 1024 | 4096 | 8192 | 16384
 MASK_SORT = {64, 128}
 if _os.environ.get("AL3D_MASK_SORT") is not None:
     MASK_SORT = {int(v) for v in _os.environ["AL3D_MASK_SORT"].split(",") if v}
-MASK_SORT_WINDOW = int(_os.environ.get("AL3D_MASK_SORT_WINDOW", "8192"))
+MASK_SORT_WINDOW = int(_os.environ.get("AL3D_MASK_SORT_WINDOW", "16384"))
 
 
 BLK_ORDER_ONLY = _os.environ.get("AL3D_BLK_ORDER_ONLY", "0") == "1"   # dev: column order for these pairs' levels, old kernels

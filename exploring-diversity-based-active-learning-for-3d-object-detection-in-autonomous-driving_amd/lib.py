@@ -64,7 +64,8 @@ SIGNATURES = {
     "al3d_sp_down_sites_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "al3d_sp_down_sites": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
                                    c_p, c_int, c_p, c_p]),
-    "al3d_sp_mask_window_sort": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p]),
+    "al3d_sp_mask_window_sort_workspace_bytes": (c_i64, [c_int]),
+    "al3d_sp_mask_window_sort": (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_p]),
     "al3d_sp_down_sites_blocked_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "al3d_sp_down_sites_blocked": (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p,
                                            c_p, c_int, c_p, c_p]),

@@ -319,8 +319,9 @@ class _SparseEncoderBase(nn.Module):
                         int(np.prod(nxt["mod"].kernel_size)) == 27 and nxt["mod"].out_channels in D.MASK_SORT:
                     # rows of the new level grouped by tap mask inside windows of raster rows: more whole-tile tap skips
                     sorted_coords = torch.empty_like(ocoords)
+                    msw = torch.empty(lib.load().al3d_sp_mask_window_sort_workspace_bytes(n_out), dtype=torch.uint8, device=dev)
                     lib.call("al3d_sp_mask_window_sort", _ptr(ocoords), n_out, batch_size, olv.D, olv.H, olv.W, _ptr(olv.grid),
-                             D.MASK_SORT_WINDOW, _ptr(sorted_coords), st)
+                             D.MASK_SORT_WINDOW, _ptr(sorted_coords), _ptr(msw), st)
                     ocoords = sorted_coords
                 used.append((olv, ocoords, n_out))
                 if tiled:

@@ -259,12 +259,14 @@ int al3d_sp_down_sites_blocked(const int* coords_in, int n_in, const int* ksize,
                                const int* pad, int B, int OD, int OH, int OW, int* grid_out,
                                int* coords_out, int* counter, int cap, void* workspace, void* stream);
 /* Re-numbers the rows of a level (coords in raster order, grid[cell] = row, as al3d_sp_down_sites leaves them) inside windows of
- * `window` (256 | 1024 | 4096 | 8192 | 16384) consecutive rows by their own 27-tap submanifold neighbour mask, so that the rows of a 32-row tile tend to
- * lack the SAME taps and the conv kernels' whole-tile tap skip fires more often (the order of a level's rows is free: spconv's
- * own, indice.cu's atomics, is arbitrary).  coords_out [n, 4] = the permuted coords (must not alias coords); grid is renumbered in
- * place.  Call before any table of the level is built.  Reference: spconv_ops.h:51-120 (getIndicePair). */
+ * `window` (1024 | 4096 | 8192 | 16384) consecutive rows by their own 27-tap submanifold neighbour mask, so that the rows of a
+ * 32-row tile tend to lack the SAME taps and the conv kernels' whole-tile tap skip fires more often (the order of a level's rows
+ * is free: spconv's own, indice.cu's atomics, is arbitrary).  coords_out [n, 4] = the permuted coords (must not alias coords);
+ * grid is renumbered in place; workspace >= al3d_sp_mask_window_sort_workspace_bytes(n).  Call before any table of the level
+ * is built.  Reference: spconv_ops.h:51-120 (getIndicePair). */
+int64_t al3d_sp_mask_window_sort_workspace_bytes(int n);
 int al3d_sp_mask_window_sort(const int* coords, int n, int B, int D, int H, int W, int* grid, int window,
-                             int* coords_out, void* stream);
+                             int* coords_out, void* workspace, void* stream);
 /* ... then its rulebook from the input level's grid */
 int al3d_sp_down_table(const int* coords_out, int n_out, const int* ksize, const int* stride,
                        const int* pad, int B, int ID, int IH, int IW, const int* grid_in, int* nbr,

@@ -26,7 +26,7 @@ def _masks(coords, batch, shape):
     return m
 
 
-@pytest.mark.parametrize("window", [256, 1024, 4096, 8192, 16384])
+@pytest.mark.parametrize("window", [1024, 4096, 8192, 16384])
 @pytest.mark.parametrize("shape,batch,n", [([9, 40, 37], 3, 6001), ([5, 21, 19], 1, 40), ([11, 64, 48], 2, 3000),
                                            ([21, 100, 90], 2, 40000)])
 def test_mask_window_sort_is_a_stable_sort_by_mask_inside_windows(shape, batch, n, window):
@@ -41,7 +41,8 @@ def test_mask_window_sort_is_a_stable_sort_by_mask_inside_windows(shape, batch, 
     c = _t(coords)
     lib.call("al3d_sp_scatter_index", _ptr(c), n, batch, D_, H_, W_, _ptr(grid), 1, _stream())
     out = torch.full((n, 4), -9, dtype=torch.int32, device=DEV)
-    lib.call("al3d_sp_mask_window_sort", _ptr(c), n, batch, D_, H_, W_, _ptr(grid), window, _ptr(out), _stream())
+    ws = torch.empty(lib.load().al3d_sp_mask_window_sort_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    lib.call("al3d_sp_mask_window_sort", _ptr(c), n, batch, D_, H_, W_, _ptr(grid), window, _ptr(out), _ptr(ws), _stream())
     got = out.cpu().numpy()
     masks = _masks(coords, batch, shape)
     want = np.empty_like(coords)
@@ -58,14 +59,15 @@ def test_mask_window_sort_rejects_bad_arguments():
     from al3d import lib
     from al3d.selector_ops import _ptr, _stream
     c = torch.zeros((4, 4), dtype=torch.int32, device=DEV)
-    g = torch.full((8,), -1, dtype=torch.int32, device=DEV)
+    g = torch.full((18,), -1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(256, dtype=torch.uint8, device=DEV)
     with pytest.raises(lib.Al3dError, match="window"):
-        lib.call("al3d_sp_mask_window_sort", _ptr(c), 4, 1, 2, 2, 2, _ptr(g), 100, _ptr(torch.empty_like(c)), _stream())
+        lib.call("al3d_sp_mask_window_sort", _ptr(c), 4, 1, 2, 3, 3, _ptr(g), 100, _ptr(torch.empty_like(c)), _ptr(ws), _stream())
     with pytest.raises(lib.Al3dError, match="in-place"):
-        lib.call("al3d_sp_mask_window_sort", _ptr(c), 4, 1, 2, 2, 2, _ptr(g), 256, _ptr(c), _stream())
+        lib.call("al3d_sp_mask_window_sort", _ptr(c), 4, 1, 2, 3, 3, _ptr(g), 1024, _ptr(c), _ptr(ws), _stream())
 
 
-@pytest.mark.parametrize("window", [256, 8192])
+@pytest.mark.parametrize("window", [1024, 16384])
 @pytest.mark.parametrize("widths", [{128}, {32, 64, 128}])
 def test_encoder_on_mask_sorted_levels_equals_the_raster_encoder(widths, window):
     """The whole encoder with levels re-numbered by tap mask == the encoder on raster levels, bit for bit through the dense BEV
