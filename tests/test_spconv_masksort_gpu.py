@@ -93,3 +93,42 @@ def test_encoder_on_mask_sorted_levels_equals_the_raster_encoder(widths, window)
         D.MASK_SORT, D.MASK_SORT_WINDOW = saved
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
     assert np.array_equal(outs[0].view(np.int32), outs[1].view(np.int32))
+
+
+def test_full_size_detector_is_bit_identical_with_and_without_the_mask_sort():
+    """BASELINE configs[1] size: three synthetic 10-sweep frames through the shipped detector (voxelizer, encoder, neck, head)
+    with levels 2-3 grouped by tap mask and in raster order: the dense BEV map, the embedding and the head's raw output are
+    the same bits -- every kernel sums a row's taps in tap order, whatever the row's number."""
+    import os
+    from al3d import detector_ops as D, synthetic
+    from al3d.datasets import DeviceSweepLoader, PoolFrames, generate_task_anchors
+    from al3d.models import build_detector
+    from al3d.utils import Config
+    from test_detector_oracle import G
+    cfg = Config.fromfile(os.path.join(os.path.dirname(G), "..", "examples", "active", "cbgs_spatial_temporal_feature.py"))
+    model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    synthetic.seeded_init_(model, seed=0)
+    model = model.to(DEV).eval()
+    anchors = generate_task_anchors(cfg.tasks, cfg.target_assigner.anchor_generators, [1, 128, 128])
+    pool = PoolFrames.from_synthetic(3, DEV, num_base=3)
+    outs = []
+    saved = set(D.MASK_SORT)
+    try:
+        for ms in (set(), {64, 128}):
+            D.MASK_SORT = ms
+            ex = next(iter(DeviceSweepLoader(pool, cfg.voxel_generator, anchors, batch_size=3, device=DEV)))
+            with torch.no_grad():
+                bev, _ = model.backbone(ex["voxel_features"], ex["coordinates"], 3, ex["shape"][0])
+                dets, middle = model(ex, return_loss=False, estimate=True)
+            emb = middle[-1].mean(-1).mean(-1) if hasattr(middle[-1], "mean") else None
+            outs.append((bev.cpu().numpy(), None if emb is None else emb.cpu().numpy(),
+                         [d["box3d_lidar"].cpu().numpy() for d in dets], [d["scores"].cpu().numpy() for d in dets]))
+    finally:
+        D.MASK_SORT = saved
+    a, b = outs
+    assert np.abs(a[0]).max() > 0
+    assert np.array_equal(a[0].view(np.int32), b[0].view(np.int32))
+    if a[1] is not None:
+        assert np.array_equal(a[1].view(np.int32), b[1].view(np.int32))
+    for x, y in zip(a[2] + a[3], b[2] + b[3]):
+        assert np.array_equal(x.view(np.int32), y.view(np.int32))
