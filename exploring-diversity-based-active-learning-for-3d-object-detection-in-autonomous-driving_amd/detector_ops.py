@@ -278,6 +278,9 @@ MASK_SORT = {64, 128}
 if _os.environ.get("AL3D_MASK_SORT") is not None:
     MASK_SORT = {int(v) for v in _os.environ["AL3D_MASK_SORT"].split(",") if v}
 MASK_SORT_WINDOW = int(_os.environ.get("AL3D_MASK_SORT_WINDOW", "16384"))
+MASK_SORT_WINDOWS = {}         # per width, e.g. AL3D_MASK_SORT_WINDOWS="64:4096,128:16384" (else MASK_SORT_WINDOW for all)
+if _os.environ.get("AL3D_MASK_SORT_WINDOWS"):
+    MASK_SORT_WINDOWS = {int(a): int(b) for a, b in (t.split(":") for t in _os.environ["AL3D_MASK_SORT_WINDOWS"].split(",") if t)}
 
 
 BLK_ORDER_ONLY = _os.environ.get("AL3D_BLK_ORDER_ONLY", "0") == "1"   # dev: column order for these pairs' levels, old kernels

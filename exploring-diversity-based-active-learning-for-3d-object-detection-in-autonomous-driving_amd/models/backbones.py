@@ -321,7 +321,7 @@ class _SparseEncoderBase(nn.Module):
                     sorted_coords = torch.empty_like(ocoords)
                     msw = torch.empty(lib.load().al3d_sp_mask_window_sort_workspace_bytes(n_out), dtype=torch.uint8, device=dev)
                     lib.call("al3d_sp_mask_window_sort", _ptr(ocoords), n_out, batch_size, olv.D, olv.H, olv.W, _ptr(olv.grid),
-                             D.MASK_SORT_WINDOW, _ptr(sorted_coords), _ptr(msw), st)
+                             D.MASK_SORT_WINDOWS.get(nxt["mod"].out_channels, D.MASK_SORT_WINDOW), _ptr(sorted_coords), _ptr(msw), st)
                     ocoords = sorted_coords
                 used.append((olv, ocoords, n_out))
                 if tiled:
